@@ -1,0 +1,206 @@
+"""ctypes binding of include/cfear_hip.h (no torch types cross this boundary)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_LIB = None
+CFEAR_MAX_OUTER = 64
+
+
+class CfearError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """cfear_params (include/cfear_hip.h)."""
+    _fields_ = [
+        ("z_min", C.c_float), ("range_res", C.c_float), ("min_distance", C.c_float),
+        ("k_strongest", C.c_int32),
+        ("res", C.c_double), ("downsample_factor", C.c_double),
+        ("weight_intensity", C.c_int32), ("cost", C.c_int32), ("loss", C.c_int32),
+        ("weight_opt", C.c_int32),
+        ("loss_limit", C.c_double), ("covar_scale", C.c_double), ("regularization", C.c_double),
+        ("submap_scan_size", C.c_int32), ("compensate", C.c_int32), ("radar_ccw", C.c_int32),
+        ("use_keyframe", C.c_int32),
+        ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
+        ("max_itr_association", C.c_int32), ("min_itr", C.c_int32),
+        ("max_solver_iterations", C.c_int32), ("reserved0", C.c_int32),
+        ("assoc_radius", C.c_double),
+    ]
+
+
+class Cell(C.Structure):
+    _fields_ = [
+        ("mean", C.c_double * 2), ("cov", C.c_double * 3), ("normal", C.c_double * 2),
+        ("orth", C.c_double * 2), ("lambda_min", C.c_double), ("lambda_max", C.c_double),
+        ("scale", C.c_double), ("sum_intensity", C.c_double), ("avg_intensity", C.c_double),
+        ("nsamples", C.c_int32), ("valid", C.c_int32),
+    ]
+
+
+CELL_DTYPE = np.dtype([
+    ("mean", "f8", 2), ("cov", "f8", 3), ("normal", "f8", 2), ("orth", "f8", 2),
+    ("lambda_min", "f8"), ("lambda_max", "f8"), ("scale", "f8"), ("sum_intensity", "f8"),
+    ("avg_intensity", "f8"), ("nsamples", "i4"), ("valid", "i4")])
+
+
+class RegSummary(C.Structure):
+    _fields_ = [
+        ("success", C.c_int32), ("usable", C.c_int32), ("outer_iterations", C.c_int32),
+        ("num_residuals", C.c_int32), ("num_residual_blocks", C.c_int32), ("reserved", C.c_int32),
+        ("final_cost", C.c_double), ("score", C.c_double),
+        ("inner_iterations", C.c_int32 * CFEAR_MAX_OUTER), ("termination", C.c_int32 * CFEAR_MAX_OUTER),
+        ("outer_cost", C.c_double * CFEAR_MAX_OUTER), ("outer_pose", (C.c_double * 3) * CFEAR_MAX_OUTER),
+    ]
+
+
+EXPORTS = [
+    "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
+    "cfear_set_params", "cfear_synchronize", "cfear_kstrongest_device", "cfear_kstrongest_host",
+    "cfear_filter_polar", "cfear_filter_polar_device", "cfear_cloud_upload", "cfear_cloud_size",
+    "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
+    "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
+    "cfear_register", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
+    "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
+    "cfear_odometry_summary", "cfear_time_kstrongest",
+]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Loads libcfear_hip.so; raises if it is not built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CfearError("libcfear_hip.so is not built: run __graft_entry__.build() "
+                         "(python -m cfear_radarodometry_code_public_amd.build)")
+    L = C.CDLL(path)
+    vp, u8p, u32p, f32p, f64p, i32p = (C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+    sig = {
+        "cfear_version": (C.c_char_p, []),
+        "cfear_default_params": (None, [C.POINTER(Params)]),
+        "cfear_create": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.POINTER(Params), C.c_int, C.c_int]),
+        "cfear_destroy": (None, [vp]),
+        "cfear_last_error": (C.c_char_p, [vp]),
+        "cfear_set_params": (C.c_int, [vp, C.POINTER(Params)]),
+        "cfear_synchronize": (C.c_int, [vp]),
+        "cfear_kstrongest_device": (C.c_int, [vp, u8p, C.c_int, u32p]),
+        "cfear_kstrongest_host": (C.c_int, [vp, u8p, C.c_int, u32p]),
+        "cfear_filter_polar": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
+        "cfear_filter_polar_device": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
+        "cfear_cloud_upload": (C.c_int, [vp, f32p, C.c_int, C.POINTER(vp)]),
+        "cfear_cloud_size": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+        "cfear_cloud_download": (C.c_int, [vp, vp, f32p, C.c_int, C.POINTER(C.c_int)]),
+        "cfear_cloud_release": (None, [vp, vp]),
+        "cfear_compensate": (C.c_int, [vp, vp, f64p, C.c_int]),
+        "cfear_scan_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+        "cfear_scan_release": (None, [vp, vp]),
+        "cfear_scan_size": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+        "cfear_scan_download_cells": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
+        "cfear_scan_closest": (C.c_int, [vp, vp, f64p, C.c_int, C.c_double, i32p]),
+        "cfear_register": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, f64p, C.POINTER(RegSummary)]),
+        "cfear_odometry_create": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "cfear_odometry_destroy": (None, [vp, vp]),
+        "cfear_odometry_reset": (C.c_int, [vp, vp]),
+        "cfear_odometry_step_device": (C.c_int, [vp, vp, u8p]),
+        "cfear_odometry_step_host": (C.c_int, [vp, vp, u8p]),
+        "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
+        "cfear_odometry_summary": (C.c_int, [vp, vp, C.c_int, C.POINTER(RegSummary), C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int)]),
+        "cfear_time_kstrongest": (C.c_int, [vp, u8p, C.c_int, u32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the ABI is incomplete (tests/test_abi.py checks every export)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def default_params(**kw):
+    p = Params()
+    lib().cfear_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _addr(a):
+    """Device pointer (int), torch tensor (data_ptr) or numpy array -> address."""
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data
+
+
+class Context:
+    """cfear_ctx: one HIP device + stream. `stream` = raw hipStream_t handle (int) or None."""
+
+    def __init__(self, params, A, R, device=0, stream=None):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.params = params
+        self.A, self.R = int(A), int(R)
+        rc = self._L.cfear_create(C.byref(self._h), int(device), C.c_void_p(stream or 0), C.byref(params),
+                                  self.A, self.R)
+        if rc != 0:
+            self._h = None
+            raise CfearError("cfear_create failed rc=%d (is a gfx950 GPU visible?)" % rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfear_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CfearError("%s failed rc=%d: %s" % (what, rc, self._L.cfear_last_error(self._h).decode()))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_params(self, params):
+        self._check(self._L.cfear_set_params(self._h, C.byref(params)), "cfear_set_params")
+        self.params = params
+
+    def synchronize(self):
+        self._check(self._L.cfear_synchronize(self._h), "cfear_synchronize")
+
+    # ---- stage 1 ----
+    def kstrongest_host(self, polar):
+        polar = np.ascontiguousarray(polar, dtype=np.uint8)
+        if polar.ndim == 2:
+            polar = polar[None]
+        n, A, R = polar.shape
+        assert (A, R) == (self.A, self.R)
+        out = np.zeros((n, A, self.params.k_strongest), dtype=np.uint32)
+        self._check(self._L.cfear_kstrongest_host(self._h, polar.ctypes.data, n, out.ctypes.data), "cfear_kstrongest_host")
+        return out
+
+    def kstrongest_device(self, d_polar, n_scans, d_slots):
+        self._check(self._L.cfear_kstrongest_device(self._h, _addr(d_polar), int(n_scans), _addr(d_slots)),
+                    "cfear_kstrongest_device")
+
+    def time_kstrongest(self, d_polar, n_scans, d_slots, warmup, iters):
+        t = C.c_double()
+        self._check(self._L.cfear_time_kstrongest(self._h, _addr(d_polar), int(n_scans), _addr(d_slots), int(warmup),
+                                                  int(iters), C.byref(t)), "cfear_time_kstrongest")
+        return t.value

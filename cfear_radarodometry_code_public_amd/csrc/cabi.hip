@@ -1,0 +1,172 @@
+// cabi.hip -- C ABI of libcfear_hip.so: context management + stage-1 entry points.
+// Interface contract and reference citations: include/cfear_hip.h.
+#include <math.h>
+
+#include "common.h"
+
+extern "C" {
+
+const char* cfear_version(void) { return "cfear-hip 0.1 (gfx950)"; }
+
+void cfear_default_params(cfear_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->z_min = 60.f;            // radar_driver.h:40
+  p->range_res = 0.0438f;     // radar_driver.h:41
+  p->min_distance = 2.5f;     // radar_driver.h:45
+  p->k_strongest = 12;        // radar_driver.h:42
+  p->res = 3.0;               // odometrykeyframefuser.h:132
+  p->downsample_factor = 1.0; // pointnormal.cpp:5
+  p->weight_intensity = 1;    // offline_odometry.cpp:160
+  p->cost = CFEAR_COST_P2L;   // odometrykeyframefuser.h:86
+  p->loss = CFEAR_LOSS_HUBER; // odometrykeyframefuser.h:99
+  p->weight_opt = 4;          // launch/oxford/eval/params/baseline/*
+  p->loss_limit = 0.1;
+  p->covar_scale = 1.0;
+  p->regularization = 0.1;
+  p->submap_scan_size = 4;
+  p->compensate = 1;
+  p->radar_ccw = 0;
+  p->use_keyframe = 1;
+  p->min_keyframe_dist = 1.5;
+  p->min_keyframe_rot_deg = 5.0;
+  p->max_itr_association = 8;   // n_scan_normal.h:75
+  p->min_itr = 3;               // n_scan_normal.h:75
+  p->max_solver_iterations = 20; // n_scan_normal.cpp:9
+  p->assoc_radius = 2.0;        // registration.h:122
+}
+
+static int validate_params(cfear_ctx* ctx, const cfear_params* p) {
+  if (p->k_strongest < 1 || p->k_strongest > 64) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "k_strongest must be in 1..64");
+  if (!(p->range_res > 0.f)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "range_res must be > 0");
+  if (!(p->res > 0.05)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "res must be > 0.05 (odometrykeyframefuser.cpp:25)");
+  if (!(p->downsample_factor > 0)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "downsample_factor must be > 0");
+  if (p->submap_scan_size < 1 || p->submap_scan_size > 63) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "submap_scan_size must be in 1..63");
+  if (p->max_itr_association < 1 || p->max_itr_association > CFEAR_MAX_OUTER) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "max_itr_association must be in 1..64");
+  if (p->cost < 0 || p->cost > 2) return cfear_fail(ctx, CFEAR_ERR_INVALID, "unknown cost");
+  if (p->loss < 0 || p->loss > 5) return cfear_fail(ctx, CFEAR_ERR_INVALID, "unknown loss");
+  return CFEAR_OK;
+}
+
+int cfear_create(cfear_ctx** out, int device, void* stream, const cfear_params* p, int A, int R) {
+  if (!out || !p || A <= 0 || R <= 0) return CFEAR_ERR_INVALID;
+  *out = nullptr;
+  cfear_ctx* ctx = new cfear_ctx();
+  ctx->device = device;
+  int rc = validate_params(ctx, p);
+  if (rc != CFEAR_OK) { delete ctx; return rc; }
+  if (R + 27 > 16 * 1024) { delete ctx; return CFEAR_ERR_UNSUPPORTED; }
+  ctx->par = *p;
+  ctx->A = A;
+  ctx->R = R;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { delete ctx; return CFEAR_ERR_HIP; }
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CFEAR_ERR_HIP; }
+    ctx->own_stream = true;
+  }
+  if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { cfear_destroy(ctx); return CFEAR_ERR_HIP; }
+  // theta = (double(bearing + 1) / nb_azimuths) * 2 * M_PI (radar_filters.cpp:317), cos/sin by host libm
+  std::vector<double> trig(2 * (size_t)A);
+  for (int b = 0; b < A; b++) {
+    const double theta = ((double)(b + 1) / A) * 2. * M_PI;
+    trig[2 * b] = cos(theta);
+    trig[2 * b + 1] = sin(theta);
+  }
+  if (hipMalloc(&ctx->d_trig, trig.size() * sizeof(double)) != hipSuccess) { cfear_destroy(ctx); return CFEAR_ERR_NOMEM; }
+  if (hipMemcpy(ctx->d_trig, trig.data(), trig.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { cfear_destroy(ctx); return CFEAR_ERR_HIP; }
+  *out = ctx;
+  return CFEAR_OK;
+}
+
+void cfear_destroy(cfear_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_trig) (void)hipFree(ctx->d_trig);
+  if (ctx->d_polar) (void)hipFree(ctx->d_polar);
+  if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* cfear_last_error(const cfear_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cfear_set_params(cfear_ctx* ctx, const cfear_params* p) {
+  if (!ctx || !p) return CFEAR_ERR_INVALID;
+  int rc = validate_params(ctx, p);
+  if (rc != CFEAR_OK) return rc;
+  ctx->par = *p;
+  return CFEAR_OK;
+}
+
+int cfear_synchronize(cfear_ctx* ctx) {
+  if (!ctx) return CFEAR_ERR_INVALID;
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots) {
+  if (!ctx) return CFEAR_ERR_INVALID;
+  return cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+}
+
+int cfear_ensure_staging(cfear_ctx* ctx, int n_scans) {
+  const size_t pb = (size_t)n_scans * ctx->A * ctx->R + 64;
+  const size_t sb = (size_t)n_scans * ctx->A * ctx->par.k_strongest * sizeof(uint32_t);
+  if (pb > ctx->d_polar_bytes) {
+    if (ctx->d_polar) (void)hipFree(ctx->d_polar);
+    ctx->d_polar = nullptr; ctx->d_polar_bytes = 0;
+    if (hipMalloc(&ctx->d_polar, pb) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc polar staging");
+    ctx->d_polar_bytes = pb;
+  }
+  if (sb > ctx->d_slots_bytes) {
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    ctx->d_slots = nullptr; ctx->d_slots_bytes = 0;
+    if (hipMalloc(&ctx->d_slots, sb) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc slot staging");
+    ctx->d_slots_bytes = sb;
+  }
+  return CFEAR_OK;
+}
+
+int cfear_kstrongest_host(cfear_ctx* ctx, const uint8_t* h_polar, int n_scans, uint32_t* h_slots) {
+  if (!ctx || !h_polar || !h_slots || n_scans <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "kstrongest_host: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = cfear_ensure_staging(ctx, n_scans);
+  if (rc != CFEAR_OK) return rc;
+  const size_t pb = (size_t)n_scans * ctx->A * ctx->R;
+  const size_t sb = (size_t)n_scans * ctx->A * ctx->par.k_strongest * sizeof(uint32_t);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, pb, hipMemcpyHostToDevice, ctx->stream));
+  rc = cfear_launch_kstrongest(ctx, ctx->d_polar, n_scans, ctx->d_slots);
+  if (rc != CFEAR_OK) return rc;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(h_slots, ctx->d_slots, sb, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_time_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, int warmup,
+                          int iters, double* avg_seconds) {
+  if (!ctx || !avg_seconds || iters <= 0) return CFEAR_ERR_INVALID;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < warmup; i++) {
+    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+    if (rc != CFEAR_OK) return rc;
+  }
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < iters; i++) {
+    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+    if (rc != CFEAR_OK) return rc;
+  }
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_seconds = (double)ms * 1e-3 / iters;
+  return CFEAR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// common.h -- shared host-side definitions of libcfear_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cfear_hip.h"
+
+#define CFEAR_WAVE 64
+
+struct cfear_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  cfear_params par;
+  int A = 0, R = 0;
+  std::string err;
+  // per-azimuth (cos, sin) of theta=(b+1)/A*2pi computed on the host with libm so that the
+  // polar->Cartesian conversion (radar_filters.cpp:317-330) is bit-identical to a CPU run.
+  double* d_trig = nullptr;  // [A][2]
+  // staging for the host entry points
+  uint8_t* d_polar = nullptr;
+  size_t d_polar_bytes = 0;
+  uint32_t* d_slots = nullptr;
+  size_t d_slots_bytes = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // scratch for the per-call feature / registration kernels
+  void* d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  if (c) {
+    char buf[512];
+    if (e != hipSuccess)
+      snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else
+      snprintf(buf, sizeof(buf), "%s", what);
+    c->err = buf;
+  }
+  return code;
+}
+
+#define CFEAR_HIP_CHECK(ctx, call)                                            \
+  do {                                                                        \
+    hipError_t _e = (call);                                                   \
+    if (_e != hipSuccess) return cfear_fail((ctx), CFEAR_ERR_HIP, #call, _e); \
+  } while (0)
+
+// kstrongest.hip
+int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots);

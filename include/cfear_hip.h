@@ -1,0 +1,184 @@
+/*
+ * cfear_hip.h -- C ABI of the MI355X-native CFEAR hot path (libcfear_hip.so).
+ *
+ * Drop-in boundary for the per-scan path of dan11003/CFEAR_Radarodometry_code_public:
+ *   k-strongest filter -> oriented surface points -> scan-to-keyframes registration.
+ * Every entry point states the reference interface it replaces (file:line relative to the
+ * reference repository). POD only: plain pointers, sizes and opaque handles; no C++/torch types.
+ * All functions return 0 (CFEAR_OK) or a negative error code and never exit() (the reference
+ * does: pointnormal.cpp:72-75, registration.cpp:24-25). cfear_last_error() gives the text.
+ *
+ * Threading: one cfear_ctx per caller thread / per sequence (the reference classes are not
+ * re-entrant either, registration.h:104-131). All work of a context is ordered on its HIP stream.
+ */
+#ifndef CFEAR_HIP_H
+#define CFEAR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFEAR_OK 0
+#define CFEAR_ERR_INVALID (-1)     /* bad argument */
+#define CFEAR_ERR_HIP (-2)         /* HIP runtime failure */
+#define CFEAR_ERR_UNSUPPORTED (-3) /* size outside the compiled kernel range */
+#define CFEAR_ERR_EMPTY (-4)       /* empty cloud (reference: exit(0)) */
+#define CFEAR_ERR_NOMEM (-5)
+
+/* registration.h:48-60 */
+enum { CFEAR_COST_P2P = 0, CFEAR_COST_P2L = 1, CFEAR_COST_P2D = 2 };
+enum { CFEAR_LOSS_NONE = 0, CFEAR_LOSS_HUBER = 1, CFEAR_LOSS_CAUCHY = 2, CFEAR_LOSS_SOFTLONE = 3,
+       CFEAR_LOSS_COMBINED = 4, CFEAR_LOSS_TUKEY = 5 };
+
+/* Union of radarDriver::Parameters (radar_driver.h:35-48), OdometryKeyframeFuser::Parameters
+ * (odometrykeyframefuser.h:72-114) and the n_scan_normal_reg knobs (n_scan_normal.h:72-81,
+ * n_scan_normal.cpp:9, registration.h:117-122) that are on the path. */
+typedef struct cfear_params {
+  float z_min;        /* radar_driver.h:40 (float, truncated to int at radar_filters.cpp:198) */
+  float range_res;    /* radar_driver.h:41 */
+  float min_distance; /* radar_driver.h:45 */
+  int32_t k_strongest;      /* radar_driver.h:42; 1..64 supported */
+  double res;               /* odometrykeyframefuser.h:97 (narrowed to float at pointnormal.h:118) */
+  double downsample_factor; /* pointnormal.h:241 */
+  int32_t weight_intensity; /* odometrykeyframefuser.h:92 */
+  int32_t cost;             /* CFEAR_COST_*  (cost_type string, odometrykeyframefuser.h:86) */
+  int32_t loss;             /* CFEAR_LOSS_*  (loss_type_ string, :99) */
+  int32_t weight_opt;       /* registration.h:50 */
+  double loss_limit;        /* :100 */
+  double covar_scale;       /* :101, SetD2dPar n_scan_normal.h:53 */
+  double regularization;    /* :102 */
+  int32_t submap_scan_size; /* :91 */
+  int32_t compensate;       /* :95 */
+  int32_t radar_ccw;        /* :95 */
+  int32_t use_keyframe;     /* :96 */
+  double min_keyframe_dist;    /* :98 */
+  double min_keyframe_rot_deg; /* :98 */
+  int32_t max_itr_association; /* n_scan_normal.h:75 (8) */
+  int32_t min_itr;             /* n_scan_normal.h:75 (3) */
+  int32_t max_solver_iterations; /* n_scan_normal.cpp:9 (20) */
+  int32_t reserved0;
+  double assoc_radius;         /* registration.h:122 (2.0) */
+} cfear_params;
+
+void cfear_default_params(cfear_params* p);
+
+typedef struct cfear_ctx cfear_ctx;
+
+/* One context = one HIP device + stream + scratch. `stream` may be NULL (the context creates its
+ * own) or an existing hipStream_t passed as void*. A, R = polar image shape the context is sized
+ * for (rows = azimuths, cols = range bins; radar_driver.cpp:92-98). */
+int cfear_create(cfear_ctx** out, int device, void* stream, const cfear_params* p, int A, int R);
+void cfear_destroy(cfear_ctx* ctx);
+const char* cfear_last_error(const cfear_ctx* ctx);
+int cfear_set_params(cfear_ctx* ctx, const cfear_params* p);
+int cfear_synchronize(cfear_ctx* ctx);
+
+/* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------
+ * Packed slot: bits 0..15 range bin | 16..23 intensity | 24 valid | 25 peak (AxialNonMaxSupress).
+ * Per azimuth row k slots in ascending (intensity, range) order, unused slots = 0. */
+#define CFEAR_SLOT_RANGE(s) ((int)((s) & 0xFFFFu))
+#define CFEAR_SLOT_INTENSITY(s) ((int)(((s) >> 16) & 0xFFu))
+#define CFEAR_SLOT_VALID(s) ((int)(((s) >> 24) & 1u))
+#define CFEAR_SLOT_PEAK(s) ((int)(((s) >> 25) & 1u))
+
+/* Batched filter on device-resident data, asynchronous on the context stream.
+ * d_polar: n_scans contiguous A*R uint8 images; d_slots: n_scans*A*k uint32. */
+int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots);
+/* Same with host buffers (H2D, kernel, D2H, synchronous). Replaces FilterKstrongest +
+ * AxialNonMaxSupress called from radarDriver::Process (radar_driver.cpp:58-60). */
+int cfear_kstrongest_host(cfear_ctx* ctx, const uint8_t* h_polar, int n_scans, uint32_t* h_slots);
+
+/* ---- Stage 1/1.5: point clouds -------------------------------------------------------------- */
+typedef struct cfear_cloud cfear_cloud; /* pcl::PointCloud<pcl::PointXYZI> on the device */
+
+/* radarDriver::CallbackOffline (radar_driver.cpp:163-176): polar image -> filtered cloud and
+ * peaks cloud. h_polar: A*R uint8 host image (rows = azimuth). */
+int cfear_filter_polar(cfear_ctx* ctx, const uint8_t* h_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks);
+/* Same from a device-resident image (no copy). */
+int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks);
+/* Upload an existing cloud: xyi = n x (x, y, intensity) floats. */
+int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cloud);
+int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* cloud, int* n);
+int cfear_cloud_download(cfear_ctx* ctx, const cfear_cloud* cloud, float* xyi, int capacity, int* n);
+void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* cloud);
+/* Compensate(cloud, Tmotion, ccw) (utils.h:49, utils.cpp:96-113); motion = (tx, ty, theta). In place. */
+int cfear_compensate(cfear_ctx* ctx, cfear_cloud* cloud, const double motion_xyt[3], int ccw);
+
+/* ---- Stage 2: MapPointNormal (pointnormal.h:110-243) ------------------------------------------ */
+typedef struct cfear_scan cfear_scan; /* MapNormalPtr: cells + search structure, device resident */
+
+/* One oriented surface point (class cell, pointnormal.h:45-105). */
+typedef struct cfear_cell {
+  double mean[2];   /* u_ */
+  double cov[3];    /* cov_ xx, xy, yy */
+  double normal[2]; /* snormal_ */
+  double orth[2];   /* orth_normal (sign not defined by the reference) */
+  double lambda_min, lambda_max;
+  double scale;     /* scale_ (planarity) */
+  double sum_intensity, avg_intensity;
+  int32_t nsamples; /* Nsamples_ */
+  int32_t valid;
+} cfear_cell;
+
+/* MapPointNormal(cld, radius = params.res, origin = (0,0), weight_intensity, raw = false)
+ * (pointnormal.cpp:65-90 -> ComputeNormals :265-297 -> ComputeSearchTreeFromCells :151-162). */
+int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** scan);
+void cfear_scan_release(cfear_ctx* ctx, cfear_scan* scan);
+int cfear_scan_size(cfear_ctx* ctx, const cfear_scan* scan, int* n_cells);          /* GetSize() */
+int cfear_scan_download_cells(cfear_ctx* ctx, const cfear_scan* scan, cfear_cell* cells, int capacity, int* n);
+/* GetClosestIdx(p, d) (pointnormal.cpp:238-254) for nq query points; idx[i] = -1 if none. */
+int cfear_scan_closest(cfear_ctx* ctx, const cfear_scan* scan, const double* qxy, int nq, double d, int32_t* idx);
+
+/* ---- Stage 3: n_scan_normal_reg (n_scan_normal.h:27-85) ---------------------------------------- */
+#define CFEAR_MAX_OUTER 64
+typedef struct cfear_reg_summary {
+  int32_t success;          /* Register() return value */
+  int32_t usable;           /* solver solution usable (summary_.IsSolutionUsable()) */
+  int32_t outer_iterations; /* itr_ as documented at n_scan_normal.cpp:161 */
+  int32_t num_residuals;    /* problem_->NumResiduals() of the last problem */
+  int32_t num_residual_blocks;
+  int32_t reserved;
+  double final_cost;        /* summary_.final_cost */
+  double score;             /* getScore() */
+  int32_t inner_iterations[CFEAR_MAX_OUTER]; /* summary_.iterations.size() per outer iteration */
+  int32_t termination[CFEAR_MAX_OUTER];      /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE */
+  double outer_cost[CFEAR_MAX_OUTER];
+  double outer_pose[CFEAR_MAX_OUTER][3];
+} cfear_reg_summary;
+
+/* bool Register(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc,
+ *               std::vector<Matrix6d>& reg_cov, bool soft_constraints=false)
+ * (n_scan_normal.cpp:82-187). scans[0..n-2] keyframes (fixed), scans[n-1] current.
+ * poses_xyt: n x (x, y, theta) in/out; cov6_last: 36 doubles row-major = reg_cov.back().
+ * Returns CFEAR_OK; the reference's bool is summary->success. */
+int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
+                   cfear_reg_summary* summary);
+
+/* ---- Batched odometry: OdometryKeyframeFuser::pointcloudCallback for B independent sequences ---
+ * (odometrykeyframefuser.cpp:143-259, :397-411) with the filter of radar_driver.cpp:48-70 in front.
+ * All state (T_prev, Tmot, keyframe ring) lives on the device; one call = one radar sweep of every
+ * sequence. */
+typedef struct cfear_odometry cfear_odometry;
+int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** odo);
+void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* odo);
+int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* odo);
+/* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous. */
+int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_polar);
+int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_polar);
+/* Tcurrent of every sequence as (x, y, theta); synchronises the stream. */
+int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt);
+/* Last Register() summary / cell count / keyframe count of one sequence (debug + parity tests). */
+int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
+                           int* n_cells, int* n_keyframes);
+
+/* Timing hook used by bench.py: seconds of the filter kernel measured with HIP events on the
+ * context stream over `iters` launches (after `warmup`). */
+int cfear_time_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots,
+                          int warmup, int iters, double* avg_seconds);
+
+const char* cfear_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

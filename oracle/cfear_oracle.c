@@ -1,0 +1,981 @@
+/*
+ * cfear_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT THE PRODUCT).
+ * See cfear_oracle.h for the scope statement.  PARITY UNPINNED (no reference
+ * golden vectors exist; reference unbuildable here: ROS/PCL/Ceres/Eigen/OpenCV absent).
+ *
+ * Compile with -ffp-contract=off: the reference is built with plain -O3 on x86-64
+ * (CMakeLists.txt:4-5,32-33), i.e. without FMA contraction, and several decisions
+ * (voxel index, float d^2 < r^2) are rounding sensitive.
+ *
+ * [3P] marks restatements of third-party behaviour (PCL VoxelGrid, FLANN, Eigen,
+ * Ceres) that is not vendored in /root/reference; see SURVEY.md section 9.
+ */
+#include "cfear_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void cfo_default_params(cfo_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->z_min = 60.f;            /* radar_driver.h:40 */
+  p->range_res = 0.0438f;     /* radar_driver.h:41 */
+  p->min_distance = 2.5f;     /* radar_driver.h:45 */
+  p->k_strongest = 12;        /* radar_driver.h:42 */
+  p->res = 3.0;               /* odometrykeyframefuser.h:132 */
+  p->downsample_factor = 1.0; /* pointnormal.cpp:5 */
+  p->weight_intensity = 1;    /* offline_odometry.cpp:160 */
+  p->cost = CFO_COST_P2L;     /* odometrykeyframefuser.h:86 */
+  p->loss = CFO_LOSS_HUBER;   /* odometrykeyframefuser.h:99 */
+  p->weight_opt = 4;          /* launch/oxford/eval/params/baseline */
+  p->loss_limit = 0.1;
+  p->covar_scale = 1.0;
+  p->regularization = 0.1;
+  p->submap_scan_size = 4;
+  p->compensate = 1;
+  p->radar_ccw = 0;
+  p->use_keyframe = 1;
+  p->min_keyframe_dist = 1.5;
+  p->min_keyframe_rot_deg = 5.0;
+  p->max_itr_association = 8; /* n_scan_normal.h:75 */
+  p->min_itr = 3;
+  p->max_solver_iterations = 20; /* n_scan_normal.cpp:9 */
+  p->assoc_radius = 2.0;         /* registration.h:122 */
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 1: k-strongest (radar_filters.cpp:209-237) and peaks (radar_filters.cpp:238-298)
+ * ------------------------------------------------------------------------------------------ */
+
+#define SLOT(range, inten) ((uint32_t)(range) | ((uint32_t)(inten) << 16) | (1u << 24))
+
+/* lexicographic std::pair<uchar,int> operator< */
+static int pair_less(int i1, int r1, int i2, int r2) { return (i1 < i2) || (i1 == i2 && r1 < r2); }
+
+int cfo_filter(const uint8_t* img, int A, int R, int z_min, int k, uint32_t* out) {
+  if (!img || !out || A <= 0 || R <= 0 || k <= 0 || R > 65536) return -1;
+  const uint8_t u_zmin = (uint8_t)z_min; /* radar_filters.cpp:212 */
+  int* vi = (int*)malloc(sizeof(int) * (size_t)(k + 2));
+  int* vr = (int*)malloc(sizeof(int) * (size_t)(k + 2));
+  uint16_t* score = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(R + 16));
+  uint8_t* has = (uint8_t*)malloc((size_t)(R + 16));
+  const long total = (long)A * (long)R;
+  memset(out, 0, sizeof(uint32_t) * (size_t)A * (size_t)k);
+  for (int b = 0; b < A; b++) {
+    const uint8_t* row = img + (size_t)b * (size_t)R;
+    int n = 0;
+    /* radar_filters.cpp:215-229: bounded ascending vector, lower_bound insert, erase begin */
+    for (int range = 0; range < R; range++) {
+      const int inten = row[range];
+      if (inten < u_zmin) continue;
+      if (n == 0) {
+        vi[0] = inten; vr[0] = range; n = 1;
+      } else {
+        int lo = 0, hi = n; /* std::lower_bound */
+        while (lo < hi) {
+          int mid = (lo + hi) / 2;
+          if (pair_less(vi[mid], vr[mid], inten, range)) lo = mid + 1; else hi = mid;
+        }
+        for (int j = n; j > lo; j--) { vi[j] = vi[j - 1]; vr[j] = vr[j - 1]; }
+        vi[lo] = inten; vr[lo] = range; n++;
+        if (n > k) { /* erase(begin) */
+          for (int j = 0; j + 1 < n; j++) { vi[j] = vi[j + 1]; vr[j] = vr[j + 1]; }
+          n--;
+        }
+      }
+    }
+    uint32_t* o = out + (size_t)b * (size_t)k;
+    for (int j = 0; j < n; j++) o[j] = SLOT(vr[j], vi[j]);
+
+    /* AxialNonMaxSupress: std::unordered_map<int,uint16_t> score restated as has[]/score[],
+     * index shifted by +8 so that keys -3..R+2 are representable (operator[] default = 0). */
+    const int ws = 3;
+    memset(has, 0, (size_t)(R + 16));
+    memset(score, 0, sizeof(uint16_t) * (size_t)(R + 16));
+    for (int j = 0; j < n; j++) {
+      const int m = vr[j];
+      if (m < ws || m >= R - ws) continue; /* radar_filters.cpp:251 */
+      for (int rn = m - ws; rn <= m + ws; rn++) {
+        if (!has[rn + 8]) {
+          uint16_t s = 0;
+          for (int rnn = rn - ws; rnn <= rn + ws; rnn++) {
+            /* cv::Mat::at<uchar>(bearing, r_nn) unchecked: address = data + bearing*step + r_nn
+             * (radar_filters.cpp:260). Inside the image buffer this reads the neighbouring row;
+             * outside it is UB in the reference -- defined here as 0. */
+            const long off = (long)b * (long)R + (long)rnn;
+            const uint8_t v = (off >= 0 && off < total) ? img[off] : 0;
+            s = (uint16_t)(s + (uint16_t)v);
+          }
+          score[rn + 8] = s; has[rn + 8] = 1;
+        }
+      }
+    }
+    for (int j = 0; j < n; j++) {
+      const int m = vr[j];
+      int largest = 1;
+      const uint16_t pthis = score[m + 8];
+      for (int i = 1; i <= ws; i++) {
+        const uint16_t pnext = (m + i + 8 < R + 16) ? score[m + i + 8] : 0;
+        const uint16_t pprev = (m - i + 8 >= 0) ? score[m - i + 8] : 0;
+        if (pprev > pthis || pthis < pnext) { largest = 0; break; } /* radar_filters.cpp:282 */
+      }
+      if (largest) o[j] |= (1u << 25);
+    }
+  }
+  free(vi); free(vr); free(score); free(has);
+  return 0;
+}
+
+typedef struct { int inten; int range; } ir_t;
+static int ir_cmp_desc(const void* a, const void* b) {
+  const ir_t* x = (const ir_t*)a; const ir_t* y = (const ir_t*)b;
+  if (x->inten != y->inten) return y->inten - x->inten;
+  return y->range - x->range;
+}
+/* Independent statement of the selection rule: the k largest by key (I, range),
+ * emitted ascending. No peak flag. */
+int cfo_filter_bruteforce(const uint8_t* img, int A, int R, int z_min, int k, uint32_t* out) {
+  if (!img || !out || A <= 0 || R <= 0 || k <= 0) return -1;
+  const uint8_t u_zmin = (uint8_t)z_min;
+  ir_t* v = (ir_t*)malloc(sizeof(ir_t) * (size_t)R);
+  memset(out, 0, sizeof(uint32_t) * (size_t)A * (size_t)k);
+  for (int b = 0; b < A; b++) {
+    int n = 0;
+    for (int r = 0; r < R; r++) {
+      int I = img[(size_t)b * R + r];
+      if (I >= u_zmin) { v[n].inten = I; v[n].range = r; n++; }
+    }
+    qsort(v, (size_t)n, sizeof(ir_t), ir_cmp_desc);
+    int m = n < k ? n : k;
+    for (int j = 0; j < m; j++) out[(size_t)b * k + j] = SLOT(v[m - 1 - j].range, v[m - 1 - j].inten);
+  }
+  free(v);
+  return 0;
+}
+
+/* getPeaksFilteredPointCloud (radar_filters.cpp:309-337) */
+int cfo_cloud(const uint32_t* slots, int A, int k, float range_res_f, float min_distance_f, int peaks,
+              float* xyi) {
+  const double range_res = (double)range_res_f;       /* float -> double at radar_driver.cpp:58 */
+  const double min_distance = (double)min_distance_f;
+  const int min_range_bin = (int)ceil(min_distance / range_res); /* :315 */
+  int n = 0;
+  for (int b = 0; b < A; b++) {
+    const double theta = ((double)(b + 1) / A) * 2. * M_PI; /* :317 */
+    const double cos_t = cos(theta), sin_t = sin(theta);
+    const double range_res_half = range_res / 2.0;
+    for (int j = 0; j < k; j++) {
+      const uint32_t s = slots[(size_t)b * k + j];
+      if (!CFO_SLOT_VALID(s)) continue;
+      if (peaks && !CFO_SLOT_PEAK(s)) continue;
+      const int range = CFO_SLOT_RANGE(s);
+      if (range > min_range_bin) { /* :327 */
+        xyi[3 * n + 0] = (float)((range_res_half + range_res * range) * cos_t);
+        xyi[3 * n + 1] = (float)((range_res_half + range_res * range) * sin_t);
+        xyi[3 * n + 2] = (float)CFO_SLOT_INTENSITY(s);
+        n++;
+      }
+    }
+  }
+  return n;
+}
+
+/* utils.h:28-32 */
+static double rel_time_stamp(double x, double y, int ccw) {
+  double a = atan2(y, x);
+  double d = ((a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI));
+  return ccw ? -(d - 0.5) : (d - 0.5);
+}
+
+/* utils.cpp:96-107 (+ getScaledRotationMatrix/TranslationVector :130-146) */
+void cfo_compensate(float* xyi, int n, const double mot[3], int ccw) {
+  for (int i = 0; i < n; i++) {
+    const double px = xyi[3 * i], py = xyi[3 * i + 1];
+    const double d = rel_time_stamp(px, py, ccw);
+    const double s1 = sin(d * mot[2]), c1 = cos(d * mot[2]);
+    const double tx = d * mot[0], ty = d * mot[1];
+    xyi[3 * i + 0] = (float)((c1 * px + (-s1) * py) + tx);
+    xyi[3 * i + 1] = (float)((s1 * px + c1 * py) + ty);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 2: oriented surface points (pointnormal.cpp:7-63, 65-90, 151-162, 238-254, 265-297)
+ * ------------------------------------------------------------------------------------------ */
+
+struct cfo_scan {
+  int n;          /* input_ size */
+  float* pts;     /* x,y,intensity */
+  int nsamp;
+  float* samples; /* voxel centroids */
+  int ncells;
+  cfo_cell* cells;
+  float* mean_f;  /* downsampled_: float(u_) (pointnormal.cpp:151-158) */
+  /* uniform grid over mean_f (acceleration only; result == brute force) */
+  double gminx, gminy, gcell;
+  int gw, gh;
+  int* gstart;
+  int* gorder;
+};
+
+typedef struct { uint64_t key; } vkey_t;
+static int u64_cmp(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return (x > y) - (x < y);
+}
+typedef struct { float d2; int idx; } nb_t;
+static int nb_cmp(const void* a, const void* b) {
+  const nb_t* x = (const nb_t*)a; const nb_t* y = (const nb_t*)b;
+  if (x->d2 < y->d2) return -1;
+  if (x->d2 > y->d2) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx); /* [3P] flann DistanceIndex operator< */
+}
+
+/* Symmetric 2x2 eigen-decomposition, closed form. [3P] Eigen::SelfAdjointEigenSolver<Matrix2d>
+ * (pointnormal.cpp:39-45) is iterative; equal up to rounding, eigenvalues ascending, unit vectors,
+ * identity eigenvectors for an isotropic matrix. Reads the lower triangle like Eigen. */
+static void eig2(double a, double b, double c, double* lmin, double* lmax, double vmin[2], double vmax[2]) {
+  const double t1 = 0.5 * (a + c);
+  const double d = 0.5 * (a - c);
+  const double t0 = sqrt(d * d + b * b);
+  *lmin = t1 - t0;
+  *lmax = t1 + t0;
+  double v0x = *lmax - c, v0y = b;
+  double v1x = b, v1y = *lmax - a;
+  const double n0 = v0x * v0x + v0y * v0y, n1 = v1x * v1x + v1y * v1y;
+  double vx, vy, nn;
+  if (n0 >= n1) { vx = v0x; vy = v0y; nn = n0; } else { vx = v1x; vy = v1y; nn = n1; }
+  if (!(nn > 0.0)) { vmax[0] = 0; vmax[1] = 1; vmin[0] = 1; vmin[1] = 0; return; }
+  const double inv = 1.0 / sqrt(nn);
+  vmax[0] = vx * inv; vmax[1] = vy * inv;
+  vmin[0] = -vmax[1]; vmin[1] = vmax[0];
+}
+
+/* cell::cell + cell::ComputeNormal (pointnormal.cpp:7-63); idx = neighbour indices in search order */
+static void make_cell(const float* pts, const int* idx, int N, int weight_intensity, cfo_cell* c) {
+  memset(c, 0, sizeof(*c));
+  c->nsamples = N;
+  double sum = 0;
+  for (int i = 0; i < N; i++) { /* :13-18 */
+    const double w = weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0;
+    sum += w;
+  }
+  c->sum_intensity = sum;
+  c->avg_intensity = sum / N;
+  double ux = 0, uy = 0;
+  for (int i = 0; i < N; i++) { /* :21-24 */
+    const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum;
+    ux += w * (double)pts[3 * idx[i]];
+    uy += w * (double)pts[3 * idx[i] + 1];
+  }
+  double cxx = 0, cyx = 0, cyy = 0;
+  for (int i = 0; i < N; i++) { /* :26-33: cov = x^T * (w .* x) */
+    const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum;
+    const double dx = (double)pts[3 * idx[i]] - ux, dy = (double)pts[3 * idx[i] + 1] - uy;
+    cxx += dx * (w * dx);
+    cyx += dy * (w * dx); /* lower triangle entry (1,0), the one the eigensolver reads */
+    cyy += dy * (w * dy);
+  }
+  c->mean[0] = ux; c->mean[1] = uy;
+  c->cov[0] = cxx; c->cov[1] = cyx; c->cov[2] = cyy;
+  double lmin, lmax, vmin[2], vmax[2];
+  eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
+  c->lambda_min = lmin; c->lambda_max = lmax;
+  const double cond = fabs(lmax / lmin);      /* :53 */
+  const double det = lmax * lmin;             /* :54 */
+  c->valid = (cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0; /* :56 */
+  c->scale = log(1.0 + cond / 2);             /* :57 */
+  /* origin = (0,0) (odometrykeyframefuser.cpp:161): Po_u = origin - u */
+  if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; } /* :59-61 */
+  c->normal[0] = vmin[0]; c->normal[1] = vmin[1];
+  c->orth[0] = vmax[0]; c->orth[1] = vmax[1];
+}
+
+static int lower_bound_u64(const uint64_t* a, int n, uint64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+static void build_cell_grid(cfo_scan* s, double cell) {
+  s->gcell = cell; s->gw = s->gh = 0; s->gstart = NULL; s->gorder = NULL;
+  const int n = s->ncells;
+  if (n == 0) return;
+  double minx = s->mean_f[0], maxx = minx, miny = s->mean_f[1], maxy = miny;
+  for (int i = 1; i < n; i++) {
+    double x = s->mean_f[2 * i], y = s->mean_f[2 * i + 1];
+    if (x < minx) minx = x; if (x > maxx) maxx = x;
+    if (y < miny) miny = y; if (y > maxy) maxy = y;
+  }
+  s->gminx = minx; s->gminy = miny;
+  s->gw = (int)floor((maxx - minx) / cell) + 1;
+  s->gh = (int)floor((maxy - miny) / cell) + 1;
+  const int G = s->gw * s->gh;
+  s->gstart = (int*)calloc((size_t)G + 1, sizeof(int));
+  s->gorder = (int*)malloc(sizeof(int) * (size_t)n);
+  int* gi = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    int gx = (int)floor((s->mean_f[2 * i] - minx) / cell), gy = (int)floor((s->mean_f[2 * i + 1] - miny) / cell);
+    gi[i] = gy * s->gw + gx;
+    s->gstart[gi[i] + 1]++;
+  }
+  for (int g = 0; g < G; g++) s->gstart[g + 1] += s->gstart[g];
+  int* fill = (int*)malloc(sizeof(int) * (size_t)G);
+  memcpy(fill, s->gstart, sizeof(int) * (size_t)G);
+  for (int i = 0; i < n; i++) s->gorder[fill[gi[i]]++] = i; /* ascending cell index inside a bucket */
+  free(fill); free(gi);
+}
+
+cfo_scan* cfo_scan_create(const float* xyi, int n, const cfo_params* p, int brute) {
+  if (n <= 0 || !xyi) return NULL; /* reference: exit(0) on an empty cloud (pointnormal.cpp:72-75) */
+  cfo_scan* s = (cfo_scan*)calloc(1, sizeof(cfo_scan));
+  s->n = n;
+  s->pts = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  memcpy(s->pts, xyi, sizeof(float) * 3 * (size_t)n);
+  const float radius = (float)p->res; /* pointnormal.h:118: float radius */
+  /* [3P] pcl::VoxelGrid<PointXYZI>::applyFilter, leaf = radius_/downsample_factor (pointnormal.cpp:279) */
+  const float leaf = (float)((double)radius / p->downsample_factor);
+  const float inv = 1.0f / leaf;
+  float minx = xyi[0], maxx = xyi[0], miny = xyi[1], maxy = xyi[1];
+  for (int i = 1; i < n; i++) {
+    const float x = xyi[3 * i], y = xyi[3 * i + 1];
+    if (x < minx) minx = x; if (x > maxx) maxx = x;
+    if (y < miny) miny = y; if (y > maxy) maxy = y;
+  }
+  const int min_b0 = (int)floorf(minx * inv), max_b0 = (int)floorf(maxx * inv);
+  const int min_b1 = (int)floorf(miny * inv), max_b1 = (int)floorf(maxy * inv);
+  const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
+  uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
+    const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+    const uint64_t idx = (uint64_t)((int64_t)ijk0 + (int64_t)ijk1 * (int64_t)div0); /* z == 0 -> ijk2 = 0 */
+    keys[i] = (idx << 24) | (uint64_t)i; /* [3P] std::sort on idx only is unstable; pinned here as stable */
+  }
+  qsort(keys, (size_t)n, sizeof(uint64_t), u64_cmp);
+  /* centroids: [3P] pcl::CentroidPoint<PointXYZI>: float sums divided by float(count), ascending idx */
+  s->samples = (float*)malloc(sizeof(float) * 3 * (size_t)n);
+  int* vstart = (int*)malloc(sizeof(int) * ((size_t)n + 1));
+  uint64_t* vidx = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+  int nv = 0;
+  for (int i = 0; i < n;) {
+    int j = i;
+    float sx = 0, sy = 0, si = 0;
+    const uint64_t id = keys[i] >> 24;
+    while (j < n && (keys[j] >> 24) == id) {
+      const int pi = (int)(keys[j] & 0xFFFFFF);
+      sx += xyi[3 * pi]; sy += xyi[3 * pi + 1]; si += xyi[3 * pi + 2];
+      j++;
+    }
+    const float cnt = (float)(j - i);
+    s->samples[3 * nv] = sx / cnt; s->samples[3 * nv + 1] = sy / cnt; s->samples[3 * nv + 2] = si / cnt;
+    vstart[nv] = i; vidx[nv] = id; nv++;
+    i = j;
+  }
+  vstart[nv] = n;
+  s->nsamp = nv;
+  /* radius search per sample point (pointnormal.cpp:286-296). [3P] flann L2_Simple<float> over (x,y,z=0),
+   * accept d2 < float(radius*radius), results sorted ascending by (d2, index). */
+  const float r2 = (float)((double)radius * (double)radius);
+  s->cells = (cfo_cell*)malloc(sizeof(cfo_cell) * (size_t)(nv > 0 ? nv : 1));
+  nb_t* nb = (nb_t*)malloc(sizeof(nb_t) * (size_t)n);
+  int* nidx = (int*)malloc(sizeof(int) * (size_t)n);
+  const int reach = (int)ceil((double)radius / (double)leaf) + 1;
+  for (int v = 0; v < nv; v++) {
+    const float cx = s->samples[3 * v], cy = s->samples[3 * v + 1];
+    int m = 0;
+    if (brute) {
+      for (int i = 0; i < n; i++) {
+        const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
+        float d2 = dx * dx; d2 += dy * dy; d2 += 0.0f * 0.0f;
+        if (d2 < r2) { nb[m].d2 = d2; nb[m].idx = i; m++; }
+      }
+    } else {
+      const int vx = (int)(floorf(cx * inv) - (float)min_b0), vy = (int)(floorf(cy * inv) - (float)min_b1);
+      for (int gy = vy - reach; gy <= vy + reach; gy++) {
+        if (gy < 0 || gy >= div1) continue;
+        int gx0 = vx - reach, gx1 = vx + reach;
+        if (gx0 < 0) gx0 = 0; if (gx1 >= div0) gx1 = div0 - 1;
+        if (gx0 > gx1) continue;
+        const uint64_t k0 = (uint64_t)((int64_t)gx0 + (int64_t)gy * div0), k1 = (uint64_t)((int64_t)gx1 + (int64_t)gy * div0);
+        const int a = lower_bound_u64(vidx, nv, k0), b = lower_bound_u64(vidx, nv, k1 + 1);
+        for (int q = vstart[a]; q < vstart[b]; q++) {
+          const int i = (int)(keys[q] & 0xFFFFFF);
+          const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
+          float d2 = dx * dx; d2 += dy * dy; d2 += 0.0f * 0.0f;
+          if (d2 < r2) { nb[m].d2 = d2; nb[m].idx = i; m++; }
+        }
+      }
+    }
+    if (m >= 6) { /* pointnormal.cpp:291 */
+      qsort(nb, (size_t)m, sizeof(nb_t), nb_cmp);
+      for (int i = 0; i < m; i++) nidx[i] = nb[i].idx;
+      cfo_cell c;
+      make_cell(xyi, nidx, m, p->weight_intensity, &c);
+      if (c.valid) s->cells[s->ncells++] = c; /* :293-294 */
+    }
+  }
+  free(nb); free(nidx); free(keys); free(vstart); free(vidx);
+  /* ComputeSearchTreeFromCells (pointnormal.cpp:151-162) */
+  s->mean_f = (float*)malloc(sizeof(float) * 2 * (size_t)(s->ncells > 0 ? s->ncells : 1));
+  for (int i = 0; i < s->ncells; i++) {
+    s->mean_f[2 * i] = (float)s->cells[i].mean[0];
+    s->mean_f[2 * i + 1] = (float)s->cells[i].mean[1];
+  }
+  build_cell_grid(s, 2.0 * p->assoc_radius);
+  return s;
+}
+
+void cfo_scan_free(cfo_scan* s) {
+  if (!s) return;
+  free(s->pts); free(s->samples); free(s->cells); free(s->mean_f); free(s->gstart); free(s->gorder);
+  free(s);
+}
+int cfo_scan_size(const cfo_scan* s) { return s ? s->ncells : 0; }
+const cfo_cell* cfo_scan_cells(const cfo_scan* s) { return s->cells; }
+int cfo_scan_num_samples(const cfo_scan* s) { return s->nsamp; }
+const float* cfo_scan_samples(const cfo_scan* s) { return s->samples; }
+
+/* GetClosestIdx (pointnormal.cpp:238-254): [3P] FLANN 1-NN over float (x,y), then d2 < d*d.
+ * Exact-distance ties: lowest cell index (kd-tree visit order is not pinnable). */
+int cfo_scan_closest(const cfo_scan* s, double px, double py, double d, int brute) {
+  const float qx = (float)px, qy = (float)py;
+  int best = -1;
+  float bd = FLT_MAX;
+  if (brute || s->gw == 0) {
+    for (int i = 0; i < s->ncells; i++) {
+      const float dx = qx - s->mean_f[2 * i], dy = qy - s->mean_f[2 * i + 1];
+      float d2 = dx * dx; d2 += dy * dy;
+      if (d2 < bd) { bd = d2; best = i; }
+    }
+  } else {
+    const double m = d * (1.0 + 1e-6) + 1e-6;
+    int gx0 = (int)floor(((double)qx - m - s->gminx) / s->gcell), gx1 = (int)floor(((double)qx + m - s->gminx) / s->gcell);
+    int gy0 = (int)floor(((double)qy - m - s->gminy) / s->gcell), gy1 = (int)floor(((double)qy + m - s->gminy) / s->gcell);
+    if (gx0 < 0) gx0 = 0; if (gy0 < 0) gy0 = 0;
+    if (gx1 >= s->gw) gx1 = s->gw - 1; if (gy1 >= s->gh) gy1 = s->gh - 1;
+    for (int gy = gy0; gy <= gy1; gy++) {
+      if (gx0 > gx1) break;
+      const int a = s->gstart[gy * s->gw + gx0], b = s->gstart[gy * s->gw + gx1 + 1];
+      for (int q = a; q < b; q++) {
+        const int i = s->gorder[q];
+        const float dx = qx - s->mean_f[2 * i], dy = qy - s->mean_f[2 * i + 1];
+        float d2 = dx * dx; d2 += dy * dy;
+        if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+      }
+    }
+  }
+  if (best >= 0 && (double)bd < d * d) return best;
+  return -1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stage 3: registration (n_scan_normal.cpp:82-187, 215-326, 344-452; registration.cpp:67-97)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct { double l[4]; double t[2]; } aff2; /* linear row-major (00,01,10,11) + translation */
+
+static aff2 aff_from_xyt(double x, double y, double th) { /* vectorToAffine3d, registration.cpp:130-136 */
+  aff2 T; const double c = cos(th), s = sin(th);
+  T.l[0] = c; T.l[1] = -s; T.l[2] = s; T.l[3] = c; T.t[0] = x; T.t[1] = y;
+  return T;
+}
+static aff2 aff_mul(const aff2* A, const aff2* B) {
+  aff2 C;
+  C.l[0] = A->l[0] * B->l[0] + A->l[1] * B->l[2];
+  C.l[1] = A->l[0] * B->l[1] + A->l[1] * B->l[3];
+  C.l[2] = A->l[2] * B->l[0] + A->l[3] * B->l[2];
+  C.l[3] = A->l[2] * B->l[1] + A->l[3] * B->l[3];
+  C.t[0] = (A->l[0] * B->t[0] + A->l[1] * B->t[1]) + A->t[0];
+  C.t[1] = (A->l[2] * B->t[0] + A->l[3] * B->t[1]) + A->t[1];
+  return C;
+}
+static aff2 aff_inv(const aff2* A) { /* [3P] Eigen Affine inverse: general linear inverse, t' = -L^-1 t */
+  aff2 I;
+  const double det = A->l[0] * A->l[3] - A->l[1] * A->l[2];
+  const double id = 1.0 / det;
+  I.l[0] = A->l[3] * id; I.l[1] = -A->l[1] * id; I.l[2] = -A->l[2] * id; I.l[3] = A->l[0] * id;
+  I.t[0] = -(I.l[0] * A->t[0] + I.l[1] * A->t[1]);
+  I.t[1] = -(I.l[2] * A->t[0] + I.l[3] * A->t[1]);
+  return I;
+}
+static void aff_to_xyt(const aff2* T, double v[3]) { /* Affine3dToVectorXYeZ, utils.cpp:115-122 */
+  v[0] = T->t[0]; v[1] = T->t[1];
+  v[2] = atan2(T->l[2], T->l[3]); /* [3P] eulerAngles(0,1,2)[2] of a pure yaw rotation */
+}
+
+typedef struct {
+  double tm[2]; /* Ttar * tar_mean */
+  double tn[2]; /* Ttar.linear() * tar_normal (P2L) */
+  double L[3];  /* P2D sqrt information, lower triangle l00,l10,l11 */
+  double s[2];  /* src mean (local) */
+  double w;     /* weight after loss */
+} match_t;
+
+static double similarity(double x, double y) { return 2 * fmin(x, y) / (x + y); } /* registration.h:96 */
+static double get_weight(int opt, double n1, double n2, double sim, double p1, double p2) { /* registration.cpp:67-76 */
+  switch (opt) {
+    case 0: return 1.0;
+    case 1: return similarity(n1, n2);
+    case 2: return sim;
+    case 3: return similarity(p1, p2);
+    case 4: return similarity(n1, n2) + sim + similarity(p1, p2);
+    default: return 1.0;
+  }
+}
+
+/* [3P] ceres::LossFunction::Evaluate for the losses of registration.cpp:78-97 (Ceres 2.0 forms) */
+static void loss_eval(int loss, double a, double s, double rho[3]) {
+  const double b = a * a;
+  switch (loss) {
+    case CFO_LOSS_HUBER:
+      if (s > b) { const double r = sqrt(s); rho[0] = 2.0 * a * r - b; rho[1] = fmax(DBL_MIN, a / r); rho[2] = -rho[1] / (2.0 * s); }
+      else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+      return;
+    case CFO_LOSS_CAUCHY: {
+      const double c = 1.0 / b, sum = 1.0 + s * c, inv = 1.0 / sum;
+      rho[0] = b * log(sum); rho[1] = fmax(DBL_MIN, inv); rho[2] = -c * (inv * inv);
+      return; }
+    case CFO_LOSS_SOFTLONE: {
+      const double c = 1.0 / b, sum = 1.0 + s * c, tmp = sqrt(sum);
+      rho[0] = 2.0 * b * (tmp - 1.0); rho[1] = fmax(DBL_MIN, 1.0 / tmp); rho[2] = -(c * rho[1]) / (2.0 * sum);
+      return; }
+    case CFO_LOSS_TUKEY:
+      if (s <= b) { const double v = 1.0 - s / b, v2 = v * v; rho[0] = b / 3.0 * (1.0 - v2 * v); rho[1] = v2; rho[2] = -2.0 / b * v; }
+      else { rho[0] = b / 3.0; rho[1] = 0.0; rho[2] = 0.0; }
+      return;
+    case CFO_LOSS_COMBINED: { /* ComposedLoss(Huber(1), Cauchy(1)) = f(g(s)), registration.cpp:89-93 */
+      double g[3], f[3];
+      loss_eval(CFO_LOSS_CAUCHY, 1.0, s, g);
+      loss_eval(CFO_LOSS_HUBER, 1.0, g[0], f);
+      rho[0] = f[0]; rho[1] = f[1] * g[1]; rho[2] = f[2] * g[1] * g[1] + f[1] * g[2];
+      return; }
+    default: rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return; /* nullptr loss */
+  }
+}
+
+typedef struct {
+  const match_t* m; int nm; int cost; int loss; double loss_limit;
+} problem_t;
+
+/* [3P] ceres ResidualBlock::Evaluate + Corrector (rho'' <= 0 for every loss here => r~ = sqrt(rho')r).
+ * cost = 1/2 sum rho(s); g = J~^T r~; H = J~^T J~ (00,01,02,11,12,22). Residual functors:
+ * n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P). */
+static double evaluate(const problem_t* P, const double x[3], double g[3], double H[6]) {
+  const double c = cos(x[2]), s = sin(x[2]);
+  double cost = 0;
+  if (g) { g[0] = g[1] = g[2] = 0; for (int i = 0; i < 6; i++) H[i] = 0; }
+  for (int i = 0; i < P->nm; i++) {
+    const match_t* m = &P->m[i];
+    const double px = (c * m->s[0] - s * m->s[1]) + x[0];
+    const double py = (s * m->s[0] + c * m->s[1]) + x[1];
+    const double dtx = -s * m->s[0] - c * m->s[1]; /* d p / d theta */
+    const double dty = c * m->s[0] - s * m->s[1];
+    double r[2], J[2][3];
+    int nr;
+    if (P->cost == CFO_COST_P2L) {
+      nr = 1;
+      r[0] = (px - m->tm[0]) * m->tn[0] + (py - m->tm[1]) * m->tn[1];
+      J[0][0] = m->tn[0]; J[0][1] = m->tn[1]; J[0][2] = dtx * m->tn[0] + dty * m->tn[1];
+    } else if (P->cost == CFO_COST_P2D) {
+      nr = 2;
+      const double dx = px - m->tm[0], dy = py - m->tm[1];
+      r[0] = m->L[0] * dx; r[1] = m->L[1] * dx + m->L[2] * dy;
+      J[0][0] = m->L[0]; J[0][1] = 0; J[0][2] = m->L[0] * dtx;
+      J[1][0] = m->L[1]; J[1][1] = m->L[2]; J[1][2] = m->L[1] * dtx + m->L[2] * dty;
+    } else {
+      nr = 2;
+      r[0] = m->tm[0] - px; r[1] = m->tm[1] - py;
+      J[0][0] = -1; J[0][1] = 0; J[0][2] = -dtx;
+      J[1][0] = 0; J[1][1] = -1; J[1][2] = -dty;
+    }
+    double sq = 0;
+    for (int k = 0; k < nr; k++) sq += r[k] * r[k];
+    double rho[3];
+    loss_eval(P->loss, P->loss_limit, sq, rho);
+    rho[0] *= m->w; rho[1] *= m->w; rho[2] *= m->w; /* ScaledLoss (n_scan_normal.cpp:277) */
+    cost += 0.5 * rho[0];
+    if (g) {
+      const double sr = sqrt(rho[1]);
+      for (int k = 0; k < nr; k++) {
+        const double rk = sr * r[k];
+        const double j0 = sr * J[k][0], j1 = sr * J[k][1], j2 = sr * J[k][2];
+        g[0] += j0 * rk; g[1] += j1 * rk; g[2] += j2 * rk;
+        H[0] += j0 * j0; H[1] += j0 * j1; H[2] += j0 * j2;
+        H[3] += j1 * j1; H[4] += j1 * j2; H[5] += j2 * j2;
+      }
+    }
+  }
+  return cost;
+}
+
+/* solve symmetric 3x3 A y = b by Cholesky; returns 0 if A is not positive definite */
+static int chol3_solve(const double A[6], const double b[3], double y[3]) {
+  const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+  if (!(a00 > 0)) return 0;
+  const double l00 = sqrt(a00), l10 = a01 / l00, l20 = a02 / l00;
+  const double d1 = a11 - l10 * l10;
+  if (!(d1 > 0)) return 0;
+  const double l11 = sqrt(d1), l21 = (a12 - l20 * l10) / l11;
+  const double d2 = a22 - l20 * l20 - l21 * l21;
+  if (!(d2 > 0)) return 0;
+  const double l22 = sqrt(d2);
+  const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
+  y[2] = z2 / l22; y[1] = (z1 - l21 * y[2]) / l11; y[0] = (z0 - l10 * y[1] - l20 * y[2]) / l00;
+  return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
+}
+
+typedef struct {
+  int num_iterations;     /* summary_.iterations.size() */
+  int termination;        /* 0 CONVERGENCE 1 NO_CONVERGENCE 2 FAILURE */
+  double final_cost;      /* min over pushed iterations (SetSummaryFinalCost) */
+  double last_relative_decrease; /* iterations.back().relative_decrease */
+} solve_summary;
+
+/* [3P] ceres::Solve with default options + max_num_iterations (n_scan_normal.cpp:9,450):
+ * trust-region Levenberg-Marquardt, Jacobi scaling, monotonic steps. */
+static solve_summary lm_solve(const problem_t* P, double x[3], int max_iterations) {
+  const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double max_radius = 1e16, min_radius = 1e-32;
+  solve_summary S;
+  double g[3], H[6];
+  double x_cost = evaluate(P, x, g, H);
+  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  S.num_iterations = 1; S.final_cost = x_cost; S.last_relative_decrease = 0.0; S.termination = 1;
+  double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+  if (gmax <= gradient_tolerance) { S.termination = 0; return S; }
+  double scale[3];
+  scale[0] = 1.0 / (1.0 + sqrt(H[0])); scale[1] = 1.0 / (1.0 + sqrt(H[3])); scale[2] = 1.0 / (1.0 + sqrt(H[5]));
+  double radius = 1e4, decrease_factor = 2.0;
+  int reuse_diagonal = 0, num_invalid = 0, iteration = 0;
+  double diag[3] = {0, 0, 0};
+  for (;;) {
+    if (iteration >= max_iterations) { S.termination = 1; return S; }
+    if (radius < min_radius) { S.termination = 0; return S; }
+    iteration++;
+    double Hs[6], gs[3];
+    Hs[0] = H[0] * scale[0] * scale[0]; Hs[1] = H[1] * scale[0] * scale[1]; Hs[2] = H[2] * scale[0] * scale[2];
+    Hs[3] = H[3] * scale[1] * scale[1]; Hs[4] = H[4] * scale[1] * scale[2]; Hs[5] = H[5] * scale[2] * scale[2];
+    gs[0] = g[0] * scale[0]; gs[1] = g[1] * scale[1]; gs[2] = g[2] * scale[2];
+    if (!reuse_diagonal) {
+      diag[0] = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
+      diag[1] = fmin(fmax(Hs[3], min_lm_diagonal), max_lm_diagonal);
+      diag[2] = fmin(fmax(Hs[5], min_lm_diagonal), max_lm_diagonal);
+    }
+    double lm[3];
+    for (int i = 0; i < 3; i++) lm[i] = sqrt(diag[i] / radius);
+    double Am[6] = {Hs[0] + lm[0] * lm[0], Hs[1], Hs[2], Hs[3] + lm[1] * lm[1], Hs[4], Hs[5] + lm[2] * lm[2]};
+    double rhs[3] = {-gs[0], -gs[1], -gs[2]}, y[3];
+    int valid = chol3_solve(Am, rhs, y);
+    reuse_diagonal = 1;
+    double model_cost_change = 0;
+    if (valid) {
+      const double Hy0 = Hs[0] * y[0] + Hs[1] * y[1] + Hs[2] * y[2];
+      const double Hy1 = Hs[1] * y[0] + Hs[3] * y[1] + Hs[4] * y[2];
+      const double Hy2 = Hs[2] * y[0] + Hs[4] * y[1] + Hs[5] * y[2];
+      model_cost_change = -((y[0] * gs[0] + y[1] * gs[1] + y[2] * gs[2]) + 0.5 * (y[0] * Hy0 + y[1] * Hy1 + y[2] * Hy2));
+      if (!(model_cost_change > 0.0)) valid = 0;
+    }
+    if (!valid) { /* HandleInvalidStep */
+      if (++num_invalid >= 5) { S.termination = 2; return S; }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = 1; /* StepIsInvalid = StepRejected(0) */
+      S.num_iterations++; S.last_relative_decrease = 0.0;
+      if (x_cost < S.final_cost) S.final_cost = x_cost;
+      continue;
+    }
+    num_invalid = 0;
+    double xc[3] = {x[0] + y[0] * scale[0], x[1] + y[1] * scale[1], x[2] + y[2] * scale[2]};
+    const double cand_cost = evaluate(P, xc, NULL, NULL);
+    const double d0 = x[0] - xc[0], d1 = x[1] - xc[1], d2 = x[2] - xc[2];
+    const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { S.termination = 0; return S; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= function_tolerance * x_cost) { S.termination = 0; return S; }
+    const double relative_decrease = cost_change / model_cost_change;
+    S.num_iterations++;
+    S.last_relative_decrease = relative_decrease;
+    if (relative_decrease > min_relative_decrease) { /* HandleSuccessfulStep */
+      x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
+      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      x_cost = evaluate(P, x, g, H);
+      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3));
+      radius = fmin(max_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = 0;
+      if (x_cost < S.final_cost) S.final_cost = x_cost;
+      gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+      if (iteration >= max_iterations) { S.termination = 1; return S; }
+      if (gmax <= gradient_tolerance) { S.termination = 0; return S; }
+    } else { /* HandleUnsuccessfulStep */
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = 1;
+      if (cand_cost < S.final_cost) S.final_cost = cand_cost;
+    }
+  }
+}
+
+/* AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367) */
+static int build_problem(cfo_scan* const* scans, int n, double (*par)[3], const cfo_params* p, int itr,
+                         int brute, match_t* M, int* num_residuals) {
+  const double angle_outlier = cos(M_PI / 6.0);
+  const double curr_radius = (itr == 1) ? 2 * p->assoc_radius : p->assoc_radius; /* :222 */
+  const aff2 Tsrc = aff_from_xyt(par[n - 1][0], par[n - 1][1], par[n - 1][2]);
+  const cfo_scan* src = scans[n - 1];
+  int nm = 0;
+  for (int i = 0; i + 1 < n; i++) {
+    const cfo_scan* tar = scans[i];
+    const aff2 Ttar = aff_from_xyt(par[i][0], par[i][1], par[i][2]);
+    const aff2 Tinv = aff_inv(&Ttar);
+    const aff2 T = aff_mul(&Tinv, &Tsrc); /* Tsrctotar, :224 */
+    for (int j = 0; j < src->ncells; j++) {
+      const cfo_cell* cs = &src->cells[j];
+      const double qx = (T.l[0] * cs->mean[0] + T.l[1] * cs->mean[1]) + T.t[0];
+      const double qy = (T.l[2] * cs->mean[0] + T.l[3] * cs->mean[1]) + T.t[1];
+      const int ti = cfo_scan_closest(tar, qx, qy, curr_radius, brute);
+      if (ti < 0) continue;
+      const cfo_cell* ct = &tar->cells[ti];
+      const double nx = T.l[0] * cs->normal[0] + T.l[1] * cs->normal[1];
+      const double ny = T.l[2] * cs->normal[0] + T.l[3] * cs->normal[1];
+      const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
+      if (!(sim > angle_outlier)) continue; /* :247 */
+      match_t* m = &M[nm++];
+      m->w = get_weight(p->weight_opt, (double)cs->nsamples, (double)ct->nsamples, sim, cs->scale, ct->scale);
+      m->tm[0] = (Ttar.l[0] * ct->mean[0] + Ttar.l[1] * ct->mean[1]) + Ttar.t[0];
+      m->tm[1] = (Ttar.l[2] * ct->mean[0] + Ttar.l[3] * ct->mean[1]) + Ttar.t[1];
+      m->tn[0] = Ttar.l[0] * ct->normal[0] + Ttar.l[1] * ct->normal[1];
+      m->tn[1] = Ttar.l[2] * ct->normal[0] + Ttar.l[3] * ct->normal[1];
+      m->s[0] = cs->mean[0]; m->s[1] = cs->mean[1];
+      m->L[0] = m->L[1] = m->L[2] = 0;
+      if (p->cost == CFO_COST_P2D) { /* :290-299 */
+        /* R*cov*R^T with the (symmetrised) cell covariance */
+        const double a = ct->cov[0], b = ct->cov[1], c = ct->cov[2];
+        const double r00 = Ttar.l[0], r01 = Ttar.l[1], r10 = Ttar.l[2], r11 = Ttar.l[3];
+        const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
+        const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
+        const double c00 = (p->regularization + (m00 * r00 + m01 * r01)) * p->covar_scale;
+        const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * p->covar_scale;
+        const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * p->covar_scale;
+        const double c11 = (p->regularization + (m10 * r10 + m11 * r11)) * p->covar_scale;
+        const double det = c00 * c11 - c01 * c10, id = 1.0 / det; /* [3P] Eigen 2x2 inverse */
+        const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
+        const double l00 = sqrt(i00), l10 = i10 / l00; /* [3P] Eigen LLT, lower */
+        const double l11 = sqrt(i11 - l10 * l10);
+        m->L[0] = l00; m->L[1] = l10; m->L[2] = l11;
+      }
+    }
+  }
+  *num_residuals = nm * (p->cost == CFO_COST_P2L ? 1 : 2);
+  return nm;
+}
+
+static void default_cov(double* cov6) {
+  for (int i = 0; i < 36; i++) cov6[i] = 0;
+  cov6[0] = 0.1 * 0.1; cov6[7] = 0.1 * 0.1; cov6[35] = 0.01 * 0.01; /* n_scan_normal.cpp:173 */
+}
+
+int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
+                 int brute, cfo_reg_summary* out) {
+  cfo_reg_summary S;
+  memset(&S, 0, sizeof(S));
+  if (n < 2 || n > 1024) { if (out) *out = S; return 0; }
+  double(*par)[3] = (double(*)[3])malloc(sizeof(double) * 3 * (size_t)n);
+  for (int i = 0; i < n; i++) { /* Affine3dToVectorXYeZ of vectorToAffine3d: theta -> atan2(sin,cos) */
+    const aff2 T = aff_from_xyt(poses_xyt[3 * i], poses_xyt[3 * i + 1], poses_xyt[3 * i + 2]);
+    aff_to_xyt(&T, par[i]);
+  }
+  const int nsrc = scans[n - 1]->ncells;
+  match_t* M = (match_t*)malloc(sizeof(match_t) * (size_t)((n - 1) * (nsrc > 0 ? nsrc : 1)));
+  double tsrc_last[3] = {poses_xyt[3 * (n - 1)], poses_xyt[3 * (n - 1) + 1], poses_xyt[3 * (n - 1) + 2]};
+  int success = 1;
+  double prev_par[3] = {par[n - 1][0], par[n - 1][1], par[n - 1][2]};
+  double prev_score = DBL_MAX;
+  problem_t P; P.m = M; P.nm = 0; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit;
+  int nres = 0;
+  solve_summary ss; memset(&ss, 0, sizeof(ss));
+  int itr;
+  for (itr = 1; itr <= p->max_itr_association && success; itr++) { /* :102 */
+    P.nm = build_problem(scans, n, par, p, itr, brute, M, &nres);
+    if (nres <= 1) { success = 0; break; } /* :370-371, :114-115 */
+    ss = lm_solve(&P, par[n - 1], p->max_solver_iterations);
+    success = (ss.termination != 2); /* IsSolutionUsable */
+    if (success) { tsrc_last[0] = par[n - 1][0]; tsrc_last[1] = par[n - 1][1]; tsrc_last[2] = par[n - 1][2]; } /* :119-121 */
+    if (itr - 1 < CFO_MAX_OUTER) {
+      S.inner_iterations[itr - 1] = ss.num_iterations; S.termination[itr - 1] = ss.termination;
+      S.outer_cost[itr - 1] = ss.final_cost;
+      S.outer_pose[itr - 1][0] = par[n - 1][0]; S.outer_pose[itr - 1][1] = par[n - 1][1]; S.outer_pose[itr - 1][2] = par[n - 1][2];
+    }
+    const double current_score = ss.final_cost;
+    const double rel_improvement = (prev_score - current_score) / prev_score;
+    if (itr > p->min_itr) { /* :134-149 */
+      if (prev_score < current_score) { par[n - 1][0] = prev_par[0]; par[n - 1][1] = prev_par[1]; par[n - 1][2] = prev_par[2]; break; }
+      else if (rel_improvement < 0.00001) break;
+      else if (ss.last_relative_decrease < 0.00001 || ss.num_iterations == 1) break;
+    }
+    prev_score = current_score;
+    prev_par[0] = par[n - 1][0]; prev_par[1] = par[n - 1][1]; prev_par[2] = par[n - 1][2];
+  }
+  S.outer_iterations = itr;
+  S.usable = success;
+  S.num_residuals = nres; S.num_residual_blocks = P.nm; S.final_cost = ss.final_cost;
+  int ret = 0;
+  if (success) {
+    S.score = ss.final_cost / nres; /* :166 */
+    if (cov6) default_cov(cov6);
+    /* Tsrc[i] = vectorToAffine3d(parameters[i]) -> the caller reads (x,y,atan2(sin,cos)) */
+    for (int i = 0; i < n; i++) { poses_xyt[3 * i] = par[i][0]; poses_xyt[3 * i + 1] = par[i][1]; poses_xyt[3 * i + 2] = par[i][2]; }
+    /* GetCovariance (:392-433): [3P] ceres::Covariance = (J~^T J~)^-1 at the final parameters */
+    double g[3], H[6];
+    evaluate(&P, par[n - 1], g, H);
+    const double a = H[0], b = H[1], c = H[2], d = H[3], e = H[4], f = H[5];
+    const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
+    const double det = a * C00 + b * C01 + c * C02;
+    const int dof = nres - 3;
+    if (det > 0 && isfinite(det) && dof != 0) {
+      const double sc = 30 * (ss.final_cost / dof) / det;
+      const double c00 = sc * C00, c01 = sc * C01, c02 = sc * C02, c11 = sc * (a * f - c * c), c22 = sc * (a * d - b * b);
+      if (cov6) {
+        for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        cov6[0] = c00; cov6[1] = c01; cov6[6] = c01; cov6[7] = c11;
+        cov6[35] = c22; cov6[5] = c02; cov6[30] = c02; /* (1,5)/(5,1) left 0: :426-430 */
+      }
+      ret = 1;
+    }
+  } else {
+    poses_xyt[3 * (n - 1)] = tsrc_last[0]; poses_xyt[3 * (n - 1) + 1] = tsrc_last[1]; poses_xyt[3 * (n - 1) + 2] = tsrc_last[2];
+  }
+  S.success = ret;
+  if (out) *out = S;
+  free(M); free(par);
+  return ret;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Caller: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259)
+ * ------------------------------------------------------------------------------------------ */
+#define CFO_MAX_KEYFRAMES 64
+struct cfo_fuser {
+  cfo_params par;
+  aff2 T_prev, Tmot, Tcurrent;
+  cfo_scan* kf_scan[CFO_MAX_KEYFRAMES];
+  aff2 kf_pose[CFO_MAX_KEYFRAMES];
+  int nkf;
+  cfo_scan* last_scan; int last_scan_owned;
+  cfo_reg_summary last;
+  double timers[4];
+  long frames;
+};
+
+static aff2 aff_identity(void) { aff2 T; T.l[0] = 1; T.l[1] = 0; T.l[2] = 0; T.l[3] = 1; T.t[0] = T.t[1] = 0; return T; }
+
+cfo_fuser* cfo_fuser_create(const cfo_params* p) {
+  cfo_fuser* f = (cfo_fuser*)calloc(1, sizeof(cfo_fuser));
+  f->par = *p;
+  if (f->par.submap_scan_size > CFO_MAX_KEYFRAMES) f->par.submap_scan_size = CFO_MAX_KEYFRAMES;
+  f->T_prev = f->Tmot = f->Tcurrent = aff_identity();
+  return f;
+}
+void cfo_fuser_free(cfo_fuser* f) {
+  if (!f) return;
+  for (int i = 0; i < f->nkf; i++) cfo_scan_free(f->kf_scan[i]);
+  if (f->last_scan_owned) cfo_scan_free(f->last_scan);
+  free(f);
+}
+int cfo_fuser_num_keyframes(const cfo_fuser* f) { return f->nkf; }
+const cfo_reg_summary* cfo_fuser_last_summary(const cfo_fuser* f) { return &f->last; }
+const cfo_scan* cfo_fuser_last_scan(const cfo_fuser* f) { return f->last_scan; }
+void cfo_fuser_timers(const cfo_fuser* f, double t[4]) { for (int i = 0; i < 4; i++) t[i] = f->timers[i]; }
+
+static void add_to_reference(cfo_fuser* f, cfo_scan* s, const aff2* T) { /* :470-476 */
+  f->kf_scan[f->nkf] = s; f->kf_pose[f->nkf] = *T; f->nkf++;
+  if (f->nkf > f->par.submap_scan_size) {
+    cfo_scan_free(f->kf_scan[0]);
+    for (int i = 0; i + 1 < f->nkf; i++) { f->kf_scan[i] = f->kf_scan[i + 1]; f->kf_pose[i] = f->kf_pose[i + 1]; }
+    f->nkf--;
+  }
+}
+
+int cfo_fuser_process_cloud(cfo_fuser* f, float* xyi, int n, double pose_xyt[3]) {
+  const cfo_params* p = &f->par;
+  double t0 = now_s();
+  const aff2 TprevMot = f->Tmot; /* :146 */
+  if (p->compensate) { double mot[3]; aff_to_xyt(&TprevMot, mot); cfo_compensate(xyi, n, mot, p->radar_ccw); }
+  double t1 = now_s();
+  if (f->last_scan_owned) { cfo_scan_free(f->last_scan); f->last_scan_owned = 0; }
+  cfo_scan* cur = cfo_scan_create(xyi, n, p, 0); /* :161 */
+  f->last_scan = cur;
+  double t2 = now_s();
+  f->timers[1] += t1 - t0; f->timers[2] += t2 - t1;
+  if (!cur) return -1;
+  const aff2 Tguess = aff_mul(&f->T_prev, &TprevMot); /* :166, use_guess forced true (offline_odometry.cpp:273) */
+  f->frames++;
+  if (f->nkf == 0) { /* :171-177 */
+    const aff2 I = aff_identity();
+    add_to_reference(f, cur, &I);
+    memset(&f->last, 0, sizeof(f->last));
+    aff_to_xyt(&f->Tcurrent, pose_xyt);
+    return 0;
+  }
+  /* FormatScans (:478-494): keyframes oldest first, current last */
+  cfo_scan* scans[CFO_MAX_KEYFRAMES + 1];
+  double poses[3 * (CFO_MAX_KEYFRAMES + 1)], cov6[36];
+  const int ns = f->nkf + 1;
+  for (int i = 0; i < f->nkf; i++) { scans[i] = f->kf_scan[i]; aff_to_xyt(&f->kf_pose[i], &poses[3 * i]); }
+  scans[ns - 1] = cur; aff_to_xyt(&Tguess, &poses[3 * (ns - 1)]);
+  cfo_register(scans, ns, poses, cov6, p, 0, &f->last); /* result ignored: shadowed 'success' (:184-186) */
+  double t3 = now_s();
+  f->timers[3] += t3 - t2;
+  aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]); /* :195 */
+  const aff2 Tpi = aff_inv(&f->T_prev);
+  const aff2 Tmot_current = aff_mul(&Tpi, &Tcurrent);
+  { /* AccelerationVelocitySanityCheck (:76-94) */
+    const double dt = 0.25, lim = 200;
+    const double vel = sqrt(Tmot_current.t[0] * Tmot_current.t[0] + Tmot_current.t[1] * Tmot_current.t[1]) / dt;
+    const double ax = (Tmot_current.t[0] - f->Tmot.t[0]) / (dt * dt), ay = (Tmot_current.t[1] - f->Tmot.t[1]) / (dt * dt);
+    const double acc = sqrt(ax * ax + ay * ay);
+    if (acc > lim || vel > lim) Tcurrent = Tguess; /* :198-199 */
+  }
+  f->Tmot = aff_mul(&Tpi, &Tcurrent); /* :200 */
+  f->Tcurrent = Tcurrent;
+  /* KeyFrameBasedFuse (:62-73) */
+  const aff2 Tki = aff_inv(&f->kf_pose[f->nkf - 1]);
+  const aff2 Tkeydiff = aff_mul(&Tki, &Tcurrent);
+  int fuse = 1;
+  if (p->use_keyframe) {
+    const double tn = sqrt(Tkeydiff.t[0] * Tkeydiff.t[0] + Tkeydiff.t[1] * Tkeydiff.t[1]);
+    const double rot = fabs(atan2(Tkeydiff.l[2], Tkeydiff.l[3]));
+    fuse = (tn > p->min_keyframe_dist) || (rot > p->min_keyframe_rot_deg * M_PI / 180.0);
+  }
+  if (fuse) add_to_reference(f, cur, &Tcurrent); /* :234-247 */
+  else f->last_scan_owned = 1;
+  f->T_prev = Tcurrent; /* :257 */
+  aff_to_xyt(&Tcurrent, pose_xyt);
+  return 0;
+}
+
+int cfo_fuser_process_polar(cfo_fuser* f, const uint8_t* img, int A, int R, double pose_xyt[3]) {
+  const cfo_params* p = &f->par;
+  const int k = p->k_strongest;
+  double t0 = now_s();
+  uint32_t* slots = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)A * (size_t)k);
+  float* xyi = (float*)malloc(sizeof(float) * 3 * (size_t)A * (size_t)k);
+  float* xyi_peaks = (float*)malloc(sizeof(float) * 3 * (size_t)A * (size_t)k);
+  cfo_filter(img, A, R, (int)p->z_min, k, slots); /* radar_driver.cpp:58: float z_min -> const int */
+  const int n = cfo_cloud(slots, A, k, p->range_res, p->min_distance, 0, xyi);       /* :59 */
+  const int np = cfo_cloud(slots, A, k, p->range_res, p->min_distance, 1, xyi_peaks); /* :60 */
+  f->timers[0] += now_s() - t0;
+  if (p->compensate) { double mot[3]; aff_to_xyt(&f->Tmot, mot); cfo_compensate(xyi_peaks, np, mot, p->radar_ccw); } /* odometrykeyframefuser.cpp:149 */
+  const int rc = cfo_fuser_process_cloud(f, xyi, n, pose_xyt);
+  free(slots); free(xyi); free(xyi_peaks);
+  return rc;
+}
