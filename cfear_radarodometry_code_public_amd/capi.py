@@ -204,3 +204,157 @@ class Context:
         self._check(self._L.cfear_time_kstrongest(self._h, _addr(d_polar), int(n_scans), _addr(d_slots), int(warmup),
                                                   int(iters), C.byref(t)), "cfear_time_kstrongest")
         return t.value
+
+    # ---- stage 1 -> clouds (radarDriver::CallbackOffline) ----
+    def filter_polar(self, polar, peaks=True):
+        """polar: uint8 [A,R] numpy (host) or a device pointer/torch tensor (device=True path via _addr)."""
+        c, cp = C.c_void_p(), C.c_void_p()
+        if isinstance(polar, np.ndarray):
+            polar = np.ascontiguousarray(polar, dtype=np.uint8)
+            assert polar.shape == (self.A, self.R)
+            rc = self._L.cfear_filter_polar(self._h, polar.ctypes.data, C.byref(c), C.byref(cp) if peaks else None)
+        else:
+            rc = self._L.cfear_filter_polar_device(self._h, _addr(polar), C.byref(c), C.byref(cp) if peaks else None)
+        self._check(rc, "cfear_filter_polar")
+        return Cloud(self, c), (Cloud(self, cp) if peaks else None)
+
+    def cloud_upload(self, xyi):
+        xyi = np.ascontiguousarray(xyi, dtype=np.float32).reshape(-1, 3)
+        c = C.c_void_p()
+        self._check(self._L.cfear_cloud_upload(self._h, xyi.ctypes.data, xyi.shape[0], C.byref(c)), "cfear_cloud_upload")
+        return Cloud(self, c)
+
+    def compensate(self, cloud, motion_xyt, ccw):
+        m = np.asarray(motion_xyt, dtype=np.float64).copy()
+        self._check(self._L.cfear_compensate(self._h, cloud._h, m.ctypes.data, int(ccw)), "cfear_compensate")
+
+    # ---- stage 2 (MapPointNormal) ----
+    def scan_create(self, cloud):
+        s = C.c_void_p()
+        self._check(self._L.cfear_scan_create(self._h, cloud._h, C.byref(s)), "cfear_scan_create")
+        return Scan(self, s)
+
+    # ---- stage 3 (n_scan_normal_reg::Register) ----
+    def register(self, scans, poses):
+        n = len(scans)
+        arr = (C.c_void_p * n)(*[s._h for s in scans])
+        P = np.ascontiguousarray(poses, dtype=np.float64).reshape(n, 3).copy()
+        cov = np.zeros(36)
+        S = RegSummary()
+        self._check(self._L.cfear_register(self._h, arr, n, P.ctypes.data, cov.ctypes.data, C.byref(S)), "cfear_register")
+        return bool(S.success), P, cov.reshape(6, 6), S
+
+    def odometry(self, n_sequences):
+        return Odometry(self, n_sequences)
+
+
+class Cloud:
+    def __init__(self, ctx, h):
+        self._ctx, self._h = ctx, h
+
+    def release(self):
+        if self._h and self._ctx._h:
+            self._ctx._L.cfear_cloud_release(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        n = C.c_int()
+        self._ctx._check(self._ctx._L.cfear_cloud_size(self._ctx._h, self._h, C.byref(n)), "cfear_cloud_size")
+        return n.value
+
+    def download(self):
+        n = self.size
+        out = np.zeros((max(n, 1), 3), dtype=np.float32)
+        m = C.c_int()
+        self._ctx._check(self._ctx._L.cfear_cloud_download(self._ctx._h, self._h, out.ctypes.data, n, C.byref(m)),
+                         "cfear_cloud_download")
+        return out[:n]
+
+
+class Scan:
+    def __init__(self, ctx, h):
+        self._ctx, self._h = ctx, h
+
+    def release(self):
+        if self._h and self._ctx._h:
+            self._ctx._L.cfear_scan_release(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        n = C.c_int()
+        self._ctx._check(self._ctx._L.cfear_scan_size(self._ctx._h, self._h, C.byref(n)), "cfear_scan_size")
+        return n.value
+
+    def cells(self):
+        n = self.size
+        out = np.zeros(max(n, 1), dtype=CELL_DTYPE)
+        m = C.c_int()
+        self._ctx._check(self._ctx._L.cfear_scan_download_cells(self._ctx._h, self._h, out.ctypes.data, n, C.byref(m)),
+                         "cfear_scan_download_cells")
+        return out[:n]
+
+    def closest(self, qxy, d):
+        q = np.ascontiguousarray(qxy, dtype=np.float64).reshape(-1, 2)
+        idx = np.zeros(q.shape[0], dtype=np.int32)
+        self._ctx._check(self._ctx._L.cfear_scan_closest(self._ctx._h, self._h, q.ctypes.data, q.shape[0], float(d),
+                                                         idx.ctypes.data), "cfear_scan_closest")
+        return idx
+
+
+class Odometry:
+    """Batched OdometryKeyframeFuser: B independent sequences, all state on the device."""
+
+    def __init__(self, ctx, n_sequences):
+        self._ctx, self.B = ctx, int(n_sequences)
+        self._h = C.c_void_p()
+        ctx._check(ctx._L.cfear_odometry_create(ctx._h, self.B, C.byref(self._h)), "cfear_odometry_create")
+
+    def release(self):
+        if self._h and self._ctx._h:
+            self._ctx._L.cfear_odometry_destroy(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._ctx._check(self._ctx._L.cfear_odometry_reset(self._ctx._h, self._h), "cfear_odometry_reset")
+
+    def step_device(self, d_polar):
+        self._ctx._check(self._ctx._L.cfear_odometry_step_device(self._ctx._h, self._h, _addr(d_polar)),
+                         "cfear_odometry_step_device")
+
+    def step_host(self, polar):
+        polar = np.ascontiguousarray(polar, dtype=np.uint8)
+        assert polar.shape == (self.B, self._ctx.A, self._ctx.R)
+        self._ctx._check(self._ctx._L.cfear_odometry_step_host(self._ctx._h, self._h, polar.ctypes.data),
+                         "cfear_odometry_step_host")
+
+    def poses(self):
+        out = np.zeros((self.B, 3))
+        self._ctx._check(self._ctx._L.cfear_odometry_poses(self._ctx._h, self._h, out.ctypes.data), "cfear_odometry_poses")
+        return out
+
+    def summary(self, sequence):
+        S = RegSummary()
+        nc, nk = C.c_int(), C.c_int()
+        self._ctx._check(self._ctx._L.cfear_odometry_summary(self._ctx._h, self._h, int(sequence), C.byref(S), C.byref(nc),
+                                                             C.byref(nk)), "cfear_odometry_summary")
+        return S, nc.value, nk.value

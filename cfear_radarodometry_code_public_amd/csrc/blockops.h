@@ -1,0 +1,107 @@
+// blockops.h -- workgroup-level primitives for gfx950 (wave64). Every function here must be
+// reached by ALL threads of the block (they contain __syncthreads()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cfear_dev {
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// ---- wave reductions (64 lanes) via ds_bpermute shuffles ----
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// scratch: >= 32 elements of T in LDS. Result broadcast to all threads.
+__device__ __forceinline__ float block_min(float v, float* scratch) {
+  v = wave_min(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane_id() == 0) scratch[w] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nw; i++) r = fminf(r, scratch[i]);
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane_id() == 0) scratch[w] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nw; i++) r = fmaxf(r, scratch[i]);
+  return r;
+}
+__device__ __forceinline__ int block_sum(int v, int* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane_id() == 0) scratch[w] = v;
+  __syncthreads();
+  int r = 0;
+  for (int i = 0; i < nw; i++) r += scratch[i];
+  return r;
+}
+
+// Exclusive prefix sum of one int per thread; *total = block sum. scratch: >= 32 ints in LDS.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) {
+    const int s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// In-place ascending bitonic sort of keys[0..p2) (p2 = power of two, padded by the caller).
+__device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int p2) {
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (p2 >> 1); t += blockDim.x) {
+        // t enumerates the pairs (i, i^j) with i having bit j clear
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int ixj = i | j;
+        const uint64_t a = keys[i], b = keys[ixj];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace cfear_dev

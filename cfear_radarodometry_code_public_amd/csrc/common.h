@@ -51,5 +51,7 @@ static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_
     if (_e != hipSuccess) return cfear_fail((ctx), CFEAR_ERR_HIP, #call, _e); \
   } while (0)
 
+// cabi.hip
+extern "C" int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
 // kstrongest.hip
 int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots);

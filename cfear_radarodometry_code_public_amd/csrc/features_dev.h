@@ -1,0 +1,383 @@
+// features_dev.h -- K3/K4/K5 device code: polar slots -> Cartesian cloud (+ motion compensation)
+// -> oriented surface points (MapPointNormal) + the uniform grid that replaces the FLANN kd-tree
+// over cell means. One workgroup builds one scan; all functions are block-collective.
+//
+// Reference: radar_filters.cpp:309-337 (cloud), utils.cpp:96-113 + utils.h:28-32 (compensation),
+// pointnormal.cpp:7-63, 151-162, 265-297 (features). Third-party behaviour restated from
+// SURVEY.md section 9 (PCL VoxelGrid, FLANN radius search).
+#pragma once
+#include "blockops.h"
+#include "../../include/cfear_hip.h"
+
+namespace cfear_dev {
+
+// Device-resident MapPointNormal. Lives in device memory; the arrays are one flat allocation.
+struct ScanDev {
+  int n_points;   // input_ size (cloud after the min-range cut, compensated)
+  int n_samples;  // voxel centroids
+  int n_cells;    // valid cells
+  int status;     // 0 ok, CFEAR_ERR_EMPTY on an empty cloud
+  float gminx, gminy, gcell;  // uniform grid over float cell means
+  int gw, gh;
+  int cap_points, cap_cells, cap_grid;
+  float* xyi;         // [cap_points][3]
+  cfear_cell* cells;  // [cap_cells]
+  float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
+  int* gstart;        // [cap_grid + 1]
+  int* gorder;        // [cap_cells] cell indices bucketed by grid cell
+};
+
+struct FeatureParams {
+  float range_res, min_distance;
+  float radius;              // (float)par.res, pointnormal.h:118
+  double downsample_factor;  // pointnormal.h:241
+  int weight_intensity;
+  double assoc_radius;       // registration.h:122 (sizes the NN grid)
+  int dbg_stage;             // bring-up only: stop after stage N (0 = run everything)
+};
+
+// Working memory of one block. keys/vstart may point to LDS (small clouds) or to global memory.
+struct FeatureScratch {
+  uint64_t* keys;      // [p2cap] (voxel idx << 32 | point index), sorted. NB: a 24-bit packing with an
+                       // '& 0xFFFFFF' extract is miscompiled by hipcc 7.2 (mask dropped before v_mad_u64_u32)
+  int* vstart;         // [cap_points + 1]
+  float* samples;      // [cap_points][3] voxel centroids (global)
+  cfear_cell* tmp;     // [cap_points] candidate cells in sample order (global)
+  int* flags;          // [cap_points]
+  int* red_i;          // LDS, >= 64 ints
+  float* red_f;        // LDS, >= 64 floats
+};
+
+#define CFEAR_TWO_PI 6.283185307179586476925286766559
+
+// getPeaksFilteredPointCloud (radar_filters.cpp:309-337): row-major over (bearing, slot).
+// trig[b] = (cos, sin) of theta = (b+1)/A*2pi computed by the host libm. Returns the point count.
+__device__ inline int cloud_build_block(const uint32_t* __restrict__ slots, int A, int k,
+                                        const double* __restrict__ trig, float range_res_f, float min_distance_f,
+                                        int peaks, float* __restrict__ xyi, int cap, int* red_i) {
+  const double range_res = (double)range_res_f;
+  const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // :315
+  const double range_res_half = range_res / 2.0;
+  const int items = A * k;
+  const int ipt = (items + blockDim.x - 1) / blockDim.x;
+  const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) {
+    const uint32_t s = slots[i];
+    const bool ok = CFEAR_SLOT_VALID(s) && (!peaks || CFEAR_SLOT_PEAK(s)) && CFEAR_SLOT_RANGE(s) > min_range_bin;  // :327
+    cnt += ok ? 1 : 0;
+  }
+  int total;
+  int o = block_exclusive_scan(cnt, red_i, &total);
+  for (int i = i0; i < i1; i++) {
+    const uint32_t s = slots[i];
+    const int range = CFEAR_SLOT_RANGE(s);
+    const bool ok = CFEAR_SLOT_VALID(s) && (!peaks || CFEAR_SLOT_PEAK(s)) && range > min_range_bin;
+    if (ok && o < cap) {
+      const int b = i / k;
+      const double cos_t = trig[2 * b], sin_t = trig[2 * b + 1];
+      const double rad = range_res_half + range_res * range;
+      xyi[3 * o + 0] = (float)(rad * cos_t);  // :329
+      xyi[3 * o + 1] = (float)(rad * sin_t);  // :330
+      xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
+      o++;
+    }
+  }
+  __syncthreads();
+  return total < cap ? total : cap;
+}
+
+// Compensate (utils.cpp:96-107) with GetRelTimeStamp (utils.h:28-32)
+__device__ inline void compensate_block(float* __restrict__ xyi, int n, double m0, double m1, double m2, int ccw) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double px = (double)xyi[3 * i], py = (double)xyi[3 * i + 1];
+    const double a = atan2(py, px);
+    const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+    const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+    const double s1 = sin(d * m2), c1 = cos(d * m2);
+    const double tx = d * m0, ty = d * m1;
+    xyi[3 * i + 0] = (float)((c1 * px + (-s1) * py) + tx);
+    xyi[3 * i + 1] = (float)((s1 * px + c1 * py) + ty);
+  }
+  __syncthreads();
+}
+
+// closed-form symmetric 2x2 eigen-decomposition; identical formulas to the oracle's eig2()
+__device__ inline void eig2(double a, double b, double c, double* lmin, double* lmax, double vmin[2], double vmax[2]) {
+  const double t1 = 0.5 * (a + c);
+  const double d = 0.5 * (a - c);
+  const double t0 = sqrt(d * d + b * b);
+  *lmin = t1 - t0;
+  *lmax = t1 + t0;
+  const double v0x = *lmax - c, v0y = b;
+  const double v1x = b, v1y = *lmax - a;
+  const double n0 = v0x * v0x + v0y * v0y, n1 = v1x * v1x + v1y * v1y;
+  double vx, vy, nn;
+  if (n0 >= n1) { vx = v0x; vy = v0y; nn = n0; } else { vx = v1x; vy = v1y; nn = n1; }
+  if (!(nn > 0.0)) { vmax[0] = 0; vmax[1] = 1; vmin[0] = 1; vmin[1] = 0; return; }
+  const double inv = 1.0 / sqrt(nn);
+  vmax[0] = vx * inv; vmax[1] = vy * inv;
+  vmin[0] = -vmax[1]; vmin[1] = vmax[0];
+}
+
+__device__ inline int lower_bound_key(const uint64_t* keys, int n, uint64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi.
+// p2 = power of two >= n with p2 <= capacity of W.keys.
+__device__ inline void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const float* __restrict__ xyi = S->xyi;
+  if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
+    if (tid == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = 0; S->status = CFEAR_ERR_EMPTY; S->gw = 0; S->gh = 0; }
+    __syncthreads();
+    return;
+  }
+  // ---- PCL VoxelGrid (pointnormal.cpp:277-280), leaf = radius_/downsample_factor ----
+  const float leaf = (float)((double)P.radius / P.downsample_factor);
+  const float inv = 1.0f / leaf;
+  float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+  for (int i = tid; i < n; i += nt) {
+    const float x = xyi[3 * i], y = xyi[3 * i + 1];
+    mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+  }
+  if (P.dbg_stage == 8) return;
+  mnx = block_min(mnx, W.red_f); mxx = block_max(mxx, W.red_f);
+  mny = block_min(mny, W.red_f); mxy = block_max(mxy, W.red_f);
+  if (P.dbg_stage == 7) return;
+  const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
+  const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
+  const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
+  for (int i = tid; i < p2; i += nt) {
+    uint64_t key = ~0ull;
+    if (i < n) {
+      const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
+      const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+      const uint64_t idx = (uint64_t)((long long)ijk0 + (long long)ijk1 * (long long)div0);
+      key = (idx << 32) | (uint64_t)(uint32_t)i;
+    }
+    W.keys[i] = key;
+  }
+  if (P.dbg_stage == 1) return;
+  block_bitonic_sort(W.keys, p2);
+  if (P.dbg_stage == 2) return;
+  // ---- voxel segments ----
+  {
+    const int ipt = (n + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(n, i0 + ipt);
+    int cnt = 0;
+    for (int i = i0; i < i1; i++) cnt += (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) ? 1 : 0;
+    int nv;
+    int o = block_exclusive_scan(cnt, W.red_i, &nv);
+    for (int i = i0; i < i1; i++)
+      if (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) W.vstart[o++] = i;
+    if (tid == 0) { W.vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
+    __syncthreads();
+  }
+  const int nv = S->n_samples;
+  if (P.dbg_stage == 3) return;
+  // ---- centroids: float sums in ascending (voxel, point) order, divided by float(count) ----
+  for (int v = tid; v < nv; v += nt) {
+    const int a = W.vstart[v], b = W.vstart[v + 1];
+    float sx = 0.f, sy = 0.f, si = 0.f;
+    for (int q = a; q < b; q++) {
+      const int pi = (int)(uint32_t)W.keys[q];
+      sx += xyi[3 * pi]; sy += xyi[3 * pi + 1]; si += xyi[3 * pi + 2];
+    }
+    const float cnt = (float)(b - a);
+    W.samples[3 * v] = sx / cnt; W.samples[3 * v + 1] = sy / cnt; W.samples[3 * v + 2] = si / cnt;
+  }
+  __syncthreads();
+  if (P.dbg_stage == 4) return;
+  // ---- radius search + cell statistics per sample point (pointnormal.cpp:286-296, :7-63) ----
+  const float r2 = (float)((double)P.radius * (double)P.radius);
+  const float rq = P.radius * 1.0001f;
+  for (int v = tid; v < nv; v += nt) {
+    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+    int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
+    int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
+    gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
+    int ra[8], rb[8];
+    int nrows = 0;
+    for (int gy = gy0; gy <= gy1 && nrows < 8; gy++) {
+      if (gx0 > gx1) break;
+      const uint64_t k0 = (uint64_t)((long long)gx0 + (long long)gy * div0), k1 = (uint64_t)((long long)gx1 + (long long)gy * div0);
+      ra[nrows] = lower_bound_key(W.keys, n, k0 << 32);
+      rb[nrows] = lower_bound_key(W.keys, n, (k1 + 1) << 32);
+      nrows++;
+    }
+    // pass A: neighbour count and weight sum
+    int m = 0;
+    double sum = 0;
+    for (int r = 0; r < nrows; r++)
+      for (int q = ra[r]; q < rb[r]; q++) {
+        const int i = (int)(uint32_t)W.keys[q];
+        const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
+        float d2 = dx * dx; d2 += dy * dy;
+        if (d2 < r2) { m++; sum += P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0; }
+      }
+    cfear_cell c;
+    c.valid = 0; c.nsamples = m;
+    if (m >= 6) {  // :291
+      double ux = 0, uy = 0;
+      for (int r = 0; r < nrows; r++)
+        for (int q = ra[r]; q < rb[r]; q++) {
+          const int i = (int)(uint32_t)W.keys[q];
+          const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
+          float d2 = dx * dx; d2 += dy * dy;
+          if (d2 < r2) {
+            const double w = (P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0) / sum;
+            ux += w * (double)xyi[3 * i]; uy += w * (double)xyi[3 * i + 1];
+          }
+        }
+      double cxx = 0, cyx = 0, cyy = 0;
+      for (int r = 0; r < nrows; r++)
+        for (int q = ra[r]; q < rb[r]; q++) {
+          const int i = (int)(uint32_t)W.keys[q];
+          const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
+          float d2 = dx * dx; d2 += dy * dy;
+          if (d2 < r2) {
+            const double w = (P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0) / sum;
+            const double ex = (double)xyi[3 * i] - ux, ey = (double)xyi[3 * i + 1] - uy;
+            cxx += ex * (w * ex); cyx += ey * (w * ex); cyy += ey * (w * ey);
+          }
+        }
+      double lmin, lmax, vmin[2], vmax[2];
+      eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
+      const double cond = fabs(lmax / lmin);  // :53
+      const double det = lmax * lmin;         // :54
+      c.valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
+      c.scale = log(1.0 + cond / 2);  // :57
+      if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
+      c.mean[0] = ux; c.mean[1] = uy;
+      c.cov[0] = cxx; c.cov[1] = cyx; c.cov[2] = cyy;
+      c.normal[0] = vmin[0]; c.normal[1] = vmin[1];
+      c.orth[0] = vmax[0]; c.orth[1] = vmax[1];
+      c.lambda_min = lmin; c.lambda_max = lmax;
+      c.sum_intensity = sum; c.avg_intensity = sum / m;
+      if (c.valid) W.tmp[v] = c;
+    }
+    W.flags[v] = c.valid;
+  }
+  __syncthreads();
+  if (P.dbg_stage == 5) return;
+  // ---- keep valid cells in sample order (pointnormal.cpp:292-294) ----
+  {
+    const int ipt = (nv + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
+    int cnt = 0;
+    for (int i = i0; i < i1; i++) cnt += W.flags[i];
+    int nc;
+    int o = block_exclusive_scan(cnt, W.red_i, &nc);
+    for (int i = i0; i < i1; i++)
+      if (W.flags[i] && o < S->cap_cells) {
+        const cfear_cell c = W.tmp[i];
+        S->cells[o] = c;
+        S->mean_f[2 * o] = (float)c.mean[0];
+        S->mean_f[2 * o + 1] = (float)c.mean[1];
+        o++;
+      }
+    if (tid == 0) S->n_cells = nc < S->cap_cells ? nc : S->cap_cells;
+    __syncthreads();
+  }
+  if (P.dbg_stage == 6) return;
+  // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
+  const int nc = S->n_cells;
+  float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
+  for (int i = tid; i < nc; i += nt) {
+    const float x = S->mean_f[2 * i], y = S->mean_f[2 * i + 1];
+    gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
+  }
+  gx0 = block_min(gx0, W.red_f); gx1 = block_max(gx1, W.red_f);
+  gy0 = block_min(gy0, W.red_f); gy1 = block_max(gy1, W.red_f);
+  if (nc == 0) {
+    if (tid == 0) { S->gw = 0; S->gh = 0; S->gcell = 1.f; S->gminx = 0.f; S->gminy = 0.f; }
+    __syncthreads();
+    return;
+  }
+  float gcell = (float)(2.0 * P.assoc_radius);
+  int gw, gh;
+  for (;;) {
+    gw = (int)floorf((gx1 - gx0) / gcell) + 1;
+    gh = (int)floorf((gy1 - gy0) / gcell) + 1;
+    if ((long long)gw * gh <= S->cap_grid) break;
+    gcell *= 2.f;
+  }
+  const int G = gw * gh;
+  for (int g = tid; g <= G; g += nt) S->gstart[g] = 0;
+  __syncthreads();
+  for (int i = tid; i < nc; i += nt) {
+    int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+    atomicAdd(&S->gstart[cy * gw + cx + 1], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of the bucket counts (gstart[g+1] holds count of bucket g)
+    const int ipt = (G + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
+    int cnt = 0;
+    for (int g = i0; g < i1; g++) cnt += S->gstart[g + 1];
+    int tot;
+    int o = block_exclusive_scan(cnt, W.red_i, &tot);
+    for (int g = i0; g < i1; g++) { const int c = S->gstart[g + 1]; S->gstart[g + 1] = o + c; o += c; }
+    __syncthreads();
+  }
+  // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query
+  // breaks exact ties by cell index). Per-bucket cursors live in W.vstart (free after the radius search); needs G <= cap_points + 1.
+  int* cursor = W.vstart;
+  const bool cursor_ok = G <= S->cap_points;
+  if (cursor_ok) {
+    for (int g = tid; g < G; g += nt) cursor[g] = S->gstart[g];
+    __syncthreads();
+    for (int i = tid; i < nc; i += nt) {
+      int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+      const int pos = atomicAdd(&cursor[cy * gw + cx], 1);
+      S->gorder[pos] = i;
+    }
+  } else if (tid == 0) {
+    // tiny clouds with a huge bounding box: serial fill (rare)
+    for (int g = 0; g < G; g++) {
+      int pos = S->gstart[g];
+      for (int i = 0; i < nc; i++) {
+        int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+        cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+        if (cy * gw + cx == g) S->gorder[pos++] = i;
+      }
+    }
+  }
+  if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
+  __syncthreads();
+}
+
+// GetClosestIdx (pointnormal.cpp:238-254): 1-NN over the float cell means, accepted iff d2 < d*d.
+// Exact-distance ties resolve to the lowest cell index (same rule as the oracle).
+__device__ inline int scan_closest(const ScanDev* __restrict__ S, double px, double py, double d) {
+  const float qx = (float)px, qy = (float)py;
+  if (S->n_cells <= 0 || S->gw <= 0) return -1;
+  const double m = d * (1.0 + 1e-6) + 1e-6;
+  const double gc = (double)S->gcell;
+  int gx0 = (int)floor(((double)qx - m - (double)S->gminx) / gc), gx1 = (int)floor(((double)qx + m - (double)S->gminx) / gc);
+  int gy0 = (int)floor(((double)qy - m - (double)S->gminy) / gc), gy1 = (int)floor(((double)qy + m - (double)S->gminy) / gc);
+  // the builder clamps bucket coordinates, so clamp the query window the same way
+  gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, S->gw - 1); gy1 = min(gy1, S->gh - 1);
+  int best = -1;
+  float bd = 3.4e38f;
+  for (int gy = gy0; gy <= gy1; gy++) {
+    if (gx0 > gx1) break;
+    const int a = S->gstart[gy * S->gw + gx0], b = S->gstart[gy * S->gw + gx1 + 1];
+    for (int q = a; q < b; q++) {
+      const int i = S->gorder[q];
+      const float dx = qx - S->mean_f[2 * i], dy = qy - S->mean_f[2 * i + 1];
+      float d2 = dx * dx; d2 += dy * dy;
+      if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+    }
+  }
+  if (best >= 0 && (double)bd < d * d) return best;
+  return -1;
+}
+
+}  // namespace cfear_dev

@@ -1,0 +1,715 @@
+// pipeline.hip -- kernels and C-ABI entry points for stages 1.5-3 and the batched odometry step.
+// Interface contract + reference citations: include/cfear_hip.h. Device code: features_dev.h,
+// registration_dev.h. One workgroup (1024 threads = 16 waves) owns one scan / one registration
+// problem / one sequence, so a batch of B sequences fills B compute units with no host round trip
+// inside a frame: filter kernel -> odometry_step_kernel, both asynchronous on the context stream.
+#include <math.h>
+#include <stdlib.h>
+
+#include <new>
+
+#include "common.h"
+#include "registration_dev.h"
+
+using namespace cfear_dev;
+
+namespace {
+
+constexpr int BLOCK = 1024;
+constexpr int LDS_KEYS = 8192;  // u64 sort keys kept in LDS when A*k <= 8192
+constexpr int MAX_SCANS = 64;   // keyframes + current
+
+struct LdsLayout {
+  // byte offsets into the dynamic LDS segment
+  static constexpr size_t red_d = 0;                                  // 320 doubles
+  static constexpr size_t par = red_d + 320 * sizeof(double);        // 3*MAX_SCANS doubles
+  static constexpr size_t red_i = par + 3 * MAX_SCANS * sizeof(double);  // 64 ints
+  static constexpr size_t red_f = red_i + 64 * sizeof(int);          // 64 floats
+  static constexpr size_t scanptr = red_f + 64 * sizeof(float);      // MAX_SCANS pointers
+  static constexpr size_t keys = scanptr + MAX_SCANS * sizeof(void*);   // LDS_KEYS u64 (optional)
+  static constexpr size_t vstart = keys + LDS_KEYS * sizeof(uint64_t);  // LDS_KEYS+1 ints (optional)
+  static constexpr size_t total_small = keys;
+  static constexpr size_t total_lds_keys = vstart + (LDS_KEYS + 8) * sizeof(int);
+};
+
+// Global per-block working memory (one per context for the per-call API, one per sequence for the batch).
+struct BlockScratch {
+  uint64_t* keys;   // [p2cap] (only used when the keys do not fit LDS)
+  int* vstart;      // [cap_points + 1]
+  float* samples;   // [cap_points * 3]
+  cfear_cell* tmp;  // [cap_points]
+  int* flags;       // [cap_points]
+  double* match;    // [8][pair_cap]
+  int* assoc;       // [pair_cap]
+  int cap_points, p2cap, pair_cap;
+};
+
+struct SeqState {  // OdometryKeyframeFuser members (odometrykeyframefuser.h:203-260) for one sequence
+  Aff2 T_prev, Tmot, Tcurrent;
+  int nkf, free_slot, frames, last_slot;
+  int ring[MAX_SCANS];
+  Aff2 kf_pose[MAX_SCANS];
+};
+
+struct OdoParams {
+  FeatureParams fp;
+  RegParams rp;
+  int A, k, compensate, ccw, use_keyframe, submap;
+  double min_keyframe_dist, min_keyframe_rot_deg;
+};
+
+__device__ inline FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds, bool lds_keys) {
+  FeatureScratch W;
+  W.keys = lds_keys ? reinterpret_cast<uint64_t*>(lds + LdsLayout::keys) : B.keys;
+  W.vstart = lds_keys ? reinterpret_cast<int*>(lds + LdsLayout::vstart) : B.vstart;
+  W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
+  W.red_i = reinterpret_cast<int*>(lds + LdsLayout::red_i);
+  W.red_f = reinterpret_cast<float*>(lds + LdsLayout::red_f);
+  return W;
+}
+__device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
+  RegScratch W;
+  const size_t c = (size_t)B.pair_cap;
+  W.tmx = B.match; W.tmy = B.match + c; W.a0 = B.match + 2 * c; W.a1 = B.match + 3 * c; W.a2 = B.match + 4 * c;
+  W.sx = B.match + 5 * c; W.sy = B.match + 6 * c; W.w = B.match + 7 * c;
+  W.assoc = B.assoc; W.sim = nullptr; W.cap = B.pair_cap;
+  W.red = reinterpret_cast<double*>(lds + LdsLayout::red_d);
+  W.red_i = reinterpret_cast<int*>(lds + LdsLayout::red_i);
+  return W;
+}
+__device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// ---- per-call kernels -------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void cloud_kernel(const uint32_t* slots, int A, int k, const double* trig, float rr,
+                                                      float md, int peaks, float* xyi, int cap, int* d_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LdsLayout::total_small];
+  const int n = cloud_build_block(slots, A, k, trig, rr, md, peaks, xyi, cap, reinterpret_cast<int*>(lds + LdsLayout::red_i));
+  if (threadIdx.x == 0) *d_n = n;
+}
+
+__global__ __launch_bounds__(BLOCK) void compensate_kernel(float* xyi, const int* d_n, double m0, double m1, double m2, int ccw) {
+  compensate_block(xyi, *d_n, m0, m1, m2, ccw);
+}
+
+template <bool LDSKEYS>
+__global__ __launch_bounds__(BLOCK) void features_kernel(ScanDev* S, const float* src_xyi, const int* d_n, FeatureParams P,
+                                                         BlockScratch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSKEYS ? LdsLayout::total_lds_keys : LdsLayout::total_small];
+  if (P.dbg_stage == -1) return;
+  int n = *d_n;
+  if (P.dbg_stage == -2) return;
+  if (n > S->cap_points) n = S->cap_points;
+  if (P.dbg_stage == -3) return;
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) S->xyi[i] = src_xyi[i];
+  __syncthreads();
+  if (P.dbg_stage == -4) return;
+  const FeatureScratch W = make_fscratch(B, lds, LDSKEYS);
+  features_block(S, n, P, W, next_pow2(n));
+}
+
+__global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq) idx[i] = scan_closest(S, q[2 * i], q[2 * i + 1], d);
+}
+
+__global__ __launch_bounds__(BLOCK) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
+                                                         BlockScratch B, cfear_reg_summary* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LdsLayout::total_small];
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + LdsLayout::scanptr);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];
+  __syncthreads();
+  const RegScratch W = make_rscratch(B, lds);
+  register_block(sp, n, poses, cov6, P, W, reinterpret_cast<double*>(lds + LdsLayout::par), out);
+}
+
+// ---- batched odometry: one workgroup = one sequence, one launch = one radar sweep --------------
+// OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all state on device.
+template <bool LDSKEYS>
+__global__ __launch_bounds__(BLOCK) void odometry_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
+                                                              SeqState* states, ScanDev* const* scan_slots /*[B][submap+1]*/,
+                                                              const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
+                                                              double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
+                                                              double* poses_out /*[B][3]*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSKEYS ? LdsLayout::total_lds_keys : LdsLayout::total_small];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  SeqState* st = &states[q];
+  const BlockScratch B = scratch[q];
+  const int nslots = OP.submap + 1;
+  ScanDev* const* my_slots = scan_slots + (size_t)q * nslots;
+  const int cur_slot = st->free_slot;
+  ScanDev* cur = my_slots[cur_slot];
+  const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;  // :146
+  const int nkf = st->nkf;
+  // stage 1 (second half): slots -> cloud (radar_driver.cpp:59)
+  const int n = cloud_build_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance, 0,
+                                  cur->xyi, cur->cap_points, reinterpret_cast<int*>(lds + LdsLayout::red_i));
+  if (OP.compensate) {  // :147-150
+    double mot[3]; aff_to_xyt(TprevMot, mot);
+    compensate_block(cur->xyi, n, mot[0], mot[1], mot[2], OP.ccw);
+  }
+  const FeatureScratch FW = make_fscratch(B, lds, LDSKEYS);
+  features_block(cur, n, OP.fp, FW, next_pow2(n));  // :161
+  const Aff2 Tguess = aff_mul(T_prev, TprevMot);    // :166
+  cfear_reg_summary* sum = &summaries[q];
+  if (nkf == 0) {  // :171-177
+    if (tid == 0) {
+      st->ring[0] = cur_slot; st->kf_pose[0] = aff_identity(); st->nkf = 1; st->free_slot = (cur_slot + 1) % nslots;
+      st->frames++; st->last_slot = cur_slot;
+      sum->success = 0; sum->usable = 0; sum->outer_iterations = 0; sum->num_residuals = 0; sum->num_residual_blocks = 0;
+      double v[3]; aff_to_xyt(st->Tcurrent, v);
+      poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
+    }
+    return;
+  }
+  // FormatScans (:478-494)
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + LdsLayout::scanptr);
+  double* poses = poses_work + (size_t)q * MAX_SCANS * 3;
+  const int ns = nkf + 1;
+  if (tid < nkf) {
+    sp[tid] = my_slots[st->ring[tid]];
+    double v[3]; aff_to_xyt(st->kf_pose[tid], v);
+    poses[3 * tid] = v[0]; poses[3 * tid + 1] = v[1]; poses[3 * tid + 2] = v[2];
+  }
+  if (tid == 0) {
+    sp[ns - 1] = cur;
+    double v[3]; aff_to_xyt(Tguess, v);
+    poses[3 * (ns - 1)] = v[0]; poses[3 * (ns - 1) + 1] = v[1]; poses[3 * (ns - 1) + 2] = v[2];
+  }
+  __syncthreads();
+  const RegScratch RW = make_rscratch(B, lds);
+  register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + LdsLayout::par), sum);  // :186 (result ignored, :184-186)
+  __syncthreads();
+  if (tid == 0) {
+    Aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]);  // :195
+    const Aff2 Tpi = aff_inv(T_prev);
+    const Aff2 Tmot_current = aff_mul(Tpi, Tcurrent);
+    {  // AccelerationVelocitySanityCheck (:76-94)
+      const double dt = 0.25, lim = 200;
+      const double vel = sqrt(Tmot_current.t0 * Tmot_current.t0 + Tmot_current.t1 * Tmot_current.t1) / dt;
+      const double ax = (Tmot_current.t0 - TprevMot.t0) / (dt * dt), ay = (Tmot_current.t1 - TprevMot.t1) / (dt * dt);
+      const double acc = sqrt(ax * ax + ay * ay);
+      if (acc > lim || vel > lim) Tcurrent = Tguess;  // :198-199
+    }
+    st->Tmot = aff_mul(Tpi, Tcurrent);  // :200
+    st->Tcurrent = Tcurrent;
+    const Aff2 Tkeydiff = aff_mul(aff_inv(st->kf_pose[nkf - 1]), Tcurrent);  // :227
+    bool fuse = true;
+    if (OP.use_keyframe) {  // KeyFrameBasedFuse (:62-73)
+      const double tn = sqrt(Tkeydiff.t0 * Tkeydiff.t0 + Tkeydiff.t1 * Tkeydiff.t1);
+      const double rot = fabs(atan2(Tkeydiff.l2, Tkeydiff.l3));
+      fuse = (tn > OP.min_keyframe_dist) || (rot > OP.min_keyframe_rot_deg * 3.14159265358979323846 / 180.0);
+    }
+    if (fuse) {  // AddToReference (:470-476)
+      int m = nkf;
+      st->ring[m] = cur_slot; st->kf_pose[m] = Tcurrent; m++;
+      int freed;
+      if (m > OP.submap) {
+        freed = st->ring[0];
+        for (int i = 0; i + 1 < m; i++) { st->ring[i] = st->ring[i + 1]; st->kf_pose[i] = st->kf_pose[i + 1]; }
+        m--;
+      } else {
+        freed = m;  // slots are handed out in increasing order until the ring is full
+      }
+      st->nkf = m; st->free_slot = freed;
+    }
+    st->T_prev = Tcurrent;  // :257
+    st->frames++; st->last_slot = cur_slot;
+    double v[3]; aff_to_xyt(Tcurrent, v);
+    poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
+  }
+}
+
+// ---- host-side helpers ---------------------------------------------------------------------------
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+FeatureParams feature_params(const cfear_ctx* ctx) {
+  FeatureParams P;
+  P.range_res = ctx->par.range_res; P.min_distance = ctx->par.min_distance;
+  P.radius = (float)ctx->par.res;
+  P.downsample_factor = ctx->par.downsample_factor;
+  P.weight_intensity = ctx->par.weight_intensity;
+  P.assoc_radius = ctx->par.assoc_radius;
+  const char* dbg = getenv("CFEAR_DBG_STAGE");
+  P.dbg_stage = dbg ? atoi(dbg) : 0;
+  return P;
+}
+RegParams reg_params(const cfear_ctx* ctx) {
+  RegParams P;
+  P.cost = ctx->par.cost; P.loss = ctx->par.loss; P.weight_opt = ctx->par.weight_opt;
+  P.loss_limit = ctx->par.loss_limit; P.covar_scale = ctx->par.covar_scale; P.regularization = ctx->par.regularization;
+  P.assoc_radius = ctx->par.assoc_radius;
+  P.max_outer = ctx->par.max_itr_association; P.min_itr = ctx->par.min_itr; P.max_inner = ctx->par.max_solver_iterations;
+  return P;
+}
+
+constexpr int GRID_CAP = 128 * 128;
+
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, total; };
+ScanLayout scan_layout(int cap_points) {
+  ScanLayout L;
+  size_t o = align_up(sizeof(ScanDev), 256);
+  L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
+  L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
+  L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
+  L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
+  L.gorder = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
+  L.total = o;
+  return L;
+}
+// writes a ScanDev header for a flat device block at d_base
+ScanDev scan_header(unsigned char* d_base, int cap_points) {
+  const ScanLayout L = scan_layout(cap_points);
+  ScanDev h;
+  memset(&h, 0, sizeof(h));
+  h.status = CFEAR_ERR_EMPTY;
+  h.cap_points = cap_points; h.cap_cells = cap_points; h.cap_grid = GRID_CAP;
+  h.xyi = reinterpret_cast<float*>(d_base + L.xyi);
+  h.cells = reinterpret_cast<cfear_cell*>(d_base + L.cells);
+  h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
+  h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
+  h.gorder = reinterpret_cast<int*>(d_base + L.gorder);
+  h.gcell = 1.f;
+  return h;
+}
+
+struct ScratchLayout { size_t keys, vstart, samples, tmp, flags, match, assoc, total; int p2cap; };
+ScratchLayout scratch_layout(int cap_points, int pair_cap) {
+  ScratchLayout L;
+  int p2 = 1; while (p2 < cap_points) p2 <<= 1;
+  L.p2cap = p2;
+  size_t o = 0;
+  L.keys = o; o = align_up(o + sizeof(uint64_t) * (size_t)p2, 256);
+  L.vstart = o; o = align_up(o + sizeof(int) * ((size_t)cap_points + 2), 256);
+  L.samples = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
+  L.tmp = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
+  L.flags = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
+  L.match = o; o = align_up(o + sizeof(double) * 8 * (size_t)pair_cap, 256);
+  L.assoc = o; o = align_up(o + sizeof(int) * (size_t)pair_cap, 256);
+  L.total = o;
+  return L;
+}
+BlockScratch scratch_header(unsigned char* d_base, int cap_points, int pair_cap) {
+  const ScratchLayout L = scratch_layout(cap_points, pair_cap);
+  BlockScratch B;
+  B.keys = reinterpret_cast<uint64_t*>(d_base + L.keys);
+  B.vstart = reinterpret_cast<int*>(d_base + L.vstart);
+  B.samples = reinterpret_cast<float*>(d_base + L.samples);
+  B.tmp = reinterpret_cast<cfear_cell*>(d_base + L.tmp);
+  B.flags = reinterpret_cast<int*>(d_base + L.flags);
+  B.match = reinterpret_cast<double*>(d_base + L.match);
+  B.assoc = reinterpret_cast<int*>(d_base + L.assoc);
+  B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap;
+  return B;
+}
+
+int set_kernel_attributes(cfear_ctx*) { return CFEAR_OK; }  // LDS is static (up to 160 KiB per workgroup on gfx950)
+
+}  // namespace
+
+struct cfear_cloud {
+  int cap = 0;
+  float* d_xyi = nullptr;
+  int* d_n = nullptr;
+};
+struct cfear_scan {
+  unsigned char* d_block = nullptr;  // ScanDev header + arrays
+  int cap_points = 0;
+};
+struct cfear_odometry {
+  int B = 0, nslots = 0, cap_points = 0, pair_cap = 0;
+  unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
+  ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
+  unsigned char* d_scratch = nullptr;  // B scratch blocks
+  BlockScratch* d_scratch_hdr = nullptr;
+  SeqState* d_states = nullptr;
+  double* d_poses_work = nullptr;
+  double* d_cov_work = nullptr;
+  cfear_reg_summary* d_summaries = nullptr;
+  double* d_poses_out = nullptr;
+  uint32_t* d_slots = nullptr;
+  uint8_t* d_polar = nullptr;  // staging for step_host
+};
+
+// per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
+static int ensure_ctx_scratch(cfear_ctx* ctx, int cap_points, int pair_cap) {
+  const ScratchLayout L = scratch_layout(cap_points, pair_cap);
+  const size_t extra = 4096;  // summary + poses + cov + scan pointer table + closest buffers live after the layout
+  const size_t need = L.total + extra + sizeof(double) * (3 * MAX_SCANS + 36) + sizeof(void*) * MAX_SCANS + sizeof(cfear_reg_summary);
+  if (need > ctx->scratch_bytes) {
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    if (hipMalloc(&ctx->d_scratch, need) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc context scratch");
+    ctx->scratch_bytes = need;
+  }
+  return CFEAR_OK;
+}
+
+extern "C" {
+
+// ---- clouds ------------------------------------------------------------------------------------
+static int cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out) {
+  cfear_cloud* c = new (std::nothrow) cfear_cloud();
+  if (!c) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "cloud alloc");
+  c->cap = cap > 0 ? cap : 1;
+  if (hipMalloc(&c->d_xyi, sizeof(float) * 3 * (size_t)c->cap) != hipSuccess || hipMalloc(&c->d_n, sizeof(int)) != hipSuccess) {
+    if (c->d_xyi) (void)hipFree(c->d_xyi);
+    delete c;
+    return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cloud");
+  }
+  *out = c;
+  return CFEAR_OK;
+}
+
+void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* c) {
+  if (!c) return;
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (c->d_xyi) (void)hipFree(c->d_xyi);
+  if (c->d_n) (void)hipFree(c->d_n);
+  delete c;
+}
+
+int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks) {
+  if (!ctx || !d_polar || !cloud) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_polar: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *cloud = nullptr;
+  if (cloud_peaks) *cloud_peaks = nullptr;
+  int rc = cfear_ensure_staging(ctx, 1);
+  if (rc != CFEAR_OK) return rc;
+  rc = cfear_launch_kstrongest(ctx, d_polar, 1, ctx->d_slots);  // radar_driver.cpp:58
+  if (rc != CFEAR_OK) return rc;
+  const int A = ctx->A, k = ctx->par.k_strongest, cap = A * k;
+  for (int peaks = 0; peaks < (cloud_peaks ? 2 : 1); peaks++) {  // radar_driver.cpp:59-60
+    cfear_cloud* c = nullptr;
+    rc = cloud_alloc(ctx, cap, &c);
+    if (rc != CFEAR_OK) return rc;
+    hipLaunchKernelGGL(cloud_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
+                       ctx->par.range_res, ctx->par.min_distance, peaks, c->d_xyi, cap, c->d_n);
+    if (peaks == 0) *cloud = c; else *cloud_peaks = c;
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+int cfear_filter_polar(cfear_ctx* ctx, const uint8_t* h_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks) {
+  if (!ctx || !h_polar || !cloud) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_polar: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = cfear_ensure_staging(ctx, 1);
+  if (rc != CFEAR_OK) return rc;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R, hipMemcpyHostToDevice, ctx->stream));
+  return cfear_filter_polar_device(ctx, ctx->d_polar, cloud, cloud_peaks);
+}
+
+int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cloud) {
+  if (!ctx || !cloud || n < 0 || (n > 0 && !xyi)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cloud_upload: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  cfear_cloud* c = nullptr;
+  int rc = cloud_alloc(ctx, n, &c);
+  if (rc != CFEAR_OK) return rc;
+  if (n > 0) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_xyi, xyi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_n, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *cloud = c;
+  return CFEAR_OK;
+}
+
+int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* c, int* n) {
+  if (!ctx || !c || !n) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cloud_size: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(n, c->d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_cloud_download(cfear_ctx* ctx, const cfear_cloud* c, float* xyi, int capacity, int* n) {
+  int m = 0;
+  int rc = cfear_cloud_size(ctx, c, &m);
+  if (rc != CFEAR_OK) return rc;
+  if (n) *n = m;
+  const int cnt = m < capacity ? m : capacity;
+  if (cnt > 0 && xyi) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyi, c->d_xyi, sizeof(float) * 3 * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
+int cfear_compensate(cfear_ctx* ctx, cfear_cloud* c, const double motion_xyt[3], int ccw) {
+  if (!ctx || !c || !motion_xyt) return cfear_fail(ctx, CFEAR_ERR_INVALID, "compensate: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // Affine3dToVectorXYeZ of the motion (utils.cpp:109-112): theta passes through atan2(sin, cos)
+  const double th = atan2(sin(motion_xyt[2]), cos(motion_xyt[2]));
+  hipLaunchKernelGGL(compensate_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, c->d_xyi, c->d_n, motion_xyt[0], motion_xyt[1], th, ccw);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+// ---- scans -------------------------------------------------------------------------------------
+int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** scan) {
+  if (!ctx || !cloud || !scan) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_create: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *scan = nullptr;
+  int rc = set_kernel_attributes(ctx);
+  if (rc != CFEAR_OK) return rc;
+  const int cap = cloud->cap;
+  if (cap >= (1 << 24)) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "scan_create: more than 2^24 points");
+  rc = ensure_ctx_scratch(ctx, cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest,
+                          (MAX_SCANS - 1) * (cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest));
+  if (rc != CFEAR_OK) return rc;
+  cfear_scan* s = new (std::nothrow) cfear_scan();
+  if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
+  s->cap_points = cap;
+  const ScanLayout L = scan_layout(cap);
+  if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
+  const ScanDev h = scan_header(s->d_block, cap);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
+  const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
+  const FeatureParams P = feature_params(ctx);
+  if (getenv("CFEAR_DBG_PTRS")) {
+    const ScratchLayout WL = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
+    fprintf(stderr, "scan block %p +%zu | xyi %p cells %p mean_f %p gstart %p gorder %p\n", (void*)s->d_block, L.total, (void*)h.xyi, (void*)h.cells, (void*)h.mean_f, (void*)h.gstart, (void*)h.gorder);
+    fprintf(stderr, "scratch %p +%zu (alloc %zu) | keys %p vstart %p samples %p tmp %p flags %p match %p assoc %p\n", ctx->d_scratch, WL.total, ctx->scratch_bytes, (void*)B.keys, (void*)B.vstart, (void*)B.samples, (void*)B.tmp, (void*)B.flags, (void*)B.match, (void*)B.assoc);
+    fprintf(stderr, "cloud xyi %p cap %d d_n %p\n", (void*)cloud->d_xyi, cloud->cap, (void*)cloud->d_n);
+  }
+  if (cap <= LDS_KEYS)
+    hipLaunchKernelGGL(features_kernel<true>, dim3(1), dim3(BLOCK), 0, ctx->stream,
+                       reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi, cloud->d_n, P, B);
+  else
+    hipLaunchKernelGGL(features_kernel<false>, dim3(1), dim3(BLOCK), 0, ctx->stream,
+                       reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi, cloud->d_n, P, B);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
+  ScanDev back;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&back, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (back.status != 0) {
+    (void)hipFree(s->d_block);
+    delete s;
+    return cfear_fail(ctx, CFEAR_ERR_EMPTY, "scan_create: empty cloud (reference: 'error, cloud empty' + exit)");
+  }
+  *scan = s;
+  return CFEAR_OK;
+}
+
+void cfear_scan_release(cfear_ctx* ctx, cfear_scan* s) {
+  if (!s) return;
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (s->d_block) (void)hipFree(s->d_block);
+  delete s;
+}
+
+static int scan_header_download(cfear_ctx* ctx, const cfear_scan* s, ScanDev* h) {
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(h, s->d_block, sizeof(ScanDev), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_scan_size(cfear_ctx* ctx, const cfear_scan* s, int* n_cells) {
+  if (!ctx || !s || !n_cells) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_size: bad argument");
+  ScanDev h;
+  int rc = scan_header_download(ctx, s, &h);
+  if (rc != CFEAR_OK) return rc;
+  *n_cells = h.n_cells;
+  return CFEAR_OK;
+}
+
+int cfear_scan_download_cells(cfear_ctx* ctx, const cfear_scan* s, cfear_cell* cells, int capacity, int* n) {
+  if (!ctx || !s) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_download_cells: bad argument");
+  ScanDev h;
+  int rc = scan_header_download(ctx, s, &h);
+  if (rc != CFEAR_OK) return rc;
+  if (n) *n = h.n_cells;
+  const int cnt = h.n_cells < capacity ? h.n_cells : capacity;
+  if (cnt > 0 && cells) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cells, h.cells, sizeof(cfear_cell) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
+int cfear_scan_closest(cfear_ctx* ctx, const cfear_scan* s, const double* qxy, int nq, double d, int32_t* idx) {
+  if (!ctx || !s || !qxy || !idx || nq <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_closest: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double* dq = nullptr; int* di = nullptr;
+  if (hipMalloc(&dq, sizeof(double) * 2 * (size_t)nq) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc queries");
+  if (hipMalloc(&di, sizeof(int) * (size_t)nq) != hipSuccess) { (void)hipFree(dq); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc idx"); }
+  hipError_t e = hipMemcpyAsync(dq, qxy, sizeof(double) * 2 * (size_t)nq, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(closest_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const ScanDev*>(s->d_block), dq, nq, d, di);
+    e = hipMemcpyAsync(idx, di, sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dq); (void)hipFree(di);
+  if (e != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_closest", e);
+  return CFEAR_OK;
+}
+
+// ---- registration ------------------------------------------------------------------------------
+int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
+                   cfear_reg_summary* summary) {
+  if (!ctx || !scans || !poses_xyt || n < 2) return cfear_fail(ctx, CFEAR_ERR_INVALID, "register: need >= 2 scans and poses");
+  if (n > MAX_SCANS) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "register: more than 64 scans");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = set_kernel_attributes(ctx);
+  if (rc != CFEAR_OK) return rc;
+  int capmax = ctx->A * ctx->par.k_strongest;
+  for (int i = 0; i < n; i++) {
+    if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "register: null scan");
+    if (scans[i]->cap_points > capmax) capmax = scans[i]->cap_points;
+  }
+  rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
+  if (rc != CFEAR_OK) return rc;
+  const ScratchLayout L = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
+  unsigned char* base = static_cast<unsigned char*>(ctx->d_scratch);
+  const BlockScratch B = scratch_header(base, capmax, (MAX_SCANS - 1) * capmax);
+  unsigned char* tail = base + L.total;
+  double* d_poses = reinterpret_cast<double*>(tail);
+  double* d_cov = d_poses + 3 * MAX_SCANS;
+  ScanDev** d_ptrs = reinterpret_cast<ScanDev**>(d_cov + 36);
+  cfear_reg_summary* d_sum = reinterpret_cast<cfear_reg_summary*>(reinterpret_cast<unsigned char*>(d_ptrs) + sizeof(void*) * MAX_SCANS);
+  ScanDev* h_ptrs[MAX_SCANS];
+  for (int i = 0; i < n; i++) h_ptrs[i] = reinterpret_cast<ScanDev*>(scans[i]->d_block);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+  const RegParams P = reg_params(ctx);
+  hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, d_poses, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6_last, d_cov, sizeof(double) * 36, hipMemcpyDeviceToHost, ctx->stream));
+  if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(summary, d_sum, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+// ---- batched odometry --------------------------------------------------------------------------
+void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
+  if (!o) return;
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
+                  o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete o;
+}
+
+int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_reset: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<SeqState> st((size_t)o->B);
+  for (auto& s : st) {
+    memset(&s, 0, sizeof(s));
+    s.T_prev.l0 = s.T_prev.l3 = 1; s.Tmot.l0 = s.Tmot.l3 = 1; s.Tcurrent.l0 = s.Tcurrent.l3 = 1;  // odometrykeyframefuser.cpp:34-38
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->d_states, st.data(), sizeof(SeqState) * st.size(), hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_summaries, 0, sizeof(cfear_reg_summary) * (size_t)o->B, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_poses_out, 0, sizeof(double) * 3 * (size_t)o->B, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out) {
+  if (!ctx || !out || n_sequences <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_create: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *out = nullptr;
+  int rc = set_kernel_attributes(ctx);
+  if (rc != CFEAR_OK) return rc;
+  cfear_odometry* o = new (std::nothrow) cfear_odometry();
+  if (!o) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "odometry alloc");
+  const int B = n_sequences, s = ctx->par.submap_scan_size;
+  o->B = B; o->nslots = s + 1; o->cap_points = ctx->A * ctx->par.k_strongest; o->pair_cap = s * o->cap_points;
+  const ScanLayout SL = scan_layout(o->cap_points);
+  const ScratchLayout WL = scratch_layout(o->cap_points, o->pair_cap);
+  bool ok = true;
+  ok = ok && hipMalloc(&o->d_scans, SL.total * (size_t)B * o->nslots) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_scan_ptrs, sizeof(ScanDev*) * (size_t)B * o->nslots) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_scratch, WL.total * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_scratch_hdr, sizeof(BlockScratch) * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_states, sizeof(SeqState) * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_poses_work, sizeof(double) * 3 * MAX_SCANS * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_cov_work, sizeof(double) * 36 * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_summaries, sizeof(cfear_reg_summary) * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_poses_out, sizeof(double) * 3 * (size_t)B) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_slots, sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+  if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc odometry state"); }
+  std::vector<ScanDev*> ptrs((size_t)B * o->nslots);
+  std::vector<BlockScratch> hdrs((size_t)B);
+  for (int q = 0; q < B; q++) {
+    for (int j = 0; j < o->nslots; j++) {
+      unsigned char* blk = o->d_scans + SL.total * ((size_t)q * o->nslots + j);
+      const ScanDev h = scan_header(blk, o->cap_points);
+      if (hipMemcpyAsync(blk, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ok = false;
+      ptrs[(size_t)q * o->nslots + j] = reinterpret_cast<ScanDev*>(blk);
+    }
+    hdrs[q] = scratch_header(o->d_scratch + WL.total * (size_t)q, o->cap_points, o->pair_cap);
+  }
+  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;  // the header temporaries above are stack objects
+  ok = ok && hipMemcpy(o->d_scan_ptrs, ptrs.data(), sizeof(ScanDev*) * ptrs.size(), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && hipMemcpy(o->d_scratch_hdr, hdrs.data(), sizeof(BlockScratch) * hdrs.size(), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry state upload"); }
+  rc = cfear_odometry_reset(ctx, o);
+  if (rc != CFEAR_OK) { cfear_odometry_destroy(ctx, o); return rc; }
+  *out = o;
+  return CFEAR_OK;
+}
+
+int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_polar) {
+  if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
+  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
+  int rc = cfear_launch_kstrongest(ctx, d_polar, o->B, o->d_slots);  // radar_driver.cpp:58
+  if (rc != CFEAR_OK) return rc;
+  OdoParams OP;
+  OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
+  OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
+  OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
+  OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
+  if (o->cap_points <= LDS_KEYS)
+    hipLaunchKernelGGL(odometry_step_kernel<true>, dim3(o->B), dim3(BLOCK), 0, ctx->stream, o->d_slots,
+                       ctx->d_trig, OP, o->d_states, o->d_scan_ptrs, o->d_scratch_hdr, o->d_poses_work, o->d_cov_work,
+                       o->d_summaries, o->d_poses_out);
+  else
+    hipLaunchKernelGGL(odometry_step_kernel<false>, dim3(o->B), dim3(BLOCK), 0, ctx->stream, o->d_slots,
+                       ctx->d_trig, OP, o->d_states, o->d_scan_ptrs, o->d_scratch_hdr, o->d_poses_work, o->d_cov_work,
+                       o->d_summaries, o->d_poses_out);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h_polar) {
+  if (!ctx || !o || !h_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_host: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)o->B * ctx->A * ctx->R;
+  if (!o->d_polar && hipMalloc(&o->d_polar, bytes + 64) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc polar batch");
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->d_polar, h_polar, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return cfear_odometry_step_device(ctx, o, o->d_polar);
+}
+
+int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {
+  if (!ctx || !o || !poses_xyt) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_poses: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, o->d_poses_out, sizeof(double) * 3 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfear_reg_summary* summary, int* n_cells,
+                           int* n_keyframes) {
+  if (!ctx || !o || sequence < 0 || sequence >= o->B) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_summary: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpy(summary, o->d_summaries + sequence, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost));
+  if (n_cells || n_keyframes) {
+    SeqState st;
+    CFEAR_HIP_CHECK(ctx, hipMemcpy(&st, o->d_states + sequence, sizeof(st), hipMemcpyDeviceToHost));
+    if (n_keyframes) *n_keyframes = st.nkf;
+    if (n_cells) {  // cells of the scan built by the last step
+      const ScanLayout SL = scan_layout(o->cap_points);
+      ScanDev h;
+      CFEAR_HIP_CHECK(ctx, hipMemcpy(&h, o->d_scans + SL.total * ((size_t)sequence * o->nslots + st.last_slot), sizeof(h), hipMemcpyDeviceToHost));
+      *n_cells = h.n_cells;
+    }
+  }
+  return CFEAR_OK;
+}
+
+}  // extern "C"

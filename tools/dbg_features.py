@@ -1,0 +1,18 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+from cfear_radarodometry_code_public_amd import capi, synth
+from oracle import binding as ob
+RR = np.float32(0.0595238)
+imgs, gt = synth.world_sequence(3, seed=3)
+po = ob.default_params(range_res=RR)
+pg = capi.default_params(range_res=RR)
+ctx = capi.Context(pg, 400, 3360)
+slots = ob.filter_polar(imgs[1], 60, 12)
+xyi = ob.compensate(ob.cloud(slots, RR, 2.5), [1.0, 0.01, 0.02], 0)
+print("points", xyi.shape, flush=True)
+c = ctx.cloud_upload(xyi)
+print("uploaded", c.size, flush=True)
+s = ctx.scan_create(c)
+print("scan", s.size, flush=True)
+so = ob.Scan(xyi, po)
+print("oracle", so.size)
