@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- CFEAR hot path throughput on MI355X (BASELINE.json metric).
+
+One "step" = one radar sweep of every resident sequence: batched k-strongest filter kernel over
+B polar images (400 x 3360 uint8) followed by the odometry kernel (cloud, motion compensation,
+oriented surface points, 4-keyframe P2L registration, keyframe logic) -- one workgroup per sequence.
+All sweeps are resident in HBM before the timed region starts.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Rank 0 prints ONE JSON line: scans/s over all ranks (max-over-ranks time), the HBM roofline of the
+filter kernel measured with HIP events on the launch stream, and the CPU oracle baseline (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+A, R, K_STRONGEST = 400, 3360, 12
+RANGE_RES = np.float32(0.0595238)
+ALGO_BYTES_PER_SCAN = A * R + A * K_STRONGEST * 4  # 1,363,200 B
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def params(mod):
+    # BASELINE.json configs[1]: k=12, CFEAR-3 features (r=3.0, weight_intensity, weight_option 4),
+    # P2L + Huber(0.1), 4 keyframes, compensation on (SURVEY.md 8d "Config 2")
+    return mod.default_params(range_res=RANGE_RES, z_min=60.0, min_distance=2.5, k_strongest=K_STRONGEST, res=3.0,
+                              weight_intensity=1, weight_opt=4, cost=1, loss=1, loss_limit=0.1, submap_scan_size=4,
+                              min_keyframe_dist=1.5, compensate=1, radar_ccw=1)
+
+
+def make_streams(n_unique, frames, seed0):
+    from cfear_radarodometry_code_public_amd import synth
+    out = []
+    for u in range(n_unique):
+        imgs, _ = synth.world_sequence(frames, A, R, RANGE_RES, seed=seed0 + u, world_seed=1234 + seed0 + u, ccw=True,
+                                       t0=17 * u)
+        out.append(imgs)
+    return np.stack(out)  # [U, T, A, R]
+
+
+def cpu_baseline(streams, budget_s=12.0):
+    """Oracle (single thread, kind=port) on the same sweeps; bounded to ~budget_s of CPU work."""
+    from oracle import binding as ob
+    p = params(ob)
+    U, T = streams.shape[:2]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for u in range(U):
+            f = ob.Fuser(p)
+            for t in range(T):
+                f.process_polar(streams[u, t])
+            done += T
+            if time.perf_counter() - t0 > budget_s:
+                dt = time.perf_counter() - t0
+                return {"value": done / dt, "unit": "scans/s", "cores": 1, "kind": "port",
+                        "sample": "%d synthetic 400x3360 sweeps (%d sequences x %d frames, repeated) in %.1f s, oracle/cfear_oracle.c single thread"
+                                  % (done, U, T, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sequences", type=int, default=256, help="independent sequences resident per GPU")
+    ap.add_argument("--unique", type=int, default=4, help="distinct synthetic sequences generated per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from cfear_radarodometry_code_public_amd import build, capi
+    build.build()
+    B, K, W = args.sequences, args.steps, args.warmup
+    frames = K + W
+    t_gen = time.perf_counter()
+    streams = make_streams(args.unique, frames, seed0=100 * rank)
+    t_gen = time.perf_counter() - t_gen
+
+    # resident input: frame-major [T][B][A][R] so that one step reads B contiguous sweeps
+    d_unique = torch.from_numpy(streams).to(dev)  # [U, T, A, R]
+    idx = torch.arange(B, device=dev) % args.unique
+    d_polar = torch.empty((frames, B, A, R), dtype=torch.uint8, device=dev)
+    for t in range(frames):
+        d_polar[t] = d_unique[idx, t]
+    del d_unique
+    torch.cuda.synchronize()
+
+    p = params(capi)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = capi.Context(p, A, R, device=local_rank, stream=stream)
+    odo = ctx.odometry(B)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for t in range(W):
+        odo.step_device(d_polar[t].data_ptr())
+    odo.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        odo.step_device(d_polar[t].data_ptr())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    t_filter, t_odo, nprof = odo.profile_read()
+    poses = odo.poses()
+    S, n_cells, n_kf = odo.summary(0)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    scans = torch.tensor([float(B * K)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # RCCL over xGMI: 8-byte messages, the only collective
+        dist.all_reduce(scans, op=dist.ReduceOp.SUM)
+    total_time, total_scans = float(tmax.item()), float(scans.item())
+
+    if rank == 0:
+        filt = t_filter / max(nprof, 1)
+        achieved = ALGO_BYTES_PER_SCAN * B / filt / 1e9
+        out = {
+            "metric": "radar scans/s (filter+feat+4-keyframe reg), 400x3360 polar",
+            "value": total_scans / total_time,
+            "unit": "scans/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * total_time / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (filter) / f32+f64 (features, registration)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 400-bin x 3360-azimuth-sample polar stream (400 azimuth rows x 3360 range bins), "
+                                   "k=12, CFEAR-3 features (r=3.0), P2L + Huber 0.1, 4 keyframes, motion compensation on",
+                       "sequences_per_gpu": B, "sweeps_per_step": B * world, "unique_sequences_per_gpu": args.unique,
+                       "parallelism": "independent sequences per GPU, 1 workgroup per sequence"},
+            "roofline": {"bound": "hbm", "kernel": "kstrongest_kernel<4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": ALGO_BYTES_PER_SCAN * B, "avg_launch_us": filt * 1e6},
+            "kernels": {"kstrongest_us": filt * 1e6, "odometry_step_us": 1e6 * t_odo / max(nprof, 1)},
+            "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,
+                      "pose_seq0": [float(x) for x in poses[0]], "datagen_s": t_gen},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(streams)
+        print(json.dumps(out), flush=True)
+    odo.release()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

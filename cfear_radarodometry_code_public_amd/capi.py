@@ -65,7 +65,7 @@ EXPORTS = [
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
-    "cfear_odometry_summary", "cfear_time_kstrongest",
+    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_time_kstrongest",
 ]
 
 
@@ -115,6 +115,8 @@ def lib():
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_summary": (C.c_int, [vp, vp, C.c_int, C.POINTER(RegSummary), C.POINTER(C.c_int),
                                              C.POINTER(C.c_int)]),
+        "cfear_odometry_profile": (C.c_int, [vp, vp, C.c_int]),
+        "cfear_odometry_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "cfear_time_kstrongest": (C.c_int, [vp, u8p, C.c_int, u32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -346,6 +348,15 @@ class Odometry:
         assert polar.shape == (self.B, self._ctx.A, self._ctx.R)
         self._ctx._check(self._ctx._L.cfear_odometry_step_host(self._ctx._h, self._h, polar.ctypes.data),
                          "cfear_odometry_step_host")
+
+    def profile(self, enable):
+        self._ctx._check(self._ctx._L.cfear_odometry_profile(self._ctx._h, self._h, int(enable)), "cfear_odometry_profile")
+
+    def profile_read(self):
+        tf, to, n = C.c_double(), C.c_double(), C.c_int()
+        self._ctx._check(self._ctx._L.cfear_odometry_profile_read(self._ctx._h, self._h, C.byref(tf), C.byref(to), C.byref(n)),
+                         "cfear_odometry_profile_read")
+        return tf.value, to.value, n.value
 
     def poses(self):
         out = np.zeros((self.B, 3))

@@ -328,6 +328,8 @@ struct cfear_odometry {
   double* d_poses_out = nullptr;
   uint32_t* d_slots = nullptr;
   uint8_t* d_polar = nullptr;  // staging for step_host
+  bool profile = false;        // record HIP events around both kernels of every step
+  std::vector<hipEvent_t> events;  // 3 per profiled step
 };
 
 // per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
@@ -589,6 +591,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : o->events) (void)hipEventDestroy(e);
   delete o;
 }
 
@@ -656,8 +659,14 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (o->profile) {
+    for (int i = 0; i < 3; i++) { CFEAR_HIP_CHECK(ctx, hipEventCreate(&ev[i])); o->events.push_back(ev[i]); }
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
+  }
   int rc = cfear_launch_kstrongest(ctx, d_polar, o->B, o->d_slots);  // radar_driver.cpp:58
   if (rc != CFEAR_OK) return rc;
+  if (o->profile) CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
   OdoParams OP;
   OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
   OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
@@ -672,6 +681,33 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
                        ctx->d_trig, OP, o->d_states, o->d_scan_ptrs, o->d_scratch_hdr, o->d_poses_work, o->d_cov_work,
                        o->d_summaries, o->d_poses_out);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (o->profile) CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* o, int enable) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (hipEvent_t e : o->events) (void)hipEventDestroy(e);
+  o->events.clear();
+  o->profile = enable != 0;
+  return CFEAR_OK;
+}
+
+int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filter_seconds, double* odometry_seconds, int* steps) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile_read: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tf = 0, to = 0;
+  const int n = (int)(o->events.size() / 3);
+  for (int i = 0; i < n; i++) {
+    float a = 0.f, b = 0.f;
+    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&a, o->events[3 * i], o->events[3 * i + 1]));
+    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&b, o->events[3 * i + 1], o->events[3 * i + 2]));
+    tf += a * 1e-3; to += b * 1e-3;
+  }
+  if (filter_seconds) *filter_seconds = tf;
+  if (odometry_seconds) *odometry_seconds = to;
+  if (steps) *steps = n;
   return CFEAR_OK;
 }
 

@@ -171,6 +171,12 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt)
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);
 
+/* Per-step kernel timing with HIP events recorded on the context stream: enable, run steps, read the
+ * accumulated seconds of the filter kernel and of the odometry kernel (bench.py roofline leg). */
+int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* odo, int enable);
+int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* odo, double* filter_seconds, double* odometry_seconds,
+                                int* steps);
+
 /* Timing hook used by bench.py: seconds of the filter kernel measured with HIP events on the
  * context stream over `iters` launches (after `warmup`). */
 int cfear_time_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots,
