@@ -131,12 +131,9 @@ def main():
     poses = odo.poses()
     S, n_cells, n_kf = odo.summary(0)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    scans = torch.tensor([float(B * K)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # RCCL over xGMI: 8-byte messages, the only collective
-        dist.all_reduce(scans, op=dist.ReduceOp.SUM)
-    total_time, total_scans = float(tmax.item()), float(scans.item())
+    from cfear_radarodometry_code_public_amd.dist import reduce_throughput
+    # RCCL over xGMI: two 8-byte all-reduces, the only collective on the path
+    total_scans, total_time = reduce_throughput(B * K, elapsed, device=dev)
 
     if rank == 0:
         filt = t_filter / max(nprof, 1)
