@@ -18,6 +18,8 @@
 //      to the larger range bin exactly like std::pair<uchar,int> ordering) and
 //   4. handles rows with > 64 ties at the threshold intensity by a backwards positional scan.
 // No block-level barrier is used: the four waves of a block are independent.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -67,43 +69,57 @@ __device__ __forceinline__ uint32_t ge_flags(uint32_t x, uint32_t brep) {
 
 // Chunk candidate mask layout: bit (8*b + d) <-> byte b of dword d (byte index 4*d + b in the chunk).
 template <int NCH, bool THIGH>
-__device__ __forceinline__ int count_mask_t(const uint4 (&v)[NCH], uint32_t brep, uint32_t (&m)[NCH]) {
-  int cnt = 0;
+__device__ __forceinline__ void ge_masks_t(const uint4 (&v)[NCH], uint32_t brep, uint32_t (&m)[NCH]) {
 #pragma unroll
   for (int j = 0; j < NCH; j++) {
     const uint32_t g0 = ge_flags<THIGH>(v[j].x, brep), g1 = ge_flags<THIGH>(v[j].y, brep);
     const uint32_t g2 = ge_flags<THIGH>(v[j].z, brep), g3 = ge_flags<THIGH>(v[j].w, brep);
-    cnt += __popc(g0) + __popc(g1) + __popc(g2) + __popc(g3);
     m[j] = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
   }
-  return cnt;
 }
-// per-lane count of bytes >= T (1 <= T <= 255) and their masks; T == 256 -> none
+// masks of the bytes >= T (1 <= T <= 255; T == 256 -> none), restricted to the row by the validity
+// masks of the first chunk group (vhead, j == 0) and of the chunk groups >= jt (vtail); returns the
+// per-lane candidate count
 template <int NCH>
-__device__ __forceinline__ int count_mask(const uint4 (&v)[NCH], int T, uint32_t (&m)[NCH]) {
+__device__ __forceinline__ int count_mask(const uint4 (&v)[NCH], int T, uint32_t (&m)[NCH], uint32_t vhead, int jt,
+                                          uint32_t vtail, uint32_t vtail2) {
   if (T >= 256) {
 #pragma unroll
     for (int j = 0; j < NCH; j++) m[j] = 0;
     return 0;
   }
   const uint32_t brep = (uint32_t)(T & 0x7f) * 0x01010101u;
-  return (T >= 128) ? count_mask_t<NCH, true>(v, brep, m) : count_mask_t<NCH, false>(v, brep, m);
-}
-
-// per-lane maximum byte of the chunks (v_pk_max_u16 on the odd bytes and on the even bytes << 8)
-template <int NCH>
-__device__ __forceinline__ int lane_max_byte(const uint4 (&v)[NCH]) {
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  us2 ao = {0, 0}, ae = {0, 0};
+  if (T >= 128) ge_masks_t<NCH, true>(v, brep, m); else ge_masks_t<NCH, false>(v, brep, m);
+  m[0] &= vhead;
+  int cnt = 0;
 #pragma unroll
   for (int j = 0; j < NCH; j++) {
-    const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    if (j == jt) m[j] &= vtail;
+    if (j == jt + 1) m[j] &= vtail2;
+    if (j > jt + 1) m[j] = 0;
+    cnt += __popc(m[j]);
+  }
+  return cnt;
+}
+
+// per-lane maximum row byte, re-read from the LDS window (rare fallback: keeps the hot path's
+// register footprint small). v_pk_max_u16 on the odd bytes and on the even bytes << 8.
+template <int NCH>
+__device__ __forceinline__ int lane_max_byte_lds(const uint8_t* win, int lane, int head, int R) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  us2 ao = {0, 0}, ae = {0, 0};
+#pragma unroll 1
+  for (int j = 0; j < NCH; j++) {
+    const int c = j * 64 + lane;
+    uint4 t = reinterpret_cast<const uint4*>(win)[c];
+    const int rlo = head - 16 * c, rhi = head + R - 16 * c;
+    t = chunk_keep(t, rlo > 16 ? 16 : rlo, rhi < 0 ? 0 : rhi);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       const uint32_t o = w[d], e = w[d] << 8;
-      us2 vo = __builtin_bit_cast(us2, o), ve = __builtin_bit_cast(us2, e);
-      ao = __builtin_elementwise_max(ao, vo);
-      ae = __builtin_elementwise_max(ae, ve);
+      ao = __builtin_elementwise_max(ao, __builtin_bit_cast(us2, o));
+      ae = __builtin_elementwise_max(ae, __builtin_bit_cast(us2, e));
     }
   }
   const int m0 = ao.x >> 8, m1 = ao.y >> 8, m2 = ae.x >> 8, m3 = ae.y >> 8;
@@ -111,14 +127,63 @@ __device__ __forceinline__ int lane_max_byte(const uint4 (&v)[NCH]) {
   return a > b ? a : b;
 }
 
+// per-lane candidate mask of all chunks: chunk j occupies the bit set {8b + d + 4*(j&1)} of word j>>1
+// (b = byte in dword, d = dword in chunk), i.e. two chunks interleave into one 32-bit word.
 template <int NCH>
-__global__ __launch_bounds__(256) void kstrongest_kernel(const uint8_t* __restrict__ polar,
-                                                         uint32_t* __restrict__ slots, int A, int R,
-                                                         long long n_rows, int u_zmin, int k,
-                                                         long long alloc_bytes) {
+__device__ __forceinline__ void pack_masks(const uint32_t (&m)[NCH], uint32_t (&w)[NCH / 2]) {
+#pragma unroll
+  for (int i = 0; i < NCH / 2; i++) w[i] = m[2 * i] | (m[2 * i + 1] << 4);
+}
+
+// candidate-mask bits (layout 8*b + d) of the chunk bytes with index in [lo_b, hi_b)
+__device__ __forceinline__ uint32_t chunk_range_mask(int lo_b, int hi_b) {
+  uint32_t keep = 0;
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    int l = lo_b - 4 * d, h = hi_b - 4 * d;
+    l = l < 0 ? 0 : (l > 4 ? 4 : l);
+    h = h < 0 ? 0 : (h > 4 ? 4 : h);
+    const uint32_t nib = h > l ? (((1u << h) - 1u) & ~((1u << l) - 1u)) : 0u;  // bits b in [l, h)
+    const uint32_t spread = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+    keep |= spread << d;
+  }
+  return keep;
+}
+
+// backwards positional scan over the LDS row: position of the need-th largest range bin whose byte == val
+__device__ __forceinline__ int tie_position(const uint8_t* win, int head, int R, int val, int need, int lane) {
+  int acc = 0;
+  for (int tb = R - 64; tb > -64; tb -= 64) {
+    const int pos = tb + lane;
+    const bool hit = pos >= 0 && win[head + pos] == (uint8_t)val;
+    unsigned long long bb = __ballot(hit);
+    const int c = __popcll(bb);
+    if (acc + c >= need) {
+      int want = need - acc, bit = 63;
+      while (true) {
+        bit = 63 - __clzll(bb);
+        if (--want == 0) break;
+        bb &= ~(1ull << bit);
+      }
+      return tb + bit;
+    }
+    acc += c;
+  }
+  return 0;
+}
+
+template <int NCH, int OCC>
+__global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __restrict__ polar,
+                                                            uint32_t* __restrict__ slots, int A, int R,
+                                                            long long n_rows, int u_zmin, int k,
+                                                            long long alloc_bytes, int rows_per_wave, int dbg) {
   constexpr int WIN = NCH * 1024;  // LDS window bytes per wave
+  constexpr int SUMBITS = NCH == 4 ? 7 : (NCH == 8 ? 8 : 9);
   __shared__ uint4 lds_win[4][NCH * 64];
   __shared__ uint32_t lds_keys[4][64];
+  __shared__ uint32_t lds_ge[20];  // lds_ge[n] = candidate-mask bits of the chunk bytes with index >= n (n = 0..16)
+  if (threadIdx.x <= 16) lds_ge[threadIdx.x] = chunk_range_mask((int)threadIdx.x, 16);
+  __syncthreads();  // the only block-level barrier: before the waves go their own way
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   uint8_t* const win = reinterpret_cast<uint8_t*>(&lds_win[wave][0]);
@@ -128,58 +193,96 @@ __global__ __launch_bounds__(256) void kstrongest_kernel(const uint8_t* __restri
   const long long scan_bytes = (long long)A * (long long)R;
   const int Tfloor = u_zmin > 1 ? u_zmin : 1;
 
-  for (long long g = (long long)blockIdx.x * 4 + wave; g < n_rows; g += (long long)gridDim.x * 4) {
-    const long long scan = g / A;
-    const int bearing = (int)(g - scan * A);
+  // each wave owns rows_per_wave consecutive rows: the selection threshold of one azimuth is the
+  // first guess for the next one
+  const long long g0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
+  long long g1 = g0 + rows_per_wave;
+  if (g1 > n_rows) g1 = n_rows;
+  int Tprev = Tfloor;
+
+  long long scan = g0 / A;
+  int bearing = (int)(g0 - scan * A);
+  for (long long g = g0; g < g1; g++, bearing++) {
+    if (bearing == A) { bearing = 0; scan++; }
     const uintptr_t row_addr = base + (uintptr_t)(g * (long long)R);
-    const uintptr_t scan_lo = base + (uintptr_t)(scan * scan_bytes), scan_hi = scan_lo + (uintptr_t)scan_bytes;
     const uintptr_t wstart = (row_addr - 6) & ~(uintptr_t)15;
     const int head = (int)(row_addr - wstart);  // 6..21: window offset of range bin 0
-    const int need_bytes = head + R + 6;
+    // chunks [c_lo, c_hi) are inside the allocation and needed (row + 6-byte halo either side)
+    const int c_lo = wstart >= base ? 0 : (int)((base - wstart + 15) >> 4);
+    int c_hi = (head + R + 6 + 15) >> 4;
+    {
+      const long long lim = ((long long)alloc_end - (long long)wstart + 15) >> 4;
+      if (lim < c_hi) c_hi = (int)lim;
+    }
+    const bool edge_row = bearing == 0 || bearing == A - 1;
+    const uint8_t* const wp = reinterpret_cast<const uint8_t*>(wstart);  // wave-uniform base, 32-bit lane offsets
 
     // ---- load: HBM -> VGPR (row-masked) and LDS (scan-masked, keeps the cross-row halo) ----
     uint4 v[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       const int c = j * 64 + lane;
-      const uintptr_t ca = wstart + (uintptr_t)(16 * c);
-      uint4 raw = make_uint4(0, 0, 0, 0);
-      if (16 * c < need_bytes && ca >= base && ca < alloc_end) raw = *reinterpret_cast<const uint4*>(ca);
-      // bytes outside this scan's image read as 0 (the reference's unchecked cv::Mat::at would run
-      // off the buffer there, radar_filters.cpp:260)
-      const long long slo = (long long)scan_lo - (long long)ca, shi = (long long)scan_hi - (long long)ca;
+      const uint32_t boff = (uint32_t)(16 * c);
+      uint4 raw;
+      if (j * 64 >= c_lo && j * 64 + 64 <= c_hi) {  // whole 1 KiB inside: unpredicated load
+        raw = *reinterpret_cast<const uint4*>(wp + boff);
+      } else {
+        raw = make_uint4(0, 0, 0, 0);
+        if (c >= c_lo && c < c_hi) raw = *reinterpret_cast<const uint4*>(wp + boff);
+      }
       uint4 staged = raw;
-      if (slo > 0 || shi < 16) staged = chunk_keep(raw, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
+      if (edge_row) {
+        // bytes outside this scan's image read as 0 (the reference's unchecked cv::Mat::at would run
+        // off the buffer there, radar_filters.cpp:260)
+        const uintptr_t scan_lo = base + (uintptr_t)(scan * scan_bytes);
+        const long long ca = (long long)(wstart + (uintptr_t)boff);
+        const long long slo = (long long)scan_lo - ca, shi = (long long)scan_lo + scan_bytes - ca;
+        if (slo > 0 || shi < 16) staged = chunk_keep(raw, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
+      }
       reinterpret_cast<uint4*>(win)[c] = staged;
-      const int rlo = head - 16 * c, rhi = head + R - 16 * c;
-      v[j] = (rlo > 0 || rhi < 16) ? chunk_keep(raw, rlo > 16 ? 16 : rlo, rhi < 0 ? 0 : rhi) : raw;
+      v[j] = raw;  // bytes outside the row are excluded through the candidate masks (vhead / vtail)
+    }
+    // validity of the chunk bytes w.r.t. the row [0, R): only the first chunk group and the group(s)
+    // holding the row end can be partial
+    const int jt = (head + R - 1) >> 10;  // chunk group of the last range bin
+    int hb = head - 16 * lane, tb = head + R - 16 * (jt * 64 + lane);
+    hb = hb < 0 ? 0 : (hb > 16 ? 16 : hb);
+    tb = tb < 0 ? 0 : (tb > 16 ? 16 : tb);
+    const uint32_t vhead = lds_ge[hb];
+    const uint32_t vtail = (~lds_ge[tb] & 0x0F0F0F0Fu) & (jt == 0 ? vhead : 0x0F0F0F0Fu);
+    const uint32_t vtail2 = 0u;  // groups after jt hold no row bytes
+    wave_lds_fence();
+    if (dbg == 1) {  // bring-up: streaming ceiling of the load phase
+      uint32_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+      if (acc == 0x12345678u) slots[g * (long long)k] = acc;
+      continue;
     }
 
-    wave_lds_fence();
-
-    // ---- threshold search ----
-    int lo = Tfloor;
-    if (k <= 64) {
-      int lm = lane_max_byte<NCH>(v);
+    // ---- threshold search: first probe = previous row's threshold ----
+    int lo = Tprev;
+    uint32_t m[NCH];
+    int cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+    if (cnt < k && lo > Tfloor) {
+      // too few: restart from the floor, bounded below by the k-th largest per-lane maximum
+      lo = Tfloor;
+      int lm = lane_max_byte_lds<NCH>(win, lane, head, R);
       if (lm < Tfloor) lm = 0;
-      // k-th largest lane maximum: largest t with #{lanes: lm >= t} >= k (t = 0 always qualifies)
       int tl = 0, th = 256;
       while (th - tl > 1) {
         const int mid = (tl + th) >> 1;
         if (__popcll(__ballot(lm >= mid)) >= k) tl = mid; else th = mid;
       }
       if (tl > lo) lo = tl;  // count(bytes >= tl) >= k is guaranteed
+      cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
     }
-    uint32_t m[NCH];
-    int ln = count_mask<NCH>(v, lo, m);
-    int cnt = wave_sum_small<(NCH == 4 ? 7 : (NCH == 8 ? 8 : 9))>(ln);
     if (cnt > 64) {
       int hi = 256;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         uint32_t mm[NCH];
-        const int l2 = count_mask<NCH>(v, mid, mm);
-        const int c2 = wave_sum_small<(NCH == 4 ? 7 : (NCH == 8 ? 8 : 9))>(l2);
+        const int c2 = wave_sum_small<SUMBITS>(count_mask<NCH>(v, mid, mm, vhead, jt, vtail, vtail2));
         if (c2 >= k) {
           lo = mid; cnt = c2;
 #pragma unroll
@@ -190,115 +293,86 @@ __global__ __launch_bounds__(256) void kstrongest_kernel(const uint8_t* __restri
         }
       }
     }
+    if (dbg == 2) {
+      if (cnt == 0x1234567) slots[g * (long long)k] = (uint32_t)cnt;
+      continue;
+    }
+    // next row starts from this threshold (one higher when the candidate set is getting large)
+    Tprev = (cnt > 40 && lo < 255) ? lo + 1 : lo;
+
     // ---- ties: > 64 bytes equal to the threshold intensity, or z_min == 0 and zeros are needed ----
-    int tie_val = -1, c_gt = 0;
     if (cnt > 64) {
-      tie_val = lo;
       uint32_t mg[NCH];
-      const int l2 = count_mask<NCH>(v, lo + 1, mg);
-      c_gt = wave_sum_small<(NCH == 4 ? 7 : (NCH == 8 ? 8 : 9))>(l2);
-      // m (>= lo) becomes the "== lo" mask, mg the "> lo" mask
-#pragma unroll
-      for (int j = 0; j < NCH; j++) { m[j] &= ~mg[j]; uint32_t t = m[j]; m[j] = mg[j]; mg[j] = t; }
-      // now m = gt mask, mg = eq mask
-      int need = k - c_gt;
-      // backwards positional scan over the LDS row for the need-th largest position with byte == lo
-      int pstar = 0, acc = 0;
-      for (int tb = R - 64; tb > -64; tb -= 64) {
-        const int pos = tb + lane;
-        const bool hit = pos >= 0 && win[head + pos] == (uint8_t)tie_val;
-        const unsigned long long b = __ballot(hit);
-        const int c = __popcll(b);
-        if (acc + c >= need) {
-          unsigned long long bb = b;
-          int want = need - acc;  // want-th highest set bit
-          int bit = 63;
-          while (true) {
-            bit = 63 - __clzll(bb);
-            if (--want == 0) break;
-            bb &= ~(1ull << bit);
-          }
-          pstar = tb + bit;
-          break;
-        }
-        acc += c;
-      }
+      const int c_gt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo + 1, mg, vhead, jt, vtail, vtail2));
+      const int pstar = tie_position(win, head, R, lo, k - c_gt, lane);
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int bp = 16 * (j * 64 + lane) - head;  // range bin of byte 0 of this chunk
-        uint32_t keep = 0;
-        for (int bi = 0; bi < 16; bi++) {
-          const int pos = bp + bi;
-          if (pos >= pstar && pos < R) keep |= 1u << (8 * (bi & 3) + (bi >> 2));
-        }
-        m[j] |= mg[j] & keep;
+        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);
+        m[j] = mg[j] | (m[j] & ~mg[j] & keep);  // (> lo) | (== lo & range >= pstar)
       }
       cnt = k;
     } else if (u_zmin == 0 && cnt < k && R > cnt && lo == 1) {
       // z_min == 0: zero-valued bins are candidates too; take the largest ranges among them
       int need = k - cnt;
       if (need > R - cnt) need = R - cnt;
-      int pstar = 0, acc = 0;
-      for (int tb = R - 64; tb > -64; tb -= 64) {
-        const int pos = tb + lane;
-        const bool hit = pos >= 0 && win[head + pos] == 0;
-        const unsigned long long b = __ballot(hit);
-        const int c = __popcll(b);
-        if (acc + c >= need) {
-          unsigned long long bb = b;
-          int want = need - acc, bit = 63;
-          while (true) {
-            bit = 63 - __clzll(bb);
-            if (--want == 0) break;
-            bb &= ~(1ull << bit);
-          }
-          pstar = tb + bit;
-          break;
-        }
-        acc += c;
-      }
+      const int pstar = tie_position(win, head, R, 0, need, lane);
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int bp = 16 * (j * 64 + lane) - head;
-        uint32_t keep = 0;
-        for (int bi = 0; bi < 16; bi++) {
-          const int pos = bp + bi;
-          if (pos >= pstar && pos < R) keep |= 1u << (8 * (bi & 3) + (bi >> 2));
-        }
+        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);
         m[j] |= (~m[j]) & 0x0F0F0F0Fu & keep;
       }
       cnt += need;
     }
 
-    // ---- compaction of the <= 64 candidates into LDS keys ----
-    wave_lds_fence();
+    // ---- compaction of the <= 64 candidates into LDS keys (one round per candidate of the fullest lane) ----
+    uint32_t w[NCH / 2];
+    pack_masks<NCH>(m, w);
     int nbase = 0;
+    while (true) {
+      uint32_t any = 0;
 #pragma unroll
-    for (int j = 0; j < NCH; j++) {
-      uint32_t mj = m[j];
-      while (true) {
-        const bool has = mj != 0;
-        const unsigned long long b = __ballot(has);
-        if (b == 0) break;
-        if (has) {
-          const int t = __ffs(mj) - 1;
-          const int bi = 4 * (t & 7) + (t >> 3);  // byte index inside the chunk
-          const int woff = 16 * (j * 64 + lane) + bi;
-          const uint32_t inten = win[woff];
-          const int pos = woff - head;
-          const int slot = nbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-          if (slot < 64) keys[slot] = (uint32_t)pos | (inten << 16) | (1u << 24);
-          mj &= mj - 1;
-        }
-        nbase += __popcll(b);
+      for (int i = 0; i < NCH / 2; i++) any |= w[i];
+      const unsigned long long b = __ballot(any != 0);
+      if (b == 0) break;
+      if (any != 0) {
+        int wi = 0;
+        uint32_t cur = w[0];
+#pragma unroll
+        for (int i = 1; i < NCH / 2; i++)
+          if (cur == 0) { cur = w[i]; wi = i; }
+        const int t = __ffs(cur) - 1;
+        const int j = 2 * wi + ((t >> 2) & 1);
+        const int bi = 4 * (t & 3) + (t >> 3);  // byte index inside the chunk
+        const int woff = 16 * (j * 64 + lane) + bi;
+        const int slot = nbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        if (slot < 64) keys[slot] = (uint32_t)woff;  // window offset; the intensity is fetched after the loop
+        const uint32_t cleared = cur & (cur - 1);
+#pragma unroll
+        for (int i = 0; i < NCH / 2; i++)
+          if (i == wi) w[i] = cleared;
       }
+      nbase += __popcll(b);
     }
     wave_lds_fence();
+    if (dbg == 3) {
+      if (nbase == 0x1234567) slots[g * (long long)k] = (uint32_t)nbase;
+      continue;
+    }
     const int C = cnt < 64 ? cnt : 64;
     const int kk = k < C ? k : C;  // number of emitted points
-    const uint32_t key = lane < C ? keys[lane] : 0u;
+    uint32_t key = 0u;
+    if (lane < C) {
+      const uint32_t woff = keys[lane];
+      key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
+    }
     int rank = 0;
-    for (int j = 0; j < C; j++) rank += (keys[j] > key) ? 1 : 0;
+    // lanes >= C hold key 0, so the loop may overrun C harmlessly: unrolled by 8, no per-key branch
+    for (int j = 0; j < C; j += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j + u) > key) ? 1 : 0;
+    }
     const bool kept = lane < C && rank < kk;
     const int mpos = (int)(key & 0xFFFFu);
 
@@ -325,23 +399,23 @@ __global__ __launch_bounds__(256) void kstrongest_kernel(const uint8_t* __restri
       }
     }
     if (kept) {
-      int byt[13];
+      const int off0 = head + mpos - 6;
+      int bv[13];
 #pragma unroll
       for (int t = 0; t < 13; t++) {
-        int off = head + mpos - 6 + t;
-        off = off < 0 ? 0 : (off > WIN - 1 ? WIN - 1 : off);
-        byt[t] = win[off];
+        bv[t] = win[off0 + t];  // 0 <= off0 + t < WIN: head >= 6 and R + 27 <= WIN
       }
-      int s[7];
+      int sm[7];  // sm[u] = sum bv[u..u+6] (7-tap box, radar_filters.cpp:258-261)
+      sm[0] = ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + bv[6]);
 #pragma unroll
-      for (int t = 0; t < 7; t++) {
-        s[t] = byt[t] + byt[t + 1] + byt[t + 2] + byt[t + 3] + byt[t + 4] + byt[t + 5] + byt[t + 6];
-        if (!((covered >> t) & 1u)) s[t] = 0;
-      }
+      for (int u = 1; u < 7; u++) sm[u] = sm[u - 1] - bv[u - 1] + bv[u + 6];
       bool largest = true;
 #pragma unroll
+      for (int u = 0; u < 7; u++)
+        if (!((covered >> u) & 1u)) sm[u] = 0;
+#pragma unroll
       for (int i = 1; i <= 3; i++) {
-        if (s[3 - i] > s[3] || s[3] < s[3 + i]) largest = false;  // :282
+        if (sm[3 - i] > sm[3] || sm[3] < sm[3 + i]) largest = false;  // :282
       }
       peak = largest ? (1u << 25) : 0u;
     }
@@ -355,6 +429,14 @@ __global__ __launch_bounds__(256) void kstrongest_kernel(const uint8_t* __restri
 
 }  // namespace
 
+// bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 grid oversubscription
+static int g_k1_dbg = 0, g_k1_occ = 6, g_k1_oversub = 1;
+extern "C" void cfear_debug_set(int key, int value) {
+  if (key == 0) g_k1_dbg = value;
+  if (key == 1) g_k1_occ = value;
+  if (key == 2) g_k1_oversub = value > 0 ? value : 1;
+}
+
 int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots) {
   const int A = ctx->A, R = ctx->R, k = ctx->par.k_strongest;
   if (!d_polar || !d_slots || n_scans <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "kstrongest: null buffer or n_scans <= 0");
@@ -363,16 +445,27 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const long long n_rows = (long long)n_scans * A;
   const long long alloc = n_rows * R;
   const int u_zmin = (int)(uint8_t)(int)ctx->par.z_min;  // float -> int (radar_filters.cpp:198) -> uchar (:212)
-  long long blocks = (n_rows + 3) / 4;
-  const long long cap = 256LL * 8;
-  if (blocks > cap) blocks = cap;
+  const int dbg = g_k1_dbg;
+  // one resident wave per SIMD slot (256 CUs x 4 SIMDs x occupancy); each wave walks consecutive rows
+  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 8 ? 8 : (g_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
+  const long long slots_total = 1024LL * occ_eff * g_k1_oversub;
+  int rows_per_wave = (int)((n_rows + slots_total - 1) / slots_total);
+  if (rows_per_wave < 1) rows_per_wave = 1;
+  const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
+  const long long blocks = (n_waves + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  if (R + 27 <= 4 * 1024)
-    hipLaunchKernelGGL(kstrongest_kernel<4>, grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc);
-  else if (R + 27 <= 8 * 1024)
-    hipLaunchKernelGGL(kstrongest_kernel<8>, grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc);
+  const int occ = g_k1_occ;
+  if (R + 27 <= 4 * 1024) {
+    if (occ >= 8)
+      hipLaunchKernelGGL((kstrongest_kernel<4, 8>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    else if (occ <= 5)
+      hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    else
+      hipLaunchKernelGGL((kstrongest_kernel<4, 6>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+  } else if (R + 27 <= 8 * 1024)
+    hipLaunchKernelGGL((kstrongest_kernel<8, 3>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
   else if (R + 27 <= 16 * 1024)
-    hipLaunchKernelGGL(kstrongest_kernel<16>, grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc);
+    hipLaunchKernelGGL((kstrongest_kernel<16, 2>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
   else
     return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "kstrongest: R > 16357 range bins not supported");
   CFEAR_HIP_CHECK(ctx, hipGetLastError());

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfear_radarodometry_code_public_amd import capi, synth
 from oracle import binding as ob
 RR = np.float32(0.0595238)
