@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   if (threadIdx.x <= 16) lds_ge[threadIdx.x] = chunk_range_mask((int)threadIdx.x, 16);
   __syncthreads();  // the only block-level barrier: before the waves go their own way
   const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: keeps all per-row bookkeeping on the SALU
   uint8_t* const win = reinterpret_cast<uint8_t*>(&lds_win[wave][0]);
   uint32_t* const keys = &lds_keys[wave][0];
   const uintptr_t base = reinterpret_cast<uintptr_t>(polar);
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 }  // namespace
 
 // bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 grid oversubscription
-static int g_k1_dbg = 0, g_k1_occ = 6, g_k1_oversub = 1;
+static int g_k1_dbg = 0, g_k1_occ = 8, g_k1_oversub = 2;
 extern "C" void cfear_debug_set(int key, int value) {
   if (key == 0) g_k1_dbg = value;
   if (key == 1) g_k1_occ = value;
