@@ -33,19 +33,32 @@ struct FeatureParams {
   double downsample_factor;  // pointnormal.h:241
   int weight_intensity;
   double assoc_radius;       // registration.h:122 (sizes the NN grid)
-  int dbg_stage;             // bring-up only: stop after stage N (0 = run everything)
 };
 
-// Working memory of one block. keys/vstart may point to LDS (small clouds) or to global memory.
+// optional per-block phase timestamps (bring-up / tuning): thread 0 stores wall_clock64() ticks (100 MHz)
+struct PhaseTimer {
+  long long* t;
+  int n;
+  __device__ inline void mark() { if (t && threadIdx.x == 0 && n < 32) t[n++] = (long long)wall_clock64(); }
+};
+
+// Working memory of one block. For clouds up to CFEAR_LDS_POINT_CAP points keys/order/vstart/vlist
+// live in LDS and the sorted points are staged over the key region after the sort; bigger clouds use
+// the global arrays of the same names.
+#define CFEAR_LDS_POINT_CAP 5120
 struct FeatureScratch {
-  uint64_t* keys;      // [p2cap] (voxel idx << 32 | point index), sorted. NB: a 24-bit packing with an
-                       // '& 0xFFFFFF' extract is miscompiled by hipcc 7.2 (mask dropped before v_mad_u64_u32)
-  int* vstart;         // [cap_points + 1]
-  float* samples;      // [cap_points][3] voxel centroids (global)
-  cfear_cell* tmp;     // [cap_points] candidate cells in sample order (global)
-  int* flags;          // [cap_points]
-  int* red_i;          // LDS, >= 64 ints
-  float* red_f;        // LDS, >= 64 floats
+  uint64_t* keys;   // [p2] (voxel << 32 | point) sort keys. NB: a 24-bit packing with an '& 0xFFFFFF' extract is
+                    // miscompiled by hipcc 7.2 (mask dropped in front of v_mad_u64_u32)
+  float* spts;      // [n][3] points in sorted order (LDS: aliases keys; global otherwise)
+  int* order;       // [n] point index of every sorted position
+  int* vstart;      // [n + 1] start of each occupied voxel in the sorted order
+  int* vlist;       // [n] voxel index of each occupied voxel, ascending
+  int* vcur;        // global [cap_grid + 1] cursors of the cell-mean grid
+  float* samples;   // global [cap_points][3] voxel centroids
+  cfear_cell* tmp;  // global [cap_points] candidate cells in sample order
+  int* flags;       // global [cap_points]
+  int* red_i;       // LDS, >= 64 ints
+  float* red_f;     // LDS, >= 64 floats
 };
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
@@ -120,15 +133,43 @@ __device__ inline void eig2(double a, double b, double c, double* lmin, double* 
   vmin[0] = -vmax[1]; vmin[1] = vmax[0];
 }
 
-__device__ inline int lower_bound_key(const uint64_t* keys, int n, uint64_t v) {
+__device__ inline int lower_bound_int(const int* a, int n, long long v) {
   int lo = 0, hi = n;
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < v) lo = mid + 1; else hi = mid; }
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)a[mid] < v) lo = mid + 1; else hi = mid; }
   return lo;
+}
+
+// shifted weighted moments of the points q in [a, b) of the sorted array that lie within r2 of (cx, cy)
+struct CellAcc { int m; double s0, s1x, s1y, sxx, sxy, syy; };
+// lane `sub` of a group of GS lanes takes the batches a + 4*sub, a + 4*(sub + GS), ...
+__device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, int a, int b, float cx, float cy, float r2,
+                                        int weight_intensity, CellAcc& A, int sub, int GS) {
+  const double cxd = (double)cx, cyd = (double)cy;
+  for (int q = a + 4 * sub; q < b; q += 4 * GS) {
+    float px[4], py[4], pw[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // independent LDS loads first, arithmetic afterwards
+      const int qq = min(q + u, b - 1);
+      px[u] = sp[3 * qq]; py[u] = sp[3 * qq + 1]; pw[u] = sp[3 * qq + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float dx = cx - px[u], dy = cy - py[u];
+      float d2 = dx * dx; d2 += dy * dy;
+      if (q + u < b && d2 < r2) {  // pointnormal.cpp:291 radius test (float, strict)
+        const double w = weight_intensity ? fmax((double)pw[u] - 60.0, 0.0) : 1.0;  // :15
+        const double ex = (double)px[u] - cxd, ey = (double)py[u] - cyd;
+        A.m++; A.s0 += w; A.s1x += w * ex; A.s1y += w * ey;
+        A.sxx += w * (ex * ex); A.sxy += w * (ex * ey); A.syy += w * (ey * ey);
+      }
+    }
+  }
 }
 
 // MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi.
 // p2 = power of two >= n with p2 <= capacity of W.keys.
-__device__ inline void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2) {
+__device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2,
+                                      PhaseTimer* pt = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const float* __restrict__ xyi = S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
@@ -144,10 +185,8 @@ __device__ inline void features_block(ScanDev* __restrict__ S, int n, const Feat
     const float x = xyi[3 * i], y = xyi[3 * i + 1];
     mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
   }
-  if (P.dbg_stage == 8) return;
   mnx = block_min(mnx, W.red_f); mxx = block_max(mxx, W.red_f);
   mny = block_min(mny, W.red_f); mxy = block_max(mxy, W.red_f);
-  if (P.dbg_stage == 7) return;
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
@@ -161,10 +200,10 @@ __device__ inline void features_block(ScanDev* __restrict__ S, int n, const Feat
     }
     W.keys[i] = key;
   }
-  if (P.dbg_stage == 1) return;
-  block_bitonic_sort(W.keys, p2);
-  if (P.dbg_stage == 2) return;
-  // ---- voxel segments ----
+  if (pt) pt->mark();
+  block_bitonic_sort(W.keys, p2);  // [3P] std::sort on the voxel index, pinned as stable by the point index
+  if (pt) pt->mark();
+  // ---- voxel segments, sorted order ----
   {
     const int ipt = (n + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(n, i0 + ipt);
@@ -172,98 +211,105 @@ __device__ inline void features_block(ScanDev* __restrict__ S, int n, const Feat
     for (int i = i0; i < i1; i++) cnt += (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) ? 1 : 0;
     int nv;
     int o = block_exclusive_scan(cnt, W.red_i, &nv);
-    for (int i = i0; i < i1; i++)
-      if (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) W.vstart[o++] = i;
+    for (int i = i0; i < i1; i++) {
+      const uint64_t k = W.keys[i];
+      W.order[i] = (int)(uint32_t)k;
+      if (i == 0 || (k >> 32) != (W.keys[i - 1] >> 32)) { W.vstart[o] = i; W.vlist[o] = (int)(k >> 32); o++; }
+    }
     if (tid == 0) { W.vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
   }
   const int nv = S->n_samples;
-  if (P.dbg_stage == 3) return;
-  // ---- centroids: float sums in ascending (voxel, point) order, divided by float(count) ----
+  // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)
+  for (int q = tid; q < n; q += nt) {
+    const int pi = W.order[q];
+    W.spts[3 * q] = xyi[3 * pi]; W.spts[3 * q + 1] = xyi[3 * pi + 1]; W.spts[3 * q + 2] = xyi[3 * pi + 2];
+  }
+  __syncthreads();
+  if (pt) pt->mark();
+  const float* __restrict__ sp = W.spts;
+  // ---- centroids: float sums in ascending (voxel, point) order, divided by float(count) ([3P] PCL CentroidPoint) ----
   for (int v = tid; v < nv; v += nt) {
     const int a = W.vstart[v], b = W.vstart[v + 1];
     float sx = 0.f, sy = 0.f, si = 0.f;
-    for (int q = a; q < b; q++) {
-      const int pi = (int)(uint32_t)W.keys[q];
-      sx += xyi[3 * pi]; sy += xyi[3 * pi + 1]; si += xyi[3 * pi + 2];
-    }
+    for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
     const float cnt = (float)(b - a);
     W.samples[3 * v] = sx / cnt; W.samples[3 * v + 1] = sy / cnt; W.samples[3 * v + 2] = si / cnt;
   }
   __syncthreads();
-  if (P.dbg_stage == 4) return;
+  if (pt) pt->mark();
   // ---- radius search + cell statistics per sample point (pointnormal.cpp:286-296, :7-63) ----
+  // One pass over the candidates with moments shifted by the sample point c:
+  //   mean = c + S1/S0,  cov = S2/S0 - (S1/S0)(S1/S0)^T   (== sum w_i (x_i-u)(x_i-u)^T with sum w_i = 1)
   const float r2 = (float)((double)P.radius * (double)P.radius);
   const float rq = P.radius * 1.0001f;
-  for (int v = tid; v < nv; v += nt) {
-    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
-    int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
-    int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
-    gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
-    int ra[8], rb[8];
-    int nrows = 0;
-    for (int gy = gy0; gy <= gy1 && nrows < 8; gy++) {
-      if (gx0 > gx1) break;
-      const uint64_t k0 = (uint64_t)((long long)gx0 + (long long)gy * div0), k1 = (uint64_t)((long long)gx1 + (long long)gy * div0);
-      ra[nrows] = lower_bound_key(W.keys, n, k0 << 32);
-      rb[nrows] = lower_bound_key(W.keys, n, (k1 + 1) << 32);
-      nrows++;
-    }
-    // pass A: neighbour count and weight sum
-    int m = 0;
-    double sum = 0;
-    for (int r = 0; r < nrows; r++)
-      for (int q = ra[r]; q < rb[r]; q++) {
-        const int i = (int)(uint32_t)W.keys[q];
-        const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
-        float d2 = dx * dx; d2 += dy * dy;
-        if (d2 < r2) { m++; sum += P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0; }
+  // Groups of 8 lanes share one sample point (candidate counts range from 1 to ~1000 per voxel, so a
+  // thread-per-voxel mapping is badly imbalanced); fixed xor-tree reduction keeps the result deterministic.
+  constexpr int GS = 2;
+  const int sub = tid & (GS - 1);
+  for (int v0 = 0; v0 < nv; v0 += nt / GS) {  // uniform trip count: the shuffles below need all lanes
+    const int v = v0 + tid / GS;
+    const bool live = v < nv;
+    const float cx = live ? W.samples[3 * v] : 0.f, cy = live ? W.samples[3 * v + 1] : 0.f;
+    CellAcc A = {0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
+      int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
+      gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
+      for (int gy = gy0; gy <= gy1 && gx0 <= gx1; gy++) {
+        // voxels gx0..gx1 of this row are contiguous in the sorted order: search the (LDS) voxel list
+        const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
+        const int p0 = lower_bound_int(W.vlist, nv, k0);
+        int p1 = p0;
+        while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
+        if (p1 > p0) accumulate_range(sp, W.vstart[p0], W.vstart[p1], cx, cy, r2, P.weight_intensity, A, sub, GS);
       }
-    cfear_cell c;
-    c.valid = 0; c.nsamples = m;
+    }
+#pragma unroll
+    for (int off = 1; off < GS; off <<= 1) {
+      A.m += __shfl_xor(A.m, off);
+      A.s0 += __shfl_xor(A.s0, off); A.s1x += __shfl_xor(A.s1x, off); A.s1y += __shfl_xor(A.s1y, off);
+      A.sxx += __shfl_xor(A.sxx, off); A.sxy += __shfl_xor(A.sxy, off); A.syy += __shfl_xor(A.syy, off);
+    }
+    if (live && sub == 0) {  // park the reduced moments in the cell slot; the f64 epilogue runs thread-per-voxel below
+      cfear_cell* c = &W.tmp[v];
+      c->mean[0] = A.s0; c->mean[1] = A.s1x; c->cov[0] = A.s1y; c->cov[1] = A.sxx; c->cov[2] = A.sxy; c->normal[0] = A.syy;
+      c->nsamples = A.m;
+    }
+  }
+  __syncthreads();
+  if (pt) pt->mark();
+  for (int v = tid; v < nv; v += nt) {
+    cfear_cell* c = &W.tmp[v];
+    const int m = c->nsamples;
+    int valid = 0;
     if (m >= 6) {  // :291
-      double ux = 0, uy = 0;
-      for (int r = 0; r < nrows; r++)
-        for (int q = ra[r]; q < rb[r]; q++) {
-          const int i = (int)(uint32_t)W.keys[q];
-          const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
-          float d2 = dx * dx; d2 += dy * dy;
-          if (d2 < r2) {
-            const double w = (P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0) / sum;
-            ux += w * (double)xyi[3 * i]; uy += w * (double)xyi[3 * i + 1];
-          }
-        }
-      double cxx = 0, cyx = 0, cyy = 0;
-      for (int r = 0; r < nrows; r++)
-        for (int q = ra[r]; q < rb[r]; q++) {
-          const int i = (int)(uint32_t)W.keys[q];
-          const float dx = cx - xyi[3 * i], dy = cy - xyi[3 * i + 1];
-          float d2 = dx * dx; d2 += dy * dy;
-          if (d2 < r2) {
-            const double w = (P.weight_intensity ? fmax((double)xyi[3 * i + 2] - 60.0, 0.0) : 1.0) / sum;
-            const double ex = (double)xyi[3 * i] - ux, ey = (double)xyi[3 * i + 1] - uy;
-            cxx += ex * (w * ex); cyx += ey * (w * ex); cyy += ey * (w * ey);
-          }
-        }
+      const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+      const double s0 = c->mean[0], s1x = c->mean[1], s1y = c->cov[0], sxx = c->cov[1], sxy = c->cov[2], syy = c->normal[0];
+      const double m1x = s1x / s0, m1y = s1y / s0;
+      const double ux = (double)cx + m1x, uy = (double)cy + m1y;
+      const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
       double lmin, lmax, vmin[2], vmax[2];
       eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
       const double cond = fabs(lmax / lmin);  // :53
       const double det = lmax * lmin;         // :54
-      c.valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
-      c.scale = log(1.0 + cond / 2);  // :57
-      if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
-      c.mean[0] = ux; c.mean[1] = uy;
-      c.cov[0] = cxx; c.cov[1] = cyx; c.cov[2] = cyy;
-      c.normal[0] = vmin[0]; c.normal[1] = vmin[1];
-      c.orth[0] = vmax[0]; c.orth[1] = vmax[1];
-      c.lambda_min = lmin; c.lambda_max = lmax;
-      c.sum_intensity = sum; c.avg_intensity = sum / m;
-      if (c.valid) W.tmp[v] = c;
+      valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
+      if (valid) {
+        if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
+        c->mean[0] = ux; c->mean[1] = uy;
+        c->cov[0] = cxx; c->cov[1] = cyx; c->cov[2] = cyy;
+        c->normal[0] = vmin[0]; c->normal[1] = vmin[1];
+        c->orth[0] = vmax[0]; c->orth[1] = vmax[1];
+        c->lambda_min = lmin; c->lambda_max = lmax;
+        c->scale = log(1.0 + cond / 2);  // :57
+        c->sum_intensity = s0; c->avg_intensity = s0 / m;
+        c->valid = 1;
+      }
     }
-    W.flags[v] = c.valid;
+    W.flags[v] = valid;
   }
   __syncthreads();
-  if (P.dbg_stage == 5) return;
+  if (pt) pt->mark();
   // ---- keep valid cells in sample order (pointnormal.cpp:292-294) ----
   {
     const int ipt = (nv + nt - 1) / nt;
@@ -283,7 +329,7 @@ __device__ inline void features_block(ScanDev* __restrict__ S, int n, const Feat
     if (tid == 0) S->n_cells = nc < S->cap_cells ? nc : S->cap_cells;
     __syncthreads();
   }
-  if (P.dbg_stage == 6) return;
+  if (pt) pt->mark();
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
   const int nc = S->n_cells;
   float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
@@ -322,35 +368,20 @@ __device__ inline void features_block(ScanDev* __restrict__ S, int n, const Feat
     for (int g = i0; g < i1; g++) cnt += S->gstart[g + 1];
     int tot;
     int o = block_exclusive_scan(cnt, W.red_i, &tot);
-    for (int g = i0; g < i1; g++) { const int c = S->gstart[g + 1]; S->gstart[g + 1] = o + c; o += c; }
+    for (int g = i0; g < i1; g++) { const int c = S->gstart[g + 1]; W.vcur[g] = o; S->gstart[g + 1] = o + c; o += c; }
     __syncthreads();
   }
-  // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query
-  // breaks exact ties by cell index). Per-bucket cursors live in W.vstart (free after the radius search); needs G <= cap_points + 1.
-  int* cursor = W.vstart;
-  const bool cursor_ok = G <= S->cap_points;
-  if (cursor_ok) {
-    for (int g = tid; g < G; g += nt) cursor[g] = S->gstart[g];
-    __syncthreads();
-    for (int i = tid; i < nc; i += nt) {
-      int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
-      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-      const int pos = atomicAdd(&cursor[cy * gw + cx], 1);
-      S->gorder[pos] = i;
-    }
-  } else if (tid == 0) {
-    // tiny clouds with a huge bounding box: serial fill (rare)
-    for (int g = 0; g < G; g++) {
-      int pos = S->gstart[g];
-      for (int i = 0; i < nc; i++) {
-        int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
-        cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-        if (cy * gw + cx == g) S->gorder[pos++] = i;
-      }
-    }
+  // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query breaks
+  // exact ties by cell index)
+  for (int i = tid; i < nc; i += nt) {
+    int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+    const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
+    S->gorder[pos] = i;
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
   __syncthreads();
+  if (pt) pt->mark();
 }
 
 // GetClosestIdx (pointnormal.cpp:238-254): 1-NN over the float cell means, accepted iff d2 < d*d.

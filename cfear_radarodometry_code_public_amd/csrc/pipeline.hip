@@ -1,8 +1,14 @@
 // pipeline.hip -- kernels and C-ABI entry points for stages 1.5-3 and the batched odometry step.
 // Interface contract + reference citations: include/cfear_hip.h. Device code: features_dev.h,
-// registration_dev.h. One workgroup (1024 threads = 16 waves) owns one scan / one registration
-// problem / one sequence, so a batch of B sequences fills B compute units with no host round trip
-// inside a frame: filter kernel -> odometry_step_kernel, both asynchronous on the context stream.
+// registration_dev.h.
+//
+// One radar sweep of B independent sequences = three launches on the context stream, no host round trip:
+//   kstrongest_kernel      (kstrongest.hip)  B*A wavefront-rows, HBM streaming
+//   features_step_kernel   one 1024-thread workgroup per sequence: cloud, motion compensation, voxel sort
+//                          and sorted points in ~125 KB of LDS, cell statistics, cell-mean grid
+//   register_step_kernel   one 256-thread workgroup per sequence (12 KB LDS, several per compute unit so
+//                          that the serial Levenberg-Marquardt controllers of different sequences overlap):
+//                          association, robust normal equations, LM, outer loop, keyframe logic
 #include <math.h>
 #include <stdlib.h>
 
@@ -15,33 +21,41 @@ using namespace cfear_dev;
 
 namespace {
 
-constexpr int BLOCK = 1024;
-constexpr int LDS_KEYS = 8192;  // u64 sort keys kept in LDS when A*k <= 8192
-constexpr int MAX_SCANS = 64;   // keyframes + current
+constexpr int BLOCK_F = 1024;  // features / cloud kernels
+constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
+constexpr int MAX_SCANS = 64;  // keyframes + current
+constexpr int VOXEL_GRID_CAP = 65536;  // dense voxel-index table (e.g. 256 x 256 leaves)
+constexpr int LDS_P2 = 8192;   // sort keys held in LDS (clouds up to CFEAR_LDS_POINT_CAP points)
 
-struct LdsLayout {
-  // byte offsets into the dynamic LDS segment
+struct FeatLds {  // byte offsets into the static LDS segment of the features kernels
+  static constexpr size_t red_i = 0;                                   // 64 ints
+  static constexpr size_t red_f = red_i + 64 * sizeof(int);           // 64 floats
+  static constexpr size_t keys = red_f + 64 * sizeof(float);          // LDS_P2 u64, later the sorted points
+  static constexpr size_t order = keys + LDS_P2 * sizeof(uint64_t);   // CFEAR_LDS_POINT_CAP ints
+  static constexpr size_t vstart = order + CFEAR_LDS_POINT_CAP * sizeof(int);      // +1 (padded)
+  static constexpr size_t vlist = vstart + (CFEAR_LDS_POINT_CAP + 8) * sizeof(int);
+  static constexpr size_t total = vlist + CFEAR_LDS_POINT_CAP * sizeof(int);
+};
+struct RegLds {  // registration kernels
   static constexpr size_t red_d = 0;                                  // 320 doubles
   static constexpr size_t par = red_d + 320 * sizeof(double);        // 3*MAX_SCANS doubles
   static constexpr size_t red_i = par + 3 * MAX_SCANS * sizeof(double);  // 64 ints
-  static constexpr size_t red_f = red_i + 64 * sizeof(int);          // 64 floats
-  static constexpr size_t scanptr = red_f + 64 * sizeof(float);      // MAX_SCANS pointers
-  static constexpr size_t keys = scanptr + MAX_SCANS * sizeof(void*);   // LDS_KEYS u64 (optional)
-  static constexpr size_t vstart = keys + LDS_KEYS * sizeof(uint64_t);  // LDS_KEYS+1 ints (optional)
-  static constexpr size_t total_small = keys;
-  static constexpr size_t total_lds_keys = vstart + (LDS_KEYS + 8) * sizeof(int);
+  static constexpr size_t scanptr = red_i + 64 * sizeof(int);        // MAX_SCANS pointers
+  static constexpr size_t regsh = scanptr + MAX_SCANS * sizeof(void*);  // RegShared
+  static constexpr size_t total = (regsh + sizeof(RegShared) + 15) / 16 * 16;
 };
 
-// Global per-block working memory (one per context for the per-call API, one per sequence for the batch).
+// Global per-sequence working memory (also one per context for the per-call API).
 struct BlockScratch {
-  uint64_t* keys;   // [p2cap] (only used when the keys do not fit LDS)
-  int* vstart;      // [cap_points + 1]
+  uint64_t* keys; float* spts; int* order; int* vstart; int* vlist;  // big-cloud fallbacks of the LDS arrays
+  int* vidx;        // [VOXEL_GRID_CAP] dense voxel table, all zero between kernels
+  int* vcur;        // [GRID_CAP + 2]
   float* samples;   // [cap_points * 3]
   cfear_cell* tmp;  // [cap_points]
   int* flags;       // [cap_points]
   double* match;    // [8][pair_cap]
   int* assoc;       // [pair_cap]
-  int cap_points, p2cap, pair_cap;
+  int cap_points, p2cap, pair_cap, gcap;
 };
 
 struct SeqState {  // OdometryKeyframeFuser members (odometrykeyframefuser.h:203-260) for one sequence
@@ -56,16 +70,40 @@ struct OdoParams {
   RegParams rp;
   int A, k, compensate, ccw, use_keyframe, submap;
   double min_keyframe_dist, min_keyframe_rot_deg;
+  long long* phase_times;  // optional [B][32] wall_clock64 ticks (tools/)
 };
 
-__device__ inline FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds, bool lds_keys) {
+__device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// LDS = true: keys/order/vstart/vlist and the staged points are LDS arrays (ds_* instructions after
+// inlining); LDS = false: their global twins for clouds above CFEAR_LDS_POINT_CAP points.
+template <bool LDS>
+__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds) {
   FeatureScratch W;
-  W.keys = lds_keys ? reinterpret_cast<uint64_t*>(lds + LdsLayout::keys) : B.keys;
-  W.vstart = lds_keys ? reinterpret_cast<int*>(lds + LdsLayout::vstart) : B.vstart;
+  if (LDS) {
+    W.keys = reinterpret_cast<uint64_t*>(lds + FeatLds::keys);
+    W.spts = reinterpret_cast<float*>(lds + FeatLds::keys);
+    W.order = reinterpret_cast<int*>(lds + FeatLds::order);
+    W.vstart = reinterpret_cast<int*>(lds + FeatLds::vstart);
+    W.vlist = reinterpret_cast<int*>(lds + FeatLds::vlist);
+  } else {
+    W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
+  }
+  W.vcur = B.vcur;
   W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
-  W.red_i = reinterpret_cast<int*>(lds + LdsLayout::red_i);
-  W.red_f = reinterpret_cast<float*>(lds + LdsLayout::red_f);
+  W.red_i = reinterpret_cast<int*>(lds + FeatLds::red_i);
+  W.red_f = reinterpret_cast<float*>(lds + FeatLds::red_f);
   return W;
+}
+__device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
+                                                  unsigned char* lds, PhaseTimer* pt) {
+  if (n <= CFEAR_LDS_POINT_CAP) {  // block-uniform
+    const FeatureScratch W = make_fscratch<true>(B, lds);
+    features_block(S, n, P, W, next_pow2(n), pt);
+  } else {
+    const FeatureScratch W = make_fscratch<false>(B, lds);
+    features_block(S, n, P, W, next_pow2(n), pt);
+  }
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
   RegScratch W;
@@ -73,38 +111,31 @@ __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char*
   W.tmx = B.match; W.tmy = B.match + c; W.a0 = B.match + 2 * c; W.a1 = B.match + 3 * c; W.a2 = B.match + 4 * c;
   W.sx = B.match + 5 * c; W.sy = B.match + 6 * c; W.w = B.match + 7 * c;
   W.assoc = B.assoc; W.sim = nullptr; W.cap = B.pair_cap;
-  W.red = reinterpret_cast<double*>(lds + LdsLayout::red_d);
-  W.red_i = reinterpret_cast<int*>(lds + LdsLayout::red_i);
+  W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
+  W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
   return W;
 }
-__device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 // ---- per-call kernels -------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void cloud_kernel(const uint32_t* slots, int A, int k, const double* trig, float rr,
-                                                      float md, int peaks, float* xyi, int cap, int* d_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LdsLayout::total_small];
-  const int n = cloud_build_block(slots, A, k, trig, rr, md, peaks, xyi, cap, reinterpret_cast<int*>(lds + LdsLayout::red_i));
+__global__ __launch_bounds__(BLOCK_F) void cloud_kernel(const uint32_t* slots, int A, int k, const double* trig, float rr,
+                                                        float md, int peaks, float* xyi, int cap, int* d_n) {
+  __shared__ int red_i[64];
+  const int n = cloud_build_block(slots, A, k, trig, rr, md, peaks, xyi, cap, red_i);
   if (threadIdx.x == 0) *d_n = n;
 }
 
-__global__ __launch_bounds__(BLOCK) void compensate_kernel(float* xyi, const int* d_n, double m0, double m1, double m2, int ccw) {
+__global__ __launch_bounds__(BLOCK_F) void compensate_kernel(float* xyi, const int* d_n, double m0, double m1, double m2, int ccw) {
   compensate_block(xyi, *d_n, m0, m1, m2, ccw);
 }
 
-template <bool LDSKEYS>
-__global__ __launch_bounds__(BLOCK) void features_kernel(ScanDev* S, const float* src_xyi, const int* d_n, FeatureParams P,
-                                                         BlockScratch B) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSKEYS ? LdsLayout::total_lds_keys : LdsLayout::total_small];
-  if (P.dbg_stage == -1) return;
+__global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const float* src_xyi, const int* d_n, FeatureParams P,
+                                                           BlockScratch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::total];
   int n = *d_n;
-  if (P.dbg_stage == -2) return;
   if (n > S->cap_points) n = S->cap_points;
-  if (P.dbg_stage == -3) return;
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) S->xyi[i] = src_xyi[i];
   __syncthreads();
-  if (P.dbg_stage == -4) return;
-  const FeatureScratch W = make_fscratch(B, lds, LDSKEYS);
-  features_block(S, n, P, W, next_pow2(n));
+  features_dispatch(S, n, P, B, lds, nullptr);
 }
 
 __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx) {
@@ -112,25 +143,47 @@ __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double
   if (i < nq) idx[i] = scan_closest(S, q[2 * i], q[2 * i + 1], d);
 }
 
-__global__ __launch_bounds__(BLOCK) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
-                                                         BlockScratch B, cfear_reg_summary* out) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LdsLayout::total_small];
-  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + LdsLayout::scanptr);
+__global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
+                                                           BlockScratch B, cfear_reg_summary* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
   for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];
   __syncthreads();
   const RegScratch W = make_rscratch(B, lds);
-  register_block(sp, n, poses, cov6, P, W, reinterpret_cast<double*>(lds + LdsLayout::par), out);
+  register_block(sp, n, poses, cov6, P, W, reinterpret_cast<double*>(lds + RegLds::par),
+                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), out);
 }
 
-// ---- batched odometry: one workgroup = one sequence, one launch = one radar sweep --------------
-// OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all state on device.
-template <bool LDSKEYS>
-__global__ __launch_bounds__(BLOCK) void odometry_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
-                                                              SeqState* states, ScanDev* const* scan_slots /*[B][submap+1]*/,
-                                                              const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
-                                                              double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
-                                                              double* poses_out /*[B][3]*/) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDSKEYS ? LdsLayout::total_lds_keys : LdsLayout::total_small];
+// ---- batched odometry: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all
+// state on the device, split after the feature build (:161) ------------------------------------------
+__global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
+                                                                const SeqState* states, ScanDev* const* scan_slots,
+                                                                const BlockScratch* scratch) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::total];
+  const int q = blockIdx.x;
+  const SeqState* st = &states[q];
+  const BlockScratch B = scratch[q];
+  ScanDev* cur = scan_slots[(size_t)q * (OP.submap + 1) + st->free_slot];
+  const Aff2 TprevMot = st->Tmot;  // :146
+  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0;
+  pt.mark();
+  // stage 1 (second half): slots -> cloud (radar_driver.cpp:59)
+  const int n = cloud_build_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance, 0,
+                                  cur->xyi, cur->cap_points, reinterpret_cast<int*>(lds + FeatLds::red_i));
+  pt.mark();
+  if (OP.compensate) {  // :147-150
+    double mot[3]; aff_to_xyt(TprevMot, mot);
+    compensate_block(cur->xyi, n, mot[0], mot[1], mot[2], OP.ccw);
+  }
+  pt.mark();
+  features_dispatch(cur, n, OP.fp, B, lds, &pt);  // :161
+}
+
+__global__ __launch_bounds__(BLOCK_R) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+                                                                const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
+                                                                double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
+                                                                double* poses_out /*[B][3]*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
   const int q = blockIdx.x, tid = threadIdx.x;
   SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
@@ -138,19 +191,13 @@ __global__ __launch_bounds__(BLOCK) void odometry_step_kernel(const uint32_t* sl
   ScanDev* const* my_slots = scan_slots + (size_t)q * nslots;
   const int cur_slot = st->free_slot;
   ScanDev* cur = my_slots[cur_slot];
-  const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;  // :146
+  const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
   const int nkf = st->nkf;
-  // stage 1 (second half): slots -> cloud (radar_driver.cpp:59)
-  const int n = cloud_build_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance, 0,
-                                  cur->xyi, cur->cap_points, reinterpret_cast<int*>(lds + LdsLayout::red_i));
-  if (OP.compensate) {  // :147-150
-    double mot[3]; aff_to_xyt(TprevMot, mot);
-    compensate_block(cur->xyi, n, mot[0], mot[1], mot[2], OP.ccw);
-  }
-  const FeatureScratch FW = make_fscratch(B, lds, LDSKEYS);
-  features_block(cur, n, OP.fp, FW, next_pow2(n));  // :161
-  const Aff2 Tguess = aff_mul(T_prev, TprevMot);    // :166
+  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 12 : nullptr; pt.n = 0;
+  pt.mark();
+  const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
   cfear_reg_summary* sum = &summaries[q];
+  __syncthreads();  // every thread has read the state before thread 0 rewrites it
   if (nkf == 0) {  // :171-177
     if (tid == 0) {
       st->ring[0] = cur_slot; st->kf_pose[0] = aff_identity(); st->nkf = 1; st->free_slot = (cur_slot + 1) % nslots;
@@ -162,7 +209,7 @@ __global__ __launch_bounds__(BLOCK) void odometry_step_kernel(const uint32_t* sl
     return;
   }
   // FormatScans (:478-494)
-  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + LdsLayout::scanptr);
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
   double* poses = poses_work + (size_t)q * MAX_SCANS * 3;
   const int ns = nkf + 1;
   if (tid < nkf) {
@@ -177,8 +224,10 @@ __global__ __launch_bounds__(BLOCK) void odometry_step_kernel(const uint32_t* sl
   }
   __syncthreads();
   const RegScratch RW = make_rscratch(B, lds);
-  register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + LdsLayout::par), sum);  // :186 (result ignored, :184-186)
+  register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),
+                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), sum, &pt);  // :186 (result ignored, :184-186)
   __syncthreads();
+  pt.mark();
   if (tid == 0) {
     Aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]);  // :195
     const Aff2 Tpi = aff_inv(T_prev);
@@ -229,8 +278,6 @@ FeatureParams feature_params(const cfear_ctx* ctx) {
   P.downsample_factor = ctx->par.downsample_factor;
   P.weight_intensity = ctx->par.weight_intensity;
   P.assoc_radius = ctx->par.assoc_radius;
-  const char* dbg = getenv("CFEAR_DBG_STAGE");
-  P.dbg_stage = dbg ? atoi(dbg) : 0;
   return P;
 }
 RegParams reg_params(const cfear_ctx* ctx) {
@@ -272,14 +319,21 @@ ScanDev scan_header(unsigned char* d_base, int cap_points) {
   return h;
 }
 
-struct ScratchLayout { size_t keys, vstart, samples, tmp, flags, match, assoc, total; int p2cap; };
+struct ScratchLayout { size_t keys, spts, order, vstart, vlist, vidx, vcur, samples, tmp, flags, match, assoc, total; int p2cap; bool big; };
 ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   ScratchLayout L;
   int p2 = 1; while (p2 < cap_points) p2 <<= 1;
   L.p2cap = p2;
+  L.big = cap_points > CFEAR_LDS_POINT_CAP;  // the LDS arrays need global twins only for big clouds
+  const size_t cp = L.big ? (size_t)cap_points : 1, kp = L.big ? (size_t)p2 : 1;
   size_t o = 0;
-  L.keys = o; o = align_up(o + sizeof(uint64_t) * (size_t)p2, 256);
-  L.vstart = o; o = align_up(o + sizeof(int) * ((size_t)cap_points + 2), 256);
+  L.keys = o; o = align_up(o + sizeof(uint64_t) * kp, 256);
+  L.spts = o; o = align_up(o + sizeof(float) * 3 * cp, 256);
+  L.order = o; o = align_up(o + sizeof(int) * cp, 256);
+  L.vstart = o; o = align_up(o + sizeof(int) * (cp + 2), 256);
+  L.vlist = o; o = align_up(o + sizeof(int) * cp, 256);
+  L.vidx = o; o = align_up(o + sizeof(int) * VOXEL_GRID_CAP, 256);
+  L.vcur = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
   L.samples = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.tmp = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.flags = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
@@ -292,13 +346,18 @@ BlockScratch scratch_header(unsigned char* d_base, int cap_points, int pair_cap)
   const ScratchLayout L = scratch_layout(cap_points, pair_cap);
   BlockScratch B;
   B.keys = reinterpret_cast<uint64_t*>(d_base + L.keys);
+  B.spts = reinterpret_cast<float*>(d_base + L.spts);
+  B.order = reinterpret_cast<int*>(d_base + L.order);
   B.vstart = reinterpret_cast<int*>(d_base + L.vstart);
+  B.vlist = reinterpret_cast<int*>(d_base + L.vlist);
+  B.vidx = reinterpret_cast<int*>(d_base + L.vidx);
+  B.vcur = reinterpret_cast<int*>(d_base + L.vcur);
   B.samples = reinterpret_cast<float*>(d_base + L.samples);
   B.tmp = reinterpret_cast<cfear_cell*>(d_base + L.tmp);
   B.flags = reinterpret_cast<int*>(d_base + L.flags);
   B.match = reinterpret_cast<double*>(d_base + L.match);
   B.assoc = reinterpret_cast<int*>(d_base + L.assoc);
-  B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap;
+  B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap; B.gcap = VOXEL_GRID_CAP;
   return B;
 }
 
@@ -328,6 +387,7 @@ struct cfear_odometry {
   double* d_poses_out = nullptr;
   uint32_t* d_slots = nullptr;
   uint8_t* d_polar = nullptr;  // staging for step_host
+  long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
   bool profile = false;        // record HIP events around both kernels of every step
   std::vector<hipEvent_t> events;  // 3 per profiled step
 };
@@ -341,6 +401,7 @@ static int ensure_ctx_scratch(cfear_ctx* ctx, int cap_points, int pair_cap) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     if (hipMalloc(&ctx->d_scratch, need) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc context scratch");
+    if (hipMemset(ctx->d_scratch, 0, need) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "hipMemset context scratch");  // dense voxel table starts all-zero
     ctx->scratch_bytes = need;
   }
   return CFEAR_OK;
@@ -384,7 +445,7 @@ int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_clou
     cfear_cloud* c = nullptr;
     rc = cloud_alloc(ctx, cap, &c);
     if (rc != CFEAR_OK) return rc;
-    hipLaunchKernelGGL(cloud_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
+    hipLaunchKernelGGL(cloud_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
                        ctx->par.range_res, ctx->par.min_distance, peaks, c->d_xyi, cap, c->d_n);
     if (peaks == 0) *cloud = c; else *cloud_peaks = c;
   }
@@ -440,7 +501,7 @@ int cfear_compensate(cfear_ctx* ctx, cfear_cloud* c, const double motion_xyt[3],
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // Affine3dToVectorXYeZ of the motion (utils.cpp:109-112): theta passes through atan2(sin, cos)
   const double th = atan2(sin(motion_xyt[2]), cos(motion_xyt[2]));
-  hipLaunchKernelGGL(compensate_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, c->d_xyi, c->d_n, motion_xyt[0], motion_xyt[1], th, ccw);
+  hipLaunchKernelGGL(compensate_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, c->d_xyi, c->d_n, motion_xyt[0], motion_xyt[1], th, ccw);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -473,12 +534,8 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
     fprintf(stderr, "scratch %p +%zu (alloc %zu) | keys %p vstart %p samples %p tmp %p flags %p match %p assoc %p\n", ctx->d_scratch, WL.total, ctx->scratch_bytes, (void*)B.keys, (void*)B.vstart, (void*)B.samples, (void*)B.tmp, (void*)B.flags, (void*)B.match, (void*)B.assoc);
     fprintf(stderr, "cloud xyi %p cap %d d_n %p\n", (void*)cloud->d_xyi, cloud->cap, (void*)cloud->d_n);
   }
-  if (cap <= LDS_KEYS)
-    hipLaunchKernelGGL(features_kernel<true>, dim3(1), dim3(BLOCK), 0, ctx->stream,
-                       reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi, cloud->d_n, P, B);
-  else
-    hipLaunchKernelGGL(features_kernel<false>, dim3(1), dim3(BLOCK), 0, ctx->stream,
-                       reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi, cloud->d_n, P, B);
+  hipLaunchKernelGGL(features_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi,
+                     cloud->d_n, P, B);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
   ScanDev back;
@@ -575,7 +632,7 @@ int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* pose
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
   const RegParams P = reg_params(ctx);
-  hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum);
+  hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, d_poses, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
   if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6_last, d_cov, sizeof(double) * 36, hipMemcpyDeviceToHost, ctx->stream));
@@ -589,7 +646,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   if (!o) return;
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
-                  o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar};
+                  o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar, o->d_phase_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : o->events) (void)hipEventDestroy(e);
   delete o;
@@ -626,6 +683,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_scans, SL.total * (size_t)B * o->nslots) == hipSuccess;
   ok = ok && hipMalloc(&o->d_scan_ptrs, sizeof(ScanDev*) * (size_t)B * o->nslots) == hipSuccess;
   ok = ok && hipMalloc(&o->d_scratch, WL.total * (size_t)B) == hipSuccess;
+  ok = ok && hipMemset(o->d_scratch, 0, WL.total * (size_t)B) == hipSuccess;  // dense voxel tables start all-zero
   ok = ok && hipMalloc(&o->d_scratch_hdr, sizeof(BlockScratch) * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_states, sizeof(SeqState) * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_poses_work, sizeof(double) * 3 * MAX_SCANS * (size_t)B) == hipSuccess;
@@ -672,16 +730,28 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
   OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
   OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
-  if (o->cap_points <= LDS_KEYS)
-    hipLaunchKernelGGL(odometry_step_kernel<true>, dim3(o->B), dim3(BLOCK), 0, ctx->stream, o->d_slots,
-                       ctx->d_trig, OP, o->d_states, o->d_scan_ptrs, o->d_scratch_hdr, o->d_poses_work, o->d_cov_work,
-                       o->d_summaries, o->d_poses_out);
-  else
-    hipLaunchKernelGGL(odometry_step_kernel<false>, dim3(o->B), dim3(BLOCK), 0, ctx->stream, o->d_slots,
-                       ctx->d_trig, OP, o->d_states, o->d_scan_ptrs, o->d_scratch_hdr, o->d_poses_work, o->d_cov_work,
-                       o->d_summaries, o->d_poses_out);
+  OP.phase_times = o->d_phase_times;
+  hipLaunchKernelGGL(features_step_kernel, dim3(o->B), dim3(BLOCK_F), 0, ctx->stream, o->d_slots, ctx->d_trig, OP, o->d_states,
+                     o->d_scan_ptrs, o->d_scratch_hdr);
+  hipLaunchKernelGGL(register_step_kernel, dim3(o->B), dim3(BLOCK_R), 0, ctx->stream, OP, o->d_states, o->d_scan_ptrs,
+                     o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   if (o->profile) CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
+  return CFEAR_OK;
+}
+
+// bring-up / tuning (tools/): per-sequence phase timestamps of the last step, 32 ticks of 10 ns each
+int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, long long* host_ticks /*[B][32]*/) {
+  if (!ctx || !o) return CFEAR_ERR_INVALID;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!o->d_phase_times) {
+    if (hipMalloc(&o->d_phase_times, sizeof(long long) * 32 * (size_t)o->B) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc phase times");
+    CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
+    return CFEAR_OK;
+  }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (host_ticks) CFEAR_HIP_CHECK(ctx, hipMemcpy(host_ticks, o->d_phase_times, sizeof(long long) * 32 * (size_t)o->B, hipMemcpyDeviceToHost));
+  CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
   return CFEAR_OK;
 }
 

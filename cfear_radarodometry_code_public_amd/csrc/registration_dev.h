@@ -107,39 +107,42 @@ __device__ inline void loss_eval(int loss, double a, double s, double rho[3]) {
 
 struct NormalEq { double cost, g0, g1, g2, h00, h01, h02, h11, h12, h22; };
 
-// block reduction of the 10 accumulators; result identical in every thread
-__device__ inline NormalEq block_reduce_neq(NormalEq v, double* red) {
-  double a[10] = {v.cost, v.g0, v.g1, v.g2, v.h00, v.h01, v.h02, v.h11, v.h12, v.h22};
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int i = 0; i < 10; i++) a[i] += __shfl_xor(a[i], off);
-  }
-  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();
-  if (lane_id() == 0) {
-#pragma unroll
-    for (int i = 0; i < 10; i++) red[i * 32 + w] = a[i];
-  }
-  __syncthreads();
-  double r[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) {
-    double s = 0;
-    for (int j = 0; j < nw; j++) s += red[i * 32 + j];
-    r[i] = s;
-  }
-  NormalEq o;
-  o.cost = r[0]; o.g0 = r[1]; o.g1 = r[2]; o.g2 = r[3]; o.h00 = r[4]; o.h01 = r[5]; o.h02 = r[6]; o.h11 = r[7]; o.h12 = r[8]; o.h22 = r[9];
-  return o;
-}
+struct SolveSummary { int num_iterations; int termination; double final_cost; double last_relative_decrease; };
 
-// Robustified cost, gradient and Gauss-Newton matrix over the compacted matches at x = (x, y, theta).
-// Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P); corrector = sqrt(rho').
-__device__ inline NormalEq evaluate_block(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double x2) {
-  const double c = cos(x2), s = sin(x2);
+#define CFEAR_REG_MAX_SCANS 64
+#define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
+
+enum { REG_CMD_BUILD = 1, REG_CMD_EVAL = 2, REG_CMD_DONE = 3 };
+enum { REG_ST_BUILD = 0, REG_ST_LM_IT0 = 1, REG_ST_LM_CAND = 2, REG_ST_COV = 3 };
+
+// Block-shared state of one registration (LDS). The controller fields are only touched by wave 0.
+struct RegShared {
+  // command published by the controller (wave 0) to all waves
+  int cmd, itr, M, state;
+  double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
+  double c, s;  // cos/sin of x[2], computed once by the controller
+  double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
+  double Trel[CFEAR_REG_MAX_SCANS][6];  // Ttar^-1 * Tsrc (n_scan_normal.cpp:224)
+  // ---- controller state: outer association loop (n_scan_normal.cpp:82-187)
+  int success, nres, ret, pad0;
+  double xcur[3], prev_par[3], tsrc_last[3], prev_score;
+  SolveSummary ss;
+  // ---- controller state: Levenberg-Marquardt (ceres::Solve restatement)
+  NormalEq E;
+  double x_cost, x_norm, sc0, sc1, sc2, radius, decrease_factor, dg0, dg1, dg2, xc[3], model_cost_change;
+  int reuse_diagonal, num_invalid, iteration, pad1;
+};
+
+// Robustified cost, gradient and Gauss-Newton matrix over the compacted matches at x = (x0, x1, theta)
+// with (c, s) = (cos, sin)(theta). Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P);
+// corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
+// sums in W.red[i * 32 + wave].
+__device__ inline void evaluate_partial(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
+  const int wave = threadIdx.x >> 6;
+  if (wave >= CFEAR_EVAL_WAVES) return;
+  const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+  for (int i = threadIdx.x; i < M; i += nthr) {
     const double sx = W.sx[i], sy = W.sy[i], tmx = W.tmx[i], tmy = W.tmy[i], wgt = W.w[i];
     const double px = (c * sx - s * sy) + x0;
     const double py = (s * sx + c * sy) + x1;
@@ -181,7 +184,30 @@ __device__ inline NormalEq evaluate_block(const RegScratch& W, int M, const RegP
       a.h11 += j1 * j1; a.h12 += j1 * j2; a.h22 += j2 * j2;
     }
   }
-  return block_reduce_neq(a, W.red);
+  double v[10] = {a.cost, a.g0, a.g1, a.g2, a.h00, a.h01, a.h02, a.h11, a.h12, a.h22};
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) v[i] += __shfl_xor(v[i], off);
+  }
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) W.red[i * 32 + wave] = v[i];
+  }
+}
+
+__device__ inline NormalEq gather_partials(const RegScratch& W) {
+  const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
+  double r[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    double t = 0;
+    for (int j = 0; j < nw; j++) t += W.red[i * 32 + j];
+    r[i] = t;
+  }
+  NormalEq o;
+  o.cost = r[0]; o.g0 = r[1]; o.g1 = r[2]; o.g2 = r[3]; o.h00 = r[4]; o.h01 = r[5]; o.h02 = r[6]; o.h11 = r[7]; o.h12 = r[8]; o.h22 = r[9];
+  return o;
 }
 
 __device__ inline bool chol3_solve(const double A[6], const double b[3], double y[3]) {
@@ -199,123 +225,31 @@ __device__ inline bool chol3_solve(const double A[6], const double b[3], double 
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
-struct SolveSummary { int num_iterations; int termination; double final_cost; double last_relative_decrease; };
-
-// ceres::Solve restatement: trust-region LM, Jacobi scaling, default tolerances, max_inner iterations.
-// One residual pass per LM iteration: cost, gradient and JtJ are evaluated together at the candidate
-// point (Ceres evaluates the cost first and the Jacobian after acceptance: same values).
-__device__ inline SolveSummary lm_solve_block(const RegScratch& W, int M, const RegParams& P, double x[3]) {
-  const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
-  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
-  const double max_radius = 1e16, min_radius = 1e-32;
-  SolveSummary S;
-  NormalEq E = evaluate_block(W, M, P, x[0], x[1], x[2]);
-  double x_cost = E.cost;
-  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  S.num_iterations = 1; S.final_cost = x_cost; S.last_relative_decrease = 0.0; S.termination = 1;
-  double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
-  if (gmax <= gradient_tolerance) { S.termination = 0; return S; }
-  const double sc0 = 1.0 / (1.0 + sqrt(E.h00)), sc1 = 1.0 / (1.0 + sqrt(E.h11)), sc2 = 1.0 / (1.0 + sqrt(E.h22));
-  double radius = 1e4, decrease_factor = 2.0;
-  bool reuse_diagonal = false;
-  int num_invalid = 0, iteration = 0;
-  double dg0 = 0, dg1 = 0, dg2 = 0;
-  for (;;) {
-    if (iteration >= P.max_inner) { S.termination = 1; return S; }
-    if (radius < min_radius) { S.termination = 0; return S; }
-    iteration++;
-    double Hs[6], gs[3];
-    Hs[0] = E.h00 * sc0 * sc0; Hs[1] = E.h01 * sc0 * sc1; Hs[2] = E.h02 * sc0 * sc2;
-    Hs[3] = E.h11 * sc1 * sc1; Hs[4] = E.h12 * sc1 * sc2; Hs[5] = E.h22 * sc2 * sc2;
-    gs[0] = E.g0 * sc0; gs[1] = E.g1 * sc1; gs[2] = E.g2 * sc2;
-    if (!reuse_diagonal) {
-      dg0 = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
-      dg1 = fmin(fmax(Hs[3], min_lm_diagonal), max_lm_diagonal);
-      dg2 = fmin(fmax(Hs[5], min_lm_diagonal), max_lm_diagonal);
-    }
-    const double lm0 = sqrt(dg0 / radius), lm1 = sqrt(dg1 / radius), lm2 = sqrt(dg2 / radius);
-    const double Am[6] = {Hs[0] + lm0 * lm0, Hs[1], Hs[2], Hs[3] + lm1 * lm1, Hs[4], Hs[5] + lm2 * lm2};
-    const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
-    double y[3];
-    bool valid = chol3_solve(Am, rhs, y);
-    reuse_diagonal = true;
-    double model_cost_change = 0;
-    if (valid) {
-      const double Hy0 = Hs[0] * y[0] + Hs[1] * y[1] + Hs[2] * y[2];
-      const double Hy1 = Hs[1] * y[0] + Hs[3] * y[1] + Hs[4] * y[2];
-      const double Hy2 = Hs[2] * y[0] + Hs[4] * y[1] + Hs[5] * y[2];
-      model_cost_change = -((y[0] * gs[0] + y[1] * gs[1] + y[2] * gs[2]) + 0.5 * (y[0] * Hy0 + y[1] * Hy1 + y[2] * Hy2));
-      if (!(model_cost_change > 0.0)) valid = false;
-    }
-    if (!valid) {
-      if (++num_invalid >= 5) { S.termination = 2; return S; }
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-      S.num_iterations++; S.last_relative_decrease = 0.0;
-      if (x_cost < S.final_cost) S.final_cost = x_cost;
-      continue;
-    }
-    num_invalid = 0;
-    const double xc0 = x[0] + y[0] * sc0, xc1 = x[1] + y[1] * sc1, xc2 = x[2] + y[2] * sc2;
-    const NormalEq C = evaluate_block(W, M, P, xc0, xc1, xc2);
-    const double cand_cost = C.cost;
-    const double d0 = x[0] - xc0, d1 = x[1] - xc1, d2 = x[2] - xc2;
-    const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { S.termination = 0; return S; }
-    const double cost_change = x_cost - cand_cost;
-    if (fabs(cost_change) <= function_tolerance * x_cost) { S.termination = 0; return S; }
-    const double relative_decrease = cost_change / model_cost_change;
-    S.num_iterations++;
-    S.last_relative_decrease = relative_decrease;
-    if (relative_decrease > min_relative_decrease) {
-      x[0] = xc0; x[1] = xc1; x[2] = xc2;
-      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-      E = C; x_cost = cand_cost;
-      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3.0));
-      radius = fmin(max_radius, radius);
-      decrease_factor = 2.0; reuse_diagonal = false;
-      if (x_cost < S.final_cost) S.final_cost = x_cost;
-      gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
-      if (iteration >= P.max_inner) { S.termination = 1; return S; }
-      if (gmax <= gradient_tolerance) { S.termination = 0; return S; }
-    } else {
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-      if (cand_cost < S.final_cost) S.final_cost = cand_cost;
-    }
-  }
-}
-
 // AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
-// par = n x 3 poses in LDS/global (read only here). Returns the number of matches (compacted in W).
-__device__ inline int build_problem_block(ScanDev* const* scans, int n, const double* par, const RegParams& P, int itr,
+// Transforms come precomputed from the controller (sh->Ttar, sh->Trel). All threads; returns the
+// number of matches (compacted in W, reference residual-block order).
+__device__ inline int build_problem_block(ScanDev* const* scans, int n, const RegShared* sh, const RegParams& P, int itr,
                                           const RegScratch& W) {
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
-  const Aff2 Tsrc = aff_from_xyt(par[3 * (n - 1)], par[3 * (n - 1) + 1], par[3 * (n - 1) + 2]);
   const int ipt = (pairs + blockDim.x - 1) / blockDim.x;
   const int p0 = threadIdx.x * ipt, p1 = min(pairs, p0 + ipt);
   int cnt = 0;
-  int cur_i = -1;
-  Aff2 T = aff_identity();
-  const ScanDev* tar = nullptr;
   for (int p = p0; p < p1; p++) {
     const int i = p / nsrc, j = p - i * nsrc;
-    if (i != cur_i) {
-      cur_i = i; tar = scans[i];
-      const Aff2 Ttar = aff_from_xyt(par[3 * i], par[3 * i + 1], par[3 * i + 2]);
-      T = aff_mul(aff_inv(Ttar), Tsrc);  // Tsrctotar (:224)
-    }
+    const double* T = sh->Trel[i];
     const cfear_cell* cs = &src->cells[j];
-    const double qx = (T.l0 * cs->mean[0] + T.l1 * cs->mean[1]) + T.t0;
-    const double qy = (T.l2 * cs->mean[0] + T.l3 * cs->mean[1]) + T.t1;
-    int ti = scan_closest(tar, qx, qy, curr_radius);
-    float simf = 0.f;
+    const double mx = cs->mean[0], my = cs->mean[1];
+    const double qx = (T[0] * mx + T[1] * my) + T[4];
+    const double qy = (T[2] * mx + T[3] * my) + T[5];
+    int ti = scan_closest(scans[i], qx, qy, curr_radius);
     if (ti >= 0) {
-      const cfear_cell* ct = &tar->cells[ti];
-      const double nx = T.l0 * cs->normal[0] + T.l1 * cs->normal[1];
-      const double ny = T.l2 * cs->normal[0] + T.l3 * cs->normal[1];
+      const cfear_cell* ct = &scans[i]->cells[ti];
+      const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
+      const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
       const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
       if (!(sim > angle_outlier)) ti = -1;  // :247
     }
@@ -324,29 +258,24 @@ __device__ inline int build_problem_block(ScanDev* const* scans, int n, const do
   }
   int M;
   int o = block_exclusive_scan(cnt, W.red_i, &M);
-  cur_i = -1;
-  Aff2 Ttar = aff_identity();
   for (int p = p0; p < p1; p++) {
     const int ti = W.assoc[p];
     if (ti < 0) continue;
     const int i = p / nsrc, j = p - i * nsrc;
-    if (i != cur_i) {
-      cur_i = i; tar = scans[i];
-      Ttar = aff_from_xyt(par[3 * i], par[3 * i + 1], par[3 * i + 2]);
-      T = aff_mul(aff_inv(Ttar), Tsrc);
-    }
+    const double* T = sh->Trel[i];
+    const double* Tt = sh->Ttar[i];
     const cfear_cell* cs = &src->cells[j];
-    const cfear_cell* ct = &tar->cells[ti];
-    const double nx = T.l0 * cs->normal[0] + T.l1 * cs->normal[1];
-    const double ny = T.l2 * cs->normal[0] + T.l3 * cs->normal[1];
+    const cfear_cell* ct = &scans[i]->cells[ti];
+    const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
+    const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
     const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
     W.w[o] = get_weight(P.weight_opt, (double)cs->nsamples, (double)ct->nsamples, sim, cs->scale, ct->scale);
-    W.tmx[o] = (Ttar.l0 * ct->mean[0] + Ttar.l1 * ct->mean[1]) + Ttar.t0;
-    W.tmy[o] = (Ttar.l2 * ct->mean[0] + Ttar.l3 * ct->mean[1]) + Ttar.t1;
+    W.tmx[o] = (Tt[0] * ct->mean[0] + Tt[1] * ct->mean[1]) + Tt[4];
+    W.tmy[o] = (Tt[2] * ct->mean[0] + Tt[3] * ct->mean[1]) + Tt[5];
     W.sx[o] = cs->mean[0]; W.sy[o] = cs->mean[1];
     if (P.cost == CFEAR_COST_P2D) {  // :290-299
       const double a = ct->cov[0], b = ct->cov[1], c = ct->cov[2];
-      const double r00 = Ttar.l0, r01 = Ttar.l1, r10 = Ttar.l2, r11 = Ttar.l3;
+      const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
       const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
       const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
       const double c00 = (P.regularization + (m00 * r00 + m01 * r01)) * P.covar_scale;
@@ -359,8 +288,8 @@ __device__ inline int build_problem_block(ScanDev* const* scans, int n, const do
       const double l11 = sqrt(i11 - l10 * l10);
       W.a0[o] = l00; W.a1[o] = l10; W.a2[o] = l11;
     } else {
-      W.a0[o] = Ttar.l0 * ct->normal[0] + Ttar.l1 * ct->normal[1];
-      W.a1[o] = Ttar.l2 * ct->normal[0] + Ttar.l3 * ct->normal[1];
+      W.a0[o] = Tt[0] * ct->normal[0] + Tt[1] * ct->normal[1];
+      W.a1[o] = Tt[2] * ct->normal[0] + Tt[3] * ct->normal[1];
       W.a2[o] = 0;
     }
     o++;
@@ -369,11 +298,225 @@ __device__ inline int build_problem_block(ScanDev* const* scans, int n, const do
   return M;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Controller (wave 0 only, all 64 lanes redundantly): a state machine advanced once per command.
+// Same arithmetic, in the same order, as cfo_register()/lm_solve() of the oracle.
+// ---------------------------------------------------------------------------------------------
+struct RegIo {  // where the controller reads/writes the caller-visible data
+  double* poses; double* cov6; cfear_reg_summary* out; double* par; int n;
+};
+
+__device__ inline void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
+  sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
+  sh->c = cos(x2); sh->s = sin(x2);
+  sh->cmd = REG_CMD_EVAL; sh->state = state;
+}
+
+// transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
+__device__ inline void ctl_publish_build(RegShared* sh, const RegIo& io) {
+  const int n = io.n, L = 3 * (n - 1);
+  const Aff2 Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
+  for (int i = lane_id(); i < n - 1; i += 64) {
+    const Aff2 Tt = aff_from_xyt(io.par[3 * i], io.par[3 * i + 1], io.par[3 * i + 2]);
+    const Aff2 Tr = aff_mul(aff_inv(Tt), Tsrc);  // Tsrctotar (:224)
+    double* a = sh->Ttar[i]; double* b = sh->Trel[i];
+    a[0] = Tt.l0; a[1] = Tt.l1; a[2] = Tt.l2; a[3] = Tt.l3; a[4] = Tt.t0; a[5] = Tt.t1;
+    b[0] = Tr.l0; b[1] = Tr.l1; b[2] = Tr.l2; b[3] = Tr.l3; b[4] = Tr.t0; b[5] = Tr.t1;
+  }
+  io.par[L] = sh->xcur[0]; io.par[L + 1] = sh->xcur[1]; io.par[L + 2] = sh->xcur[2];
+  sh->x[0] = sh->xcur[0]; sh->x[1] = sh->xcur[1]; sh->x[2] = sh->xcur[2];
+  sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
+}
+
+__device__ inline void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq& E) {
+  const int n = io.n, L = 3 * (n - 1);
+  int ret = 0;
+  if (lane_id() == 0) {
+    if (sh->success) {
+      for (int i = 0; i < n - 1; i++) { io.poses[3 * i] = io.par[3 * i]; io.poses[3 * i + 1] = io.par[3 * i + 1]; io.poses[3 * i + 2] = io.par[3 * i + 2]; }
+      io.poses[L] = sh->xcur[0]; io.poses[L + 1] = sh->xcur[1]; io.poses[L + 2] = sh->xcur[2];
+      // GetCovariance (:392-433): (J~^T J~)^-1 of the last built problem at the final parameters
+      const double a = E.h00, b = E.h01, c = E.h02, d = E.h11, e = E.h12, f = E.h22;
+      const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
+      const double det = a * C00 + b * C01 + c * C02;
+      const int dof = sh->nres - 3;
+      const bool ok = have_cov && det > 0 && isfinite(det) && dof != 0;
+      ret = ok ? 1 : 0;
+      if (io.cov6) {
+        for (int i = 0; i < 36; i++) io.cov6[i] = 0;
+        io.cov6[0] = 0.1 * 0.1; io.cov6[7] = 0.1 * 0.1; io.cov6[35] = 0.01 * 0.01;  // :173
+        if (ok) {
+          const double sc = 30 * (sh->ss.final_cost / dof) / det;
+          for (int i = 0; i < 36; i++) io.cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+          io.cov6[0] = sc * C00; io.cov6[1] = sc * C01; io.cov6[6] = sc * C01; io.cov6[7] = sc * (a * f - c * c);
+          io.cov6[35] = sc * (a * d - b * b); io.cov6[5] = sc * C02; io.cov6[30] = sc * C02;  // (1,5)/(5,1) stay 0 (:426-430)
+        }
+      }
+    } else {
+      io.poses[L] = sh->tsrc_last[0]; io.poses[L + 1] = sh->tsrc_last[1]; io.poses[L + 2] = sh->tsrc_last[2];
+    }
+    if (io.out) {
+      io.out->success = ret; io.out->usable = sh->success ? 1 : 0; io.out->outer_iterations = sh->itr;
+      io.out->num_residuals = sh->nres; io.out->num_residual_blocks = sh->M; io.out->final_cost = sh->ss.final_cost;
+      io.out->score = sh->success ? sh->ss.final_cost / sh->nres : 0.0;
+    }
+    sh->ret = ret;
+  }
+  sh->cmd = REG_CMD_DONE;
+}
+
+// end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
+__device__ inline void ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
+  const int itr = sh->itr;
+  sh->success = (sh->ss.termination != 2);
+  if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
+  if (lane_id() == 0 && io.out && itr - 1 < CFEAR_MAX_OUTER) {
+    io.out->inner_iterations[itr - 1] = sh->ss.num_iterations; io.out->termination[itr - 1] = sh->ss.termination;
+    io.out->outer_cost[itr - 1] = sh->ss.final_cost;
+    io.out->outer_pose[itr - 1][0] = sh->xcur[0]; io.out->outer_pose[itr - 1][1] = sh->xcur[1]; io.out->outer_pose[itr - 1][2] = sh->xcur[2];
+  }
+  const double current_score = sh->ss.final_cost;
+  const double rel_improvement = (sh->prev_score - current_score) / sh->prev_score;
+  bool brk = false;
+  if (itr > P.min_itr) {  // :134-149
+    if (sh->prev_score < current_score) { sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; brk = true; }
+    else if (rel_improvement < 0.00001) brk = true;
+    else if (sh->ss.last_relative_decrease < 0.00001 || sh->ss.num_iterations == 1) brk = true;
+  }
+  if (!brk) {
+    sh->prev_score = current_score;
+    sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
+    sh->itr = itr + 1;  // for-loop increment (:102)
+    if (sh->itr <= P.max_outer && sh->success) { ctl_publish_build(sh, io); return; }
+  }
+  // loop left: covariance pass on the last built problem if the solution is usable (:164-183)
+  if (sh->success) ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV);
+  else { NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; ctl_finish(sh, io, P, false, z); }
+}
+
+// trust-region step(s) until a candidate needs evaluating or the solve ends
+__device__ inline void ctl_lm_next(RegShared* sh, const RegIo& io, const RegParams& P) {
+  const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
+  for (;;) {
+    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
+    if (sh->radius < min_radius) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+    sh->iteration++;
+    const NormalEq E = sh->E;
+    const double sc0 = sh->sc0, sc1 = sh->sc1, sc2 = sh->sc2;
+    double Hs[6], gs[3];
+    Hs[0] = E.h00 * sc0 * sc0; Hs[1] = E.h01 * sc0 * sc1; Hs[2] = E.h02 * sc0 * sc2;
+    Hs[3] = E.h11 * sc1 * sc1; Hs[4] = E.h12 * sc1 * sc2; Hs[5] = E.h22 * sc2 * sc2;
+    gs[0] = E.g0 * sc0; gs[1] = E.g1 * sc1; gs[2] = E.g2 * sc2;
+    if (!sh->reuse_diagonal) {
+      sh->dg0 = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
+      sh->dg1 = fmin(fmax(Hs[3], min_lm_diagonal), max_lm_diagonal);
+      sh->dg2 = fmin(fmax(Hs[5], min_lm_diagonal), max_lm_diagonal);
+    }
+    const double lm0 = sqrt(sh->dg0 / sh->radius), lm1 = sqrt(sh->dg1 / sh->radius), lm2 = sqrt(sh->dg2 / sh->radius);
+    const double Am[6] = {Hs[0] + lm0 * lm0, Hs[1], Hs[2], Hs[3] + lm1 * lm1, Hs[4], Hs[5] + lm2 * lm2};
+    const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
+    double y[3];
+    bool valid = chol3_solve(Am, rhs, y);
+    sh->reuse_diagonal = 1;
+    double mcc = 0;
+    if (valid) {
+      const double Hy0 = Hs[0] * y[0] + Hs[1] * y[1] + Hs[2] * y[2];
+      const double Hy1 = Hs[1] * y[0] + Hs[3] * y[1] + Hs[4] * y[2];
+      const double Hy2 = Hs[2] * y[0] + Hs[4] * y[1] + Hs[5] * y[2];
+      mcc = -((y[0] * gs[0] + y[1] * gs[1] + y[2] * gs[2]) + 0.5 * (y[0] * Hy0 + y[1] * Hy1 + y[2] * Hy2));
+      if (!(mcc > 0.0)) valid = false;
+    }
+    if (!valid) {  // HandleInvalidStep
+      if (++sh->num_invalid >= 5) { sh->ss.termination = 2; ctl_lm_done(sh, io, P); return; }
+      sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
+      sh->ss.num_iterations++; sh->ss.last_relative_decrease = 0.0;
+      if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
+      continue;
+    }
+    sh->num_invalid = 0;
+    sh->model_cost_change = mcc;
+    sh->xc[0] = sh->xcur[0] + y[0] * sc0; sh->xc[1] = sh->xcur[1] + y[1] * sc1; sh->xc[2] = sh->xcur[2] + y[2] * sc2;
+    ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND);
+    return;
+  }
+}
+
+// consumes the result of the command just executed and publishes the next one
+__device__ inline void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+  const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double max_radius = 1e16;
+  const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
+  switch (sh->state) {
+    case REG_ST_BUILD: {
+      sh->nres = sh->M * rpb;
+      if (sh->nres <= 1) {  // :370-371 -> :114-115
+        sh->success = 0;
+        NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        ctl_finish(sh, io, P, false, z);
+        return;
+      }
+      ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
+      return;
+    }
+    case REG_ST_LM_IT0: {
+      const NormalEq E = gather_partials(W);
+      sh->E = E; sh->x_cost = E.cost;
+      sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+      sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
+      const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
+      if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+      sh->sc0 = 1.0 / (1.0 + sqrt(E.h00)); sh->sc1 = 1.0 / (1.0 + sqrt(E.h11)); sh->sc2 = 1.0 / (1.0 + sqrt(E.h22));
+      sh->radius = 1e4; sh->decrease_factor = 2.0; sh->reuse_diagonal = 0; sh->num_invalid = 0; sh->iteration = 0;
+      sh->dg0 = sh->dg1 = sh->dg2 = 0;
+      ctl_lm_next(sh, io, P);
+      return;
+    }
+    case REG_ST_LM_CAND: {
+      const NormalEq C = gather_partials(W);
+      const double cand_cost = C.cost;
+      const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
+      const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+      const double cost_change = sh->x_cost - cand_cost;
+      if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+      const double relative_decrease = cost_change / sh->model_cost_change;
+      sh->ss.num_iterations++;
+      sh->ss.last_relative_decrease = relative_decrease;
+      if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
+        sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
+        sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+        sh->E = C; sh->x_cost = cand_cost;
+        const double t = 2.0 * relative_decrease - 1.0;
+        sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        sh->radius = fmin(max_radius, sh->radius);
+        sh->decrease_factor = 2.0; sh->reuse_diagonal = 0;
+        if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
+        const double gmax = fmax(fabs(C.g0), fmax(fabs(C.g1), fabs(C.g2)));
+        if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
+        if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+      } else {  // HandleUnsuccessfulStep
+        sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
+        if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
+      }
+      ctl_lm_next(sh, io, P);
+      return;
+    }
+    default: {  // REG_ST_COV
+      const NormalEq E = gather_partials(W);
+      ctl_finish(sh, io, P, true, E);
+      return;
+    }
+  }
+}
+
 // n_scan_normal_reg::Register. poses: n x 3 in global memory (in/out); cov6: 36 doubles or null;
-// out: summary in global memory. par_lds: >= 3*n doubles of LDS.
+// out: summary in global memory. par_lds: >= 3*n doubles of LDS; sh: RegShared in LDS.
+// Wave 0 is the controller; every wave executes the published commands (two barriers per command).
 __device__ inline int register_block(ScanDev* const* scans, int n, double* poses, double* cov6, const RegParams& P,
-                                     const RegScratch& W, double* par_lds, cfear_reg_summary* out) {
+                                     const RegScratch& W, double* par_lds, RegShared* sh, cfear_reg_summary* out,
+                                     PhaseTimer* pt = nullptr) {
   const int tid = threadIdx.x;
+  const bool master = (tid >> 6) == 0;
   // Affine3dToVectorXYeZ(Tsrc[i]) (:88-92): theta -> atan2(sin, cos)
   for (int i = tid; i < n; i += blockDim.x) {
     const Aff2 T = aff_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
@@ -386,74 +529,33 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     for (int i = 0; i < CFEAR_MAX_OUTER; i++) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
   }
   __syncthreads();
-  const int L = 3 * (n - 1);
-  double x[3] = {par_lds[L], par_lds[L + 1], par_lds[L + 2]};
-  double tsrc_last[3] = {poses[L], poses[L + 1], poses[L + 2]};
-  bool success = true;
-  double prev_par[3] = {x[0], x[1], x[2]};
-  double prev_score = 1.7976931348623157e308;
-  const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
-  int M = 0, nres = 0;
-  SolveSummary ss; ss.num_iterations = 0; ss.termination = 0; ss.final_cost = 0; ss.last_relative_decrease = 0;
-  int itr;
-  for (itr = 1; itr <= P.max_outer && success; itr++) {  // :102
-    __syncthreads();
-    if (tid == 0) { par_lds[L] = x[0]; par_lds[L + 1] = x[1]; par_lds[L + 2] = x[2]; }
-    __syncthreads();
-    M = build_problem_block(scans, n, par_lds, P, itr, W);
-    nres = M * rpb;
-    if (nres <= 1) { success = false; break; }  // :370-371
-    ss = lm_solve_block(W, M, P, x);
-    success = (ss.termination != 2);
-    if (success) { tsrc_last[0] = x[0]; tsrc_last[1] = x[1]; tsrc_last[2] = x[2]; }
-    if (tid == 0 && out && itr - 1 < CFEAR_MAX_OUTER) {
-      out->inner_iterations[itr - 1] = ss.num_iterations; out->termination[itr - 1] = ss.termination;
-      out->outer_cost[itr - 1] = ss.final_cost;
-      out->outer_pose[itr - 1][0] = x[0]; out->outer_pose[itr - 1][1] = x[1]; out->outer_pose[itr - 1][2] = x[2];
-    }
-    const double current_score = ss.final_cost;
-    const double rel_improvement = (prev_score - current_score) / prev_score;
-    if (itr > P.min_itr) {  // :134-149
-      if (prev_score < current_score) { x[0] = prev_par[0]; x[1] = prev_par[1]; x[2] = prev_par[2]; break; }
-      else if (rel_improvement < 0.00001) break;
-      else if (ss.last_relative_decrease < 0.00001 || ss.num_iterations == 1) break;
-    }
-    prev_score = current_score;
-    prev_par[0] = x[0]; prev_par[1] = x[1]; prev_par[2] = x[2];
+  RegIo io; io.poses = poses; io.cov6 = cov6; io.out = out; io.par = par_lds; io.n = n;
+  if (master) {
+    const int L = 3 * (n - 1);
+    sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
+    sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
+    sh->tsrc_last[0] = poses[L]; sh->tsrc_last[1] = poses[L + 1]; sh->tsrc_last[2] = poses[L + 2];
+    sh->prev_score = 1.7976931348623157e308;
+    sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1;
+    sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
+    ctl_publish_build(sh, io);
   }
-  int ret = 0;
-  if (success) {
-    // GetCovariance (:392-433): (J~^T J~)^-1 of the last built problem at the final parameters
-    const NormalEq E = evaluate_block(W, M, P, x[0], x[1], x[2]);
-    const double a = E.h00, b = E.h01, c = E.h02, d = E.h11, e = E.h12, f = E.h22;
-    const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
-    const double det = a * C00 + b * C01 + c * C02;
-    const int dof = nres - 3;
-    const bool ok = det > 0 && isfinite(det) && dof != 0;
-    ret = ok ? 1 : 0;
-    __syncthreads();
-    if (tid == 0) {
-      for (int i = 0; i < n; i++) { poses[3 * i] = par_lds[3 * i]; poses[3 * i + 1] = par_lds[3 * i + 1]; poses[3 * i + 2] = par_lds[3 * i + 2]; }
-      poses[L] = x[0]; poses[L + 1] = x[1]; poses[L + 2] = x[2];
-      if (cov6) {
-        for (int i = 0; i < 36; i++) cov6[i] = 0;
-        cov6[0] = 0.1 * 0.1; cov6[7] = 0.1 * 0.1; cov6[35] = 0.01 * 0.01;  // :173
-        if (ok) {
-          const double sc = 30 * (ss.final_cost / dof) / det;
-          for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-          cov6[0] = sc * C00; cov6[1] = sc * C01; cov6[6] = sc * C01; cov6[7] = sc * (a * f - c * c);
-          cov6[35] = sc * (a * d - b * b); cov6[5] = sc * C02; cov6[30] = sc * C02;  // (1,5)/(5,1) stay 0 (:426-430)
-        }
-      }
+  for (;;) {
+    __syncthreads();  // command visible to every wave
+    const int cmd = sh->cmd;
+    if (cmd == REG_CMD_DONE) break;
+    if (cmd == REG_CMD_BUILD) {
+      if (pt) pt->mark();
+      const int M = build_problem_block(scans, n, sh, P, sh->itr, W);
+      if (tid == 0) sh->M = M;
+      if (pt) pt->mark();
+    } else {
+      evaluate_partial(W, sh->M, P, sh->x[0], sh->x[1], sh->c, sh->s);
     }
-  } else if (tid == 0) {
-    poses[L] = tsrc_last[0]; poses[L + 1] = tsrc_last[1]; poses[L + 2] = tsrc_last[2];
+    __syncthreads();  // results visible to the controller
+    if (master) ctl_step(sh, io, P, W);
   }
-  if (tid == 0 && out) {
-    out->success = ret; out->usable = success ? 1 : 0; out->outer_iterations = itr;
-    out->num_residuals = nres; out->num_residual_blocks = M; out->final_cost = ss.final_cost;
-    out->score = success ? ss.final_cost / nres : 0.0;
-  }
+  const int ret = sh->ret;
   __syncthreads();
   return ret;
 }

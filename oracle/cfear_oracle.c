@@ -711,7 +711,8 @@ static solve_summary lm_solve(const problem_t* P, double x[3], int max_iteration
       x[0] = xc[0]; x[1] = xc[1]; x[2] = xc[2];
       x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
       x_cost = evaluate(P, x, g, H);
-      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * relative_decrease - 1.0, 3));
+      { const double tq = 2.0 * relative_decrease - 1.0; /* [3P] Ceres: pow(2q-1, 3) */
+        radius = radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq); }
       radius = fmin(max_radius, radius);
       decrease_factor = 2.0; reuse_diagonal = 0;
       if (x_cost < S.final_cost) S.final_cost = x_cost;
