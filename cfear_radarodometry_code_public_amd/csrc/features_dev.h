@@ -25,6 +25,7 @@ struct ScanDev {
   float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
   int* gstart;        // [cap_grid + 1]
   int* gorder;        // [cap_cells] cell indices bucketed by grid cell
+  float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
 };
 
 struct FeatureParams {
@@ -378,6 +379,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
     S->gorder[pos] = i;
+    S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
   __syncthreads();
@@ -388,23 +390,41 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
 // Exact-distance ties resolve to the lowest cell index (same rule as the oracle).
 __device__ inline int scan_closest(const ScanDev* __restrict__ S, double px, double py, double d) {
   const float qx = (float)px, qy = (float)py;
-  if (S->n_cells <= 0 || S->gw <= 0) return -1;
+  const int gw = S->gw, gh = S->gh;
+  if (S->n_cells <= 0 || gw <= 0) return -1;
   const double m = d * (1.0 + 1e-6) + 1e-6;
-  const double gc = (double)S->gcell;
-  int gx0 = (int)floor(((double)qx - m - (double)S->gminx) / gc), gx1 = (int)floor(((double)qx + m - (double)S->gminx) / gc);
-  int gy0 = (int)floor(((double)qy - m - (double)S->gminy) / gc), gy1 = (int)floor(((double)qy + m - (double)S->gminy) / gc);
+  const double gc = (double)S->gcell, gmx = (double)S->gminx, gmy = (double)S->gminy;
+  int gx0 = (int)floor(((double)qx - m - gmx) / gc), gx1 = (int)floor(((double)qx + m - gmx) / gc);
+  int gy0 = (int)floor(((double)qy - m - gmy) / gc), gy1 = (int)floor(((double)qy + m - gmy) / gc);
   // the builder clamps bucket coordinates, so clamp the query window the same way
-  gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, S->gw - 1); gy1 = min(gy1, S->gh - 1);
+  gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
+  if (gx0 > gx1 || gy0 > gy1) return -1;
+  const int* __restrict__ gs = S->gstart;
+  const float4* __restrict__ gp = S->gpts;
   int best = -1;
   float bd = 3.4e38f;
-  for (int gy = gy0; gy <= gy1; gy++) {
-    if (gx0 > gx1) break;
-    const int a = S->gstart[gy * S->gw + gx0], b = S->gstart[gy * S->gw + gx1 + 1];
-    for (int q = a; q < b; q++) {
-      const int i = S->gorder[q];
-      const float dx = qx - S->mean_f[2 * i], dy = qy - S->mean_f[2 * i + 1];
-      float d2 = dx * dx; d2 += dy * dy;
-      if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+  for (int gy = gy0; gy <= gy1; gy += 3) {  // three rows at a time: all six bucket bounds in flight together
+    int ra[3], rb[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int row = min(gy + r, gy1);
+      ra[r] = gs[row * gw + gx0]; rb[r] = gs[row * gw + gx1 + 1];
+      if (gy + r > gy1) rb[r] = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      for (int q = ra[r]; q < rb[r]; q += 4) {
+        float4 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c[u] = gp[min(q + u, rb[r] - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float dx = qx - c[u].x, dy = qy - c[u].y;
+          float d2 = dx * dx; d2 += dy * dy;
+          const int i = __float_as_int(c[u].z);
+          if (q + u < rb[r] && (d2 < bd || (d2 == bd && i < best))) { bd = d2; best = i; }
+        }
+      }
     }
   }
   if (best >= 0 && (double)bd < d * d) return best;

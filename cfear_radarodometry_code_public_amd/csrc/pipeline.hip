@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   features_dispatch(cur, n, OP.fp, B, lds, &pt);  // :161
 }
 
-__global__ __launch_bounds__(BLOCK_R) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+__global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
@@ -291,7 +291,7 @@ RegParams reg_params(const cfear_ctx* ctx) {
 
 constexpr int GRID_CAP = 128 * 128;
 
-struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, total; };
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, gpts, total; };
 ScanLayout scan_layout(int cap_points) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
@@ -300,6 +300,7 @@ ScanLayout scan_layout(int cap_points) {
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
   L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
   L.gorder = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
+  L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
   L.total = o;
   return L;
 }
@@ -315,6 +316,7 @@ ScanDev scan_header(unsigned char* d_base, int cap_points) {
   h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
   h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
   h.gorder = reinterpret_cast<int*>(d_base + L.gorder);
+  h.gpts = reinterpret_cast<float4*>(d_base + L.gpts);
   h.gcell = 1.f;
   return h;
 }

@@ -137,7 +137,7 @@ struct RegShared {
 // with (c, s) = (cos, sin)(theta). Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P);
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
-__device__ inline void evaluate_partial(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
+__device__ __noinline__ void evaluate_partial(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
   const int wave = threadIdx.x >> 6;
   if (wave >= CFEAR_EVAL_WAVES) return;
   const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
@@ -228,7 +228,7 @@ __device__ inline bool chol3_solve(const double A[6], const double b[3], double 
 // AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
 // Transforms come precomputed from the controller (sh->Ttar, sh->Trel). All threads; returns the
 // number of matches (compacted in W, reference residual-block order).
-__device__ inline int build_problem_block(ScanDev* const* scans, int n, const RegShared* sh, const RegParams& P, int itr,
+__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, const RegShared* sh, const RegParams& P, int itr,
                                           const RegScratch& W) {
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
@@ -442,7 +442,7 @@ __device__ inline void ctl_lm_next(RegShared* sh, const RegIo& io, const RegPara
 }
 
 // consumes the result of the command just executed and publishes the next one
-__device__ inline void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
   const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
