@@ -300,7 +300,7 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, co
 
 // ---------------------------------------------------------------------------------------------
 // Controller (wave 0 only, all 64 lanes redundantly): a state machine advanced once per command.
-// Same arithmetic, in the same order, as cfo_register()/lm_solve() of the oracle.
+// Same arithmetic, in the same order, as the CPU oracle's register / LM routines (tests compare iteration counts).
 // ---------------------------------------------------------------------------------------------
 struct RegIo {  // where the controller reads/writes the caller-visible data
   double* poses; double* cov6; cfear_reg_summary* out; double* par; int n;
