@@ -138,6 +138,13 @@ def main():
     if rank == 0:
         filt = t_filter / max(nprof, 1)
         achieved = ALGO_BYTES_PER_SCAN * B / filt / 1e9
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_k1_traffic.json")
+        if os.path.exists(tj):  # PMC measurement (separate rocprofv3 --pmc passes), scaled to this launch size
+            with open(tj) as fh:
+                tr = json.load(fh)
+            traffic = tr["hbm_bytes_per_scan"] * B
+            traffic_src = "profiles/r01_k1_traffic.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, %d-scan launches" % tr["scans_per_launch"]
         out = {
             "metric": "radar scans/s (filter+feat+4-keyframe reg), 400x3360 polar",
             "value": total_scans / total_time,
@@ -156,7 +163,7 @@ def main():
                        "sequences_per_gpu": B, "sweeps_per_step": B * world, "unique_sequences_per_gpu": args.unique,
                        "parallelism": "independent sequences per GPU; per sweep: 1 wavefront per azimuth row (filter), 1 workgroup per sequence (features, registration)"},
             "roofline": {"bound": "hbm", "kernel": "kstrongest_kernel<4,8>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": ALGO_BYTES_PER_SCAN * B, "avg_launch_us": filt * 1e6},
             "kernels": {"kstrongest_us": filt * 1e6, "features+registration_us": 1e6 * t_odo / max(nprof, 1)},
             "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,

@@ -1,0 +1,99 @@
+// offline_odometry.cpp -- ROS-free counterpart of the reference's src/offline_odometry.cpp main loop
+// (:73-127): replays raw polar sweeps at maximum rate through radarDriver::CallbackOffline and
+// OdometryKeyframeFuser::pointcloudCallback (both running on the MI355X through the C ABI) and
+// writes the estimated trajectory in KITTI format (one 3x4 row-major matrix per line, fixed 6
+// decimals, as EvalTrajectory / types.cpp:64-73 do).
+//
+// Input: a flat binary file of uint8 sweeps, frames x azimuths x range-bins, rows = azimuth
+// (radar_driver.cpp:92-98). Flags follow offline_odometry.cpp:152-193 where they exist there.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "cfear_host.hpp"
+
+using namespace CFEAR_Radarodometry;
+
+static const char* arg(int argc, char** argv, const char* name, const char* def) {
+  for (int i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], name)) return argv[i + 1];
+  return def;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2 || !strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) {
+    printf("usage: offline_odometry --frames sweeps.u8 [--azimuths 400] [--bins 3360] [--range-res 0.0438] [--res 3.5]\n"
+           "       [--min_distance 2.5] [--submap_scan_size 3] [--weight_intensity 1] [--k_strongest 12] [--z-min 65]\n"
+           "       [--radar_ccw 0] [--disable_compensate 0] [--cost_type P2L] [--loss_type Huber] [--loss_limit 0.1]\n"
+           "       [--covar_scale 1] [--regularization 1] [--weight_option 0] [--registered_min_keyframe_dist 1.5]\n"
+           "       [--est_directory .] [--device 0]\n");
+    return argc < 2;
+  }
+  const std::string frames = arg(argc, argv, "--frames", "");
+  const int A = atoi(arg(argc, argv, "--azimuths", "400")), R = atoi(arg(argc, argv, "--bins", "3360"));
+  // defaults of offline_odometry.cpp:155-187
+  radarDriver::Parameters rad_par;
+  rad_par.range_res = (float)atof(arg(argc, argv, "--range-res", "0.0438"));
+  rad_par.min_distance = (float)atof(arg(argc, argv, "--min_distance", "2.5"));
+  rad_par.k_strongest = atoi(arg(argc, argv, "--k_strongest", "12"));
+  rad_par.z_min = (float)atof(arg(argc, argv, "--z-min", "65"));
+  rad_par.azimuths = A;
+  OdometryKeyframeFuser::Parameters par;
+  par.res = atof(arg(argc, argv, "--res", "3.5"));
+  par.submap_scan_size = atoi(arg(argc, argv, "--submap_scan_size", "3"));
+  par.weight_intensity_ = atoi(arg(argc, argv, "--weight_intensity", "1")) != 0;
+  par.radar_ccw = atoi(arg(argc, argv, "--radar_ccw", "0")) != 0;
+  par.compensate = atoi(arg(argc, argv, "--disable_compensate", "0")) == 0;
+  par.cost_type = arg(argc, argv, "--cost_type", "P2L");
+  par.loss_type_ = arg(argc, argv, "--loss_type", "Huber");
+  par.loss_limit_ = atof(arg(argc, argv, "--loss_limit", "0.1"));
+  par.covar_scale_ = atof(arg(argc, argv, "--covar_scale", "1"));
+  par.regularization_ = atof(arg(argc, argv, "--regularization", "1"));
+  par.weight_opt = static_cast<weightoption>(atoi(arg(argc, argv, "--weight_option", "0")));
+  par.min_keyframe_dist_ = atof(arg(argc, argv, "--registered_min_keyframe_dist", "1.5"));
+  par.use_guess = true;  // forced at offline_odometry.cpp:273
+  const std::string est_dir = arg(argc, argv, "--est_directory", ".");
+
+  std::ifstream in(frames, std::ios::binary);
+  if (!in) { std::cerr << "cannot open " << frames << std::endl; return 2; }
+  cfear_params p; cfear_default_params(&p);
+  p.submap_scan_size = par.submap_scan_size;
+  try {
+    DevicePtr dev(new Device(p, A, R, atoi(arg(argc, argv, "--device", "0"))));
+    radarDriver driver(dev, rad_par, true);
+    OdometryKeyframeFuser fuser(dev, par, true);
+    std::vector<uint8_t> img((size_t)A * R);
+    std::ofstream est(est_dir + "/est_00.txt");
+    est << std::fixed; est.precision(6);
+    int n = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    while (in.read(reinterpret_cast<char*>(img.data()), (std::streamsize)img.size())) {
+      const auto t0 = std::chrono::steady_clock::now();
+      PolarImage pi; pi.rows = A; pi.cols = R; pi.data = img.data(); pi.stamp = (uint64_t)n;
+      CloudPtr cloud, cloud_peaks;
+      driver.CallbackOffline(pi, cloud, cloud_peaks);                     // offline_odometry.cpp:103
+      const auto t1 = std::chrono::steady_clock::now();
+      CFEAR_TIMING.Document("Filtering", std::chrono::duration<double, std::milli>(t1 - t0).count());  // radar_driver.cpp:111
+      CFEAR_TIMING.Document("Filtered points", (double)cloud->size());    // :104
+      Affine3d Tcurrent;
+      fuser.pointcloudCallback(cloud, cloud_peaks, Tcurrent, pi.stamp);   // :108
+      const auto t2 = std::chrono::steady_clock::now();
+      CFEAR_TIMING.Document("Registration", std::chrono::duration<double, std::milli>(t2 - t1).count());  // odometrykeyframefuser.cpp:404
+      est << Tcurrent.l[0][0] << " " << Tcurrent.l[0][1] << " 0.000000 " << Tcurrent.t[0] << " "
+          << Tcurrent.l[1][0] << " " << Tcurrent.l[1][1] << " 0.000000 " << Tcurrent.t[1] << " "
+          << "0.000000 0.000000 1.000000 0.000000\n";
+      n++;
+      const double tot = std::chrono::duration<double>(t2 - t_start).count();
+      if (n % 10 == 0) std::cout << "Frame: " << n << ", dur: " << std::chrono::duration<double>(t2 - t0).count() << ", avg: " << n / tot << " Hz" << std::endl;  // :125
+    }
+    std::cout << "frames " << n << "\n" << CFEAR_TIMING.GetStatistics();
+  } catch (const std::exception& e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return 3;
+  }
+  return 0;
+}
