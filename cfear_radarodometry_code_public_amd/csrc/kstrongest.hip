@@ -188,8 +188,6 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: keeps all per-row bookkeeping on the SALU
   uint8_t* const win = reinterpret_cast<uint8_t*>(&lds_win[wave][0]);
   uint32_t* const keys = &lds_keys[wave][0];
-  const uintptr_t base = reinterpret_cast<uintptr_t>(polar);
-  const uintptr_t alloc_end = base + (uintptr_t)alloc_bytes;
   const long long scan_bytes = (long long)A * (long long)R;
   const int Tfloor = u_zmin > 1 ? u_zmin : 1;
 
@@ -204,43 +202,44 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   int bearing = (int)(g0 - scan * A);
   for (long long g = g0; g < g1; g++, bearing++) {
     if (bearing == A) { bearing = 0; scan++; }
-    const uintptr_t row_addr = base + (uintptr_t)(g * (long long)R);
-    const uintptr_t wstart = (row_addr - 6) & ~(uintptr_t)15;
-    const int head = (int)(row_addr - wstart);  // 6..21: window offset of range bin 0
+    // all addressing relative to the (16-byte aligned) kernel argument so that the loads are
+    // global_load_dwordx4 with a scalar base and a 32-bit lane offset
+    const long long row_off = g * (long long)R;
+    const long long wstart_off = (row_off - 6) & ~15LL;     // may be -16 for the very first row
+    const int head = (int)(row_off - wstart_off);           // 6..21: window offset of range bin 0
     // chunks [c_lo, c_hi) are inside the allocation and needed (row + 6-byte halo either side)
-    const int c_lo = wstart >= base ? 0 : (int)((base - wstart + 15) >> 4);
+    const int c_lo = wstart_off >= 0 ? 0 : (int)((-wstart_off + 15) >> 4);
     int c_hi = (head + R + 6 + 15) >> 4;
     {
-      const long long lim = ((long long)alloc_end - (long long)wstart + 15) >> 4;
+      const long long lim = (alloc_bytes - wstart_off + 15) >> 4;
       if (lim < c_hi) c_hi = (int)lim;
     }
     const bool edge_row = bearing == 0 || bearing == A - 1;
-    const uint8_t* const wp = reinterpret_cast<const uint8_t*>(wstart);  // wave-uniform base, 32-bit lane offsets
+    const uint8_t* const wp = polar + wstart_off;  // wave-uniform
 
-    // ---- load: HBM -> VGPR (row-masked) and LDS (scan-masked, keeps the cross-row halo) ----
+    // ---- load: HBM -> VGPR and LDS (scan-masked on the first/last row, keeps the cross-row halo).
+    // Branch-free: out-of-range chunks read a clamped (valid) address and are zeroed afterwards, so
+    // the NCH loads of 1 KiB each are all in flight together.
     uint4 v[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       const int c = j * 64 + lane;
-      const uint32_t boff = (uint32_t)(16 * c);
-      uint4 raw;
-      if (j * 64 >= c_lo && j * 64 + 64 <= c_hi) {  // whole 1 KiB inside: unpredicated load
-        raw = *reinterpret_cast<const uint4*>(wp + boff);
-      } else {
-        raw = make_uint4(0, 0, 0, 0);
-        if (c >= c_lo && c < c_hi) raw = *reinterpret_cast<const uint4*>(wp + boff);
-      }
-      uint4 staged = raw;
+      const int cc = min(max(c, c_lo), c_hi - 1);
+      v[j] = *reinterpret_cast<const uint4*>(wp + (uint32_t)(16 * cc));
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      const int c = j * 64 + lane;
+      if (c < c_lo || c >= c_hi) v[j] = make_uint4(0, 0, 0, 0);
+      uint4 staged = v[j];
       if (edge_row) {
         // bytes outside this scan's image read as 0 (the reference's unchecked cv::Mat::at would run
         // off the buffer there, radar_filters.cpp:260)
-        const uintptr_t scan_lo = base + (uintptr_t)(scan * scan_bytes);
-        const long long ca = (long long)(wstart + (uintptr_t)boff);
-        const long long slo = (long long)scan_lo - ca, shi = (long long)scan_lo + scan_bytes - ca;
-        if (slo > 0 || shi < 16) staged = chunk_keep(raw, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
+        const long long ca = wstart_off + 16LL * c;
+        const long long slo = scan * scan_bytes - ca, shi = (scan + 1) * scan_bytes - ca;
+        if (slo > 0 || shi < 16) staged = chunk_keep(staged, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
       }
       reinterpret_cast<uint4*>(win)[c] = staged;
-      v[j] = raw;  // bytes outside the row are excluded through the candidate masks (vhead / vtail)
     }
     // validity of the chunk bytes w.r.t. the row [0, R): only the first chunk group and the group(s)
     // holding the row end can be partial
