@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 }  // namespace
 
 // bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 grid oversubscription
-static int g_k1_dbg = 0, g_k1_occ = 8, g_k1_oversub = 2;
+static int g_k1_dbg = 0, g_k1_occ = 8, g_k1_oversub = 4;
 extern "C" void cfear_debug_set(int key, int value) {
   if (key == 0) g_k1_dbg = value;
   if (key == 1) g_k1_occ = value;
