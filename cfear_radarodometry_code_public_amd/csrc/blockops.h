@@ -86,6 +86,51 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
   return base + inc - v;
 }
 
+// Exclusive prefix sum of one 64-bit value per thread (e.g. four 16-bit counters packed side by side);
+// *total = block sum. scratch: >= 32 unsigned long long in LDS.
+__device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long* scratch,
+                                                                      unsigned long long* total) {
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) scratch[w] = inc;
+  __syncthreads();
+  unsigned long long base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) {
+    const unsigned long long s = scratch[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---- wave64 sum of a double with DPP moves (no LDS round trips); the total is returned in every lane ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+  return v + __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror: every lane holds its 16-lane row sum
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3: lanes 48..63 hold the wave total
+  const unsigned long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // In-place ascending bitonic sort of keys[0..p2) (p2 = power of two, padded by the caller).
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int p2) {
   for (int k = 2; k <= p2; k <<= 1) {

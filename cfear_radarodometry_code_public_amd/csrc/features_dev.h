@@ -431,4 +431,58 @@ __device__ inline int scan_closest(const ScanDev* __restrict__ S, double px, dou
   return -1;
 }
 
+// GetClosestIdx of up to four targets at once (one query point each): the bucket bounds of all targets
+// are fetched together, then the candidates; same result as four scan_closest() calls.
+__device__ inline void scan_closest4(const ScanDev* const* S, int nt, const double* qxs, const double* qys, double d, int* out) {
+  int ra[4][3], rb[4][3];
+  float qx[4], qy[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    out[u] = -1;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { ra[u][r] = 0; rb[u][r] = 0; }
+    if (u >= nt) continue;
+    const ScanDev* s = S[u];
+    qx[u] = (float)qxs[u]; qy[u] = (float)qys[u];
+    const int gw = s->gw, gh = s->gh;
+    if (s->n_cells <= 0 || gw <= 0) continue;
+    const double m = d * (1.0 + 1e-6) + 1e-6;
+    const double gc = (double)s->gcell, gmx = (double)s->gminx, gmy = (double)s->gminy;
+    int gx0 = (int)floor(((double)qx[u] - m - gmx) / gc), gx1 = (int)floor(((double)qx[u] + m - gmx) / gc);
+    int gy0 = (int)floor(((double)qy[u] - m - gmy) / gc), gy1 = (int)floor(((double)qy[u] + m - gmy) / gc);
+    gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
+    if (gx0 > gx1 || gy0 > gy1) continue;
+    if (gy1 - gy0 > 2) { out[u] = -2; continue; }  // window taller than three buckets: generic path below
+    const int* __restrict__ gs = s->gstart;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (gy0 + r <= gy1) { ra[u][r] = gs[(gy0 + r) * gw + gx0]; rb[u][r] = gs[(gy0 + r) * gw + gx1 + 1]; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    if (u >= nt) continue;
+    if (out[u] == -2) { out[u] = scan_closest(S[u], qxs[u], qys[u], d); continue; }
+    const float4* __restrict__ gp = S[u]->gpts;
+    int best = -1;
+    float bd = 3.4e38f;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      for (int q = ra[u][r]; q < rb[u][r]; q += 4) {
+        float4 c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = gp[min(q + k, rb[u][r] - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float dx = qx[u] - c[k].x, dy = qy[u] - c[k].y;
+          float d2 = dx * dx; d2 += dy * dy;
+          const int i = __float_as_int(c[k].z);
+          if (q + k < rb[u][r] && (d2 < bd || (d2 == bd && i < best))) { bd = d2; best = i; }
+        }
+      }
+    }
+    out[u] = (best >= 0 && (double)bd < d * d) ? best : -1;
+  }
+}
+
 }  // namespace cfear_dev

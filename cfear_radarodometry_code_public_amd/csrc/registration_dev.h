@@ -29,13 +29,13 @@ struct RegScratch {
   float* sim;                // [pairs] direction similarity
   int cap;                   // capacity in pairs
   double* red;               // LDS, >= 10 * 32 doubles
-  int* red_i;                // LDS, >= 64 ints
+  int* red_i;                // LDS, >= 64 ints (also used as 32 x u64 scan scratch)
 };
 
 struct Aff2 { double l0, l1, l2, l3, t0, t1; };
 
 __device__ inline Aff2 aff_from_xyt(double x, double y, double th) {  // vectorToAffine3d, registration.cpp:130-136
-  Aff2 T; const double c = cos(th), s = sin(th);
+  Aff2 T; double s, c; sincos(th, &s, &c);
   T.l0 = c; T.l1 = -s; T.l2 = s; T.l3 = c; T.t0 = x; T.t1 = y;
   return T;
 }
@@ -75,7 +75,7 @@ __device__ inline double get_weight(int opt, double n1, double n2, double sim, d
 
 #define CFEAR_DBL_MIN 2.2250738585072014e-308
 // ceres::LossFunction::Evaluate restatement (registration.cpp:78-97)
-__device__ inline void loss_eval(int loss, double a, double s, double rho[3]) {
+__device__ __noinline__ void loss_eval(int loss, double a, double s, double rho[3]) {
   const double b = a * a;
   switch (loss) {
     case CFEAR_LOSS_HUBER:
@@ -119,6 +119,7 @@ enum { REG_ST_BUILD = 0, REG_ST_LM_IT0 = 1, REG_ST_LM_CAND = 2, REG_ST_COV = 3 }
 struct RegShared {
   // command published by the controller (wave 0) to all waves
   int cmd, itr, M, state;
+  int lds_match, pad_a;  // compacted matches live in the LDS match array (M <= CFEAR_MATCH_LDS_CAP)
   double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
   double c, s;  // cos/sin of x[2], computed once by the controller
   double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
@@ -133,31 +134,47 @@ struct RegShared {
   int reuse_diagonal, num_invalid, iteration, pad1;
 };
 
+// ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
+#define CFEAR_MATCH_LDS_CAP 640
+struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
+__device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
+  MatchPtrs m;
+  m.tmx = base; m.tmy = base + cap; m.a0 = base + 2 * cap; m.a1 = base + 3 * cap; m.a2 = base + 4 * cap;
+  m.sx = base + 5 * cap; m.sy = base + 6 * cap; m.w = base + 7 * cap;
+  return m;
+}
+__device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared array for every user of this header
+  __shared__ double s_match[8 * CFEAR_MATCH_LDS_CAP];
+  return s_match;
+}
+
 // Robustified cost, gradient and Gauss-Newton matrix over the compacted matches at x = (x0, x1, theta)
 // with (c, s) = (cos, sin)(theta). Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P);
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
-__device__ __noinline__ void evaluate_partial(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
+template <bool LDS, int COST>
+__device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
   const int wave = threadIdx.x >> 6;
   if (wave >= CFEAR_EVAL_WAVES) return;
+  const MatchPtrs m = LDS ? match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP) : match_ptrs(W.tmx, (size_t)W.cap);
   const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < M; i += nthr) {
-    const double sx = W.sx[i], sy = W.sy[i], tmx = W.tmx[i], tmy = W.tmy[i], wgt = W.w[i];
+    const double sx = m.sx[i], sy = m.sy[i], tmx = m.tmx[i], tmy = m.tmy[i], wgt = m.w[i];
     const double px = (c * sx - s * sy) + x0;
     const double py = (s * sx + c * sy) + x1;
     const double dtx = -s * sx - c * sy;
     const double dty = c * sx - s * sy;
     double r[2], J[2][3];
     int nr;
-    if (P.cost == CFEAR_COST_P2L) {
-      const double nx = W.a0[i], ny = W.a1[i];
+    if (COST == CFEAR_COST_P2L) {
+      const double nx = m.a0[i], ny = m.a1[i];
       nr = 1;
       r[0] = (px - tmx) * nx + (py - tmy) * ny;
       J[0][0] = nx; J[0][1] = ny; J[0][2] = dtx * nx + dty * ny;
       r[1] = 0; J[1][0] = J[1][1] = J[1][2] = 0;
-    } else if (P.cost == CFEAR_COST_P2D) {
-      const double l00 = W.a0[i], l10 = W.a1[i], l11 = W.a2[i];
+    } else if (COST == CFEAR_COST_P2D) {
+      const double l00 = m.a0[i], l10 = m.a1[i], l11 = m.a2[i];
       nr = 2;
       const double dx = px - tmx, dy = py - tmy;
       r[0] = l00 * dx; r[1] = l10 * dx + l11 * dy;
@@ -186,14 +203,21 @@ __device__ __noinline__ void evaluate_partial(const RegScratch& W, int M, const 
   }
   double v[10] = {a.cost, a.g0, a.g1, a.g2, a.h00, a.h01, a.h02, a.h11, a.h12, a.h22};
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int i = 0; i < 10; i++) v[i] += __shfl_xor(v[i], off);
-  }
+  for (int i = 0; i < 10; i++) v[i] = wave_sum_dpp(v[i]);
   if (lane_id() == 0) {
 #pragma unroll
     for (int i = 0; i < 10; i++) W.red[i * 32 + wave] = v[i];
   }
+}
+template <int COST>
+__device__ __noinline__ void evaluate_partial_c(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s) {
+  if (lds_match) evaluate_partial_t<true, COST>(W, M, P, x0, x1, c, s);
+  else evaluate_partial_t<false, COST>(W, M, P, x0, x1, c, s);
+}
+__device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s) {
+  if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L>(W, M, lds_match, P, x0, x1, c, s);
+  else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D>(W, M, lds_match, P, x0, x1, c, s);
+  else evaluate_partial_c<CFEAR_COST_P2P>(W, M, lds_match, P, x0, x1, c, s);
 }
 
 __device__ inline NormalEq gather_partials(const RegScratch& W) {
@@ -225,11 +249,44 @@ __device__ inline bool chol3_solve(const double A[6], const double b[3], double 
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
+// one match record (AddScanPairCost :266-320) written at position o of the destination SoA
+__device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const RegParams& P, const double* T, const double* Tt,
+                                            const cfear_cell* cs, const cfear_cell* ct) {
+  const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
+  const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
+  const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
+  m.w[o] = get_weight(P.weight_opt, (double)cs->nsamples, (double)ct->nsamples, sim, cs->scale, ct->scale);
+  m.tmx[o] = (Tt[0] * ct->mean[0] + Tt[1] * ct->mean[1]) + Tt[4];
+  m.tmy[o] = (Tt[2] * ct->mean[0] + Tt[3] * ct->mean[1]) + Tt[5];
+  m.sx[o] = cs->mean[0]; m.sy[o] = cs->mean[1];
+  if (P.cost == CFEAR_COST_P2D) {  // :290-299
+    const double a = ct->cov[0], b = ct->cov[1], c = ct->cov[2];
+    const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
+    const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
+    const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
+    const double c00 = (P.regularization + (m00 * r00 + m01 * r01)) * P.covar_scale;
+    const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * P.covar_scale;
+    const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * P.covar_scale;
+    const double c11 = (P.regularization + (m10 * r10 + m11 * r11)) * P.covar_scale;
+    const double det = c00 * c11 - c01 * c10, id = 1.0 / det;
+    const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
+    const double l00 = sqrt(i00), l10 = i10 / l00;
+    const double l11 = sqrt(i11 - l10 * l10);
+    m.a0[o] = l00; m.a1[o] = l10; m.a2[o] = l11;
+  } else {
+    m.a0[o] = Tt[0] * ct->normal[0] + Tt[1] * ct->normal[1];
+    m.a1[o] = Tt[2] * ct->normal[0] + Tt[3] * ct->normal[1];
+    m.a2[o] = 0;
+  }
+}
+
 // AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
-// Transforms come precomputed from the controller (sh->Ttar, sh->Trel). All threads; returns the
-// number of matches (compacted in W, reference residual-block order).
-__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, const RegShared* sh, const RegParams& P, int itr,
-                                          const RegScratch& W) {
+// Transforms come precomputed from the controller (sh->Ttar, sh->Trel). All threads; returns the number of
+// matches, compacted in reference residual-block order into the LDS match array if they fit, else into
+// W's global arrays. (A four-keyframes-at-a-time variant with batched bucket loads measured slower end to
+// end: it needs 248 VGPRs and halves the number of resident workgroups.)
+__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, const RegParams& P, int itr,
+                                                const RegScratch& W) {
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
   const ScanDev* src = scans[n - 1];
@@ -258,42 +315,18 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, co
   }
   int M;
   int o = block_exclusive_scan(cnt, W.red_i, &M);
+  const bool use_lds = M <= CFEAR_MATCH_LDS_CAP;
   for (int p = p0; p < p1; p++) {
     const int ti = W.assoc[p];
     if (ti < 0) continue;
     const int i = p / nsrc, j = p - i * nsrc;
-    const double* T = sh->Trel[i];
-    const double* Tt = sh->Ttar[i];
     const cfear_cell* cs = &src->cells[j];
     const cfear_cell* ct = &scans[i]->cells[ti];
-    const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
-    const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
-    const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
-    W.w[o] = get_weight(P.weight_opt, (double)cs->nsamples, (double)ct->nsamples, sim, cs->scale, ct->scale);
-    W.tmx[o] = (Tt[0] * ct->mean[0] + Tt[1] * ct->mean[1]) + Tt[4];
-    W.tmy[o] = (Tt[2] * ct->mean[0] + Tt[3] * ct->mean[1]) + Tt[5];
-    W.sx[o] = cs->mean[0]; W.sy[o] = cs->mean[1];
-    if (P.cost == CFEAR_COST_P2D) {  // :290-299
-      const double a = ct->cov[0], b = ct->cov[1], c = ct->cov[2];
-      const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
-      const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
-      const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
-      const double c00 = (P.regularization + (m00 * r00 + m01 * r01)) * P.covar_scale;
-      const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * P.covar_scale;
-      const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * P.covar_scale;
-      const double c11 = (P.regularization + (m10 * r10 + m11 * r11)) * P.covar_scale;
-      const double det = c00 * c11 - c01 * c10, id = 1.0 / det;
-      const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
-      const double l00 = sqrt(i00), l10 = i10 / l00;
-      const double l11 = sqrt(i11 - l10 * l10);
-      W.a0[o] = l00; W.a1[o] = l10; W.a2[o] = l11;
-    } else {
-      W.a0[o] = Tt[0] * ct->normal[0] + Tt[1] * ct->normal[1];
-      W.a1[o] = Tt[2] * ct->normal[0] + Tt[3] * ct->normal[1];
-      W.a2[o] = 0;
-    }
+    if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, sh->Trel[i], sh->Ttar[i], cs, ct);
+    else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, sh->Trel[i], sh->Ttar[i], cs, ct);
     o++;
   }
+  if (threadIdx.x == 0) sh->lds_match = use_lds ? 1 : 0;
   __syncthreads();
   return M;
 }
@@ -306,14 +339,14 @@ struct RegIo {  // where the controller reads/writes the caller-visible data
   double* poses; double* cov6; cfear_reg_summary* out; double* par; int n;
 };
 
-__device__ inline void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
+__device__ __noinline__ void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
   sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
-  sh->c = cos(x2); sh->s = sin(x2);
+  { double sn, cs; sincos(x2, &sn, &cs); sh->c = cs; sh->s = sn; }
   sh->cmd = REG_CMD_EVAL; sh->state = state;
 }
 
 // transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
-__device__ inline void ctl_publish_build(RegShared* sh, const RegIo& io) {
+__device__ __noinline__ void ctl_publish_build(RegShared* sh, const RegIo& io) {
   const int n = io.n, L = 3 * (n - 1);
   const Aff2 Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
   for (int i = lane_id(); i < n - 1; i += 64) {
@@ -328,7 +361,7 @@ __device__ inline void ctl_publish_build(RegShared* sh, const RegIo& io) {
   sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
 }
 
-__device__ inline void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq& E) {
+__device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq& E) {
   const int n = io.n, L = 3 * (n - 1);
   int ret = 0;
   if (lane_id() == 0) {
@@ -366,7 +399,7 @@ __device__ inline void ctl_finish(RegShared* sh, const RegIo& io, const RegParam
 }
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
-__device__ inline void ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
   const int itr = sh->itr;
   sh->success = (sh->ss.termination != 2);
   if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
@@ -395,7 +428,7 @@ __device__ inline void ctl_lm_done(RegShared* sh, const RegIo& io, const RegPara
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
-__device__ inline void ctl_lm_next(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const RegParams& P) {
   const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
   for (;;) {
     if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
@@ -441,71 +474,78 @@ __device__ inline void ctl_lm_next(RegShared* sh, const RegIo& io, const RegPara
   }
 }
 
-// consumes the result of the command just executed and publishes the next one
-__device__ __noinline__ void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+// ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
+// over its callees, and it decides how many workgroups share a compute unit) ----
+__device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, const RegParams& P) {
+  const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
+  sh->nres = sh->M * rpb;
+  if (sh->nres <= 1) {  // :370-371 -> :114-115
+    sh->success = 0;
+    NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    ctl_finish(sh, io, P, false, z);
+    return;
+  }
+  ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
+}
+
+__device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+  const double gradient_tolerance = 1e-10;
+  const NormalEq E = gather_partials(W);
+  sh->E = E; sh->x_cost = E.cost;
+  sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+  sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
+  const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
+  if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  sh->sc0 = 1.0 / (1.0 + sqrt(E.h00)); sh->sc1 = 1.0 / (1.0 + sqrt(E.h11)); sh->sc2 = 1.0 / (1.0 + sqrt(E.h22));
+  sh->radius = 1e4; sh->decrease_factor = 2.0; sh->reuse_diagonal = 0; sh->num_invalid = 0; sh->iteration = 0;
+  sh->dg0 = sh->dg1 = sh->dg2 = 0;
+  ctl_lm_next(sh, io, P);
+}
+
+__device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
-  const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
+  const NormalEq C = gather_partials(W);
+  const double cand_cost = C.cost;
+  const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
+  const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  const double cost_change = sh->x_cost - cand_cost;
+  if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  const double relative_decrease = cost_change / sh->model_cost_change;
+  sh->ss.num_iterations++;
+  sh->ss.last_relative_decrease = relative_decrease;
+  if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
+    sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
+    sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+    sh->E = C; sh->x_cost = cand_cost;
+    const double t = 2.0 * relative_decrease - 1.0;
+    sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    sh->radius = fmin(max_radius, sh->radius);
+    sh->decrease_factor = 2.0; sh->reuse_diagonal = 0;
+    if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
+    const double gmax = fmax(fabs(C.g0), fmax(fabs(C.g1), fabs(C.g2)));
+    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
+    if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  } else {  // HandleUnsuccessfulStep
+    sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
+    if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
+  }
+  ctl_lm_next(sh, io, P);
+}
+
+__device__ __noinline__ void ctl_after_cov(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+  const NormalEq E = gather_partials(W);
+  ctl_finish(sh, io, P, true, E);
+}
+
+// consumes the result of the command just executed and publishes the next one
+__device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   switch (sh->state) {
-    case REG_ST_BUILD: {
-      sh->nres = sh->M * rpb;
-      if (sh->nres <= 1) {  // :370-371 -> :114-115
-        sh->success = 0;
-        NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        ctl_finish(sh, io, P, false, z);
-        return;
-      }
-      ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
-      return;
-    }
-    case REG_ST_LM_IT0: {
-      const NormalEq E = gather_partials(W);
-      sh->E = E; sh->x_cost = E.cost;
-      sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
-      sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
-      const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
-      if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
-      sh->sc0 = 1.0 / (1.0 + sqrt(E.h00)); sh->sc1 = 1.0 / (1.0 + sqrt(E.h11)); sh->sc2 = 1.0 / (1.0 + sqrt(E.h22));
-      sh->radius = 1e4; sh->decrease_factor = 2.0; sh->reuse_diagonal = 0; sh->num_invalid = 0; sh->iteration = 0;
-      sh->dg0 = sh->dg1 = sh->dg2 = 0;
-      ctl_lm_next(sh, io, P);
-      return;
-    }
-    case REG_ST_LM_CAND: {
-      const NormalEq C = gather_partials(W);
-      const double cand_cost = C.cost;
-      const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
-      const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-      if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
-      const double cost_change = sh->x_cost - cand_cost;
-      if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
-      const double relative_decrease = cost_change / sh->model_cost_change;
-      sh->ss.num_iterations++;
-      sh->ss.last_relative_decrease = relative_decrease;
-      if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
-        sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
-        sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
-        sh->E = C; sh->x_cost = cand_cost;
-        const double t = 2.0 * relative_decrease - 1.0;
-        sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-        sh->radius = fmin(max_radius, sh->radius);
-        sh->decrease_factor = 2.0; sh->reuse_diagonal = 0;
-        if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
-        const double gmax = fmax(fabs(C.g0), fmax(fabs(C.g1), fabs(C.g2)));
-        if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
-        if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
-      } else {  // HandleUnsuccessfulStep
-        sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
-        if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
-      }
-      ctl_lm_next(sh, io, P);
-      return;
-    }
-    default: {  // REG_ST_COV
-      const NormalEq E = gather_partials(W);
-      ctl_finish(sh, io, P, true, E);
-      return;
-    }
+    case REG_ST_BUILD: ctl_after_build(sh, io, P); return;
+    case REG_ST_LM_IT0: ctl_after_it0(sh, io, P, W); return;
+    case REG_ST_LM_CAND: ctl_after_candidate(sh, io, P, W); return;
+    default: ctl_after_cov(sh, io, P, W); return;
   }
 }
 
@@ -550,7 +590,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       if (tid == 0) sh->M = M;
       if (pt) pt->mark();
     } else {
-      evaluate_partial(W, sh->M, P, sh->x[0], sh->x[1], sh->c, sh->s);
+      evaluate_partial(W, sh->M, sh->lds_match, P, sh->x[0], sh->x[1], sh->c, sh->s);
     }
     __syncthreads();  // results visible to the controller
     if (master) ctl_step(sh, io, P, W);
