@@ -157,3 +157,26 @@ def test_batched_odometry_matches_oracle_fuser(oracle, seq, cost):
     assert np.linalg.norm(got[0, :2] - gt[-1, :2]) < 0.5
     odo.release()
     ctx.close()
+
+
+@pytest.mark.parametrize("k,cost,res,submap", [(40, 0, 3.0, 4), (40, 1, 3.0, 4), (12, 1, 3.5, 3), (25, 2, 3.0, 2)])
+def test_reference_presets_through_device_fuser(oracle, k, cost, res, submap):
+    """The reference's own presets: CFEAR-3 (P2P, k=40, r=3, s=4) runs the big-cloud
+    path (400*40 points: sort keys and voxel lists in global memory instead of LDS)."""
+    imgs, gt = synth.world_sequence(7, seed=9)
+    kw = dict(k_strongest=k, cost=cost, res=res, submap_scan_size=submap, z_min=60.0)
+    po, pg = mk_params(oracle, **kw), mk_params(capi, **kw)
+    fu = oracle.Fuser(po)
+    ctx = capi.Context(pg, 400, 3360)
+    odo = ctx.odometry(1)
+    for t in range(imgs.shape[0]):
+        odo.step_host(imgs[t][None])
+        got = odo.poses()[0]
+        exp = fu.process_polar(imgs[t])
+        S, nc, nk = odo.summary(0)
+        So = fu.last_summary()
+        assert nc == len(fu.last_cells()) and nk == fu.num_keyframes
+        assert [S.outer_iterations] + list(S.inner_iterations[:8]) == [So.outer_iterations] + list(So.inner_iterations[:8]), t
+        assert np.all(np.abs(got[:2] - exp[:2]) < POS_TOL) and abs(got[2] - exp[2]) < ROT_TOL, (t, got, exp)
+    odo.release()
+    ctx.close()
