@@ -60,6 +60,7 @@ struct FeatureScratch {
   int* flags;       // global [cap_points]
   int* red_i;       // LDS, >= 64 ints
   float* red_f;     // LDS, >= 64 floats
+  bool lds;         // keys/order/vstart/vlist/spts are LDS arrays (enables the LDS counting sort)
 };
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
@@ -191,6 +192,72 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
+  const long long Gll = (long long)div0 * (long long)div1;
+  if (W.lds && Gll <= 32768) {
+    // ---- LDS counting sort over the dense voxel grid: 16-bit counters packed two per word in the (not yet
+    // used) key region; the atomic scatter is unordered, a per-voxel insertion sort restores the point order,
+    // which makes the whole sort stable ([3P] std::sort on the voxel index, pinned as stable) ----
+    const int G = (int)Gll;
+    uint32_t* tab = reinterpret_cast<uint32_t*>(W.keys);
+    for (int g = tid; g <= (G >> 1); g += nt) tab[g] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+      const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
+      const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+      const int vid = ijk0 + ijk1 * div0;
+      W.order[i] = vid;  // parked until the scatter
+      atomicAdd(&tab[vid >> 1], 1u << (16 * (vid & 1)));
+    }
+    __syncthreads();
+    if (pt) pt->mark();
+    int nvv;
+    {
+      const int ipt = ((G + nt - 1) / nt + 1) & ~1;  // even: a thread owns whole words
+      const int g0 = tid * ipt, g1 = min(G, g0 + ipt);
+      int cnt = 0, occ = 0;
+      for (int g = g0; g < g1; g++) { const int c = (tab[g >> 1] >> (16 * (g & 1))) & 0xFFFF; cnt += c; occ += c > 0 ? 1 : 0; }
+      int tot;
+      int o = block_exclusive_scan(cnt, W.red_i, &tot);
+      int ov = block_exclusive_scan(occ, W.red_i, &nvv);
+      for (int g = g0; g < g1; g += 2) {
+        const uint32_t w = tab[g >> 1];
+        const int c0 = w & 0xFFFF, c1 = (g + 1 < g1) ? (int)(w >> 16) : 0;
+        if (c0 > 0) { W.vlist[ov] = g; W.vstart[ov] = o; ov++; }
+        const int s0 = o; o += c0;
+        if (c1 > 0) { W.vlist[ov] = g + 1; W.vstart[ov] = o; ov++; }
+        const int s1 = o; o += c1;
+        tab[g >> 1] = (uint32_t)s0 | ((uint32_t)s1 << 16);  // counters become start offsets (scatter cursors)
+      }
+      if (tid == 0) { W.vstart[nvv] = n; S->n_samples = nvv; S->n_points = n; S->status = 0; }
+      __syncthreads();
+    }
+    // scatter: the voxel index parked in order[i] is consumed before any slot of order[] is overwritten.
+    // The atomic slot order inside a voxel is arbitrary; the final slot of a point is the voxel start plus
+    // the number of voxel members with a smaller point index (rank by counting).
+    {
+      int pos[8], pi[8], pv[8], np = 0;
+      for (int i = tid; i < n && np < 8; i += nt) {
+        const int vid = W.order[i];
+        const uint32_t old = atomicAdd(&tab[vid >> 1], 1u << (16 * (vid & 1)));
+        pos[np] = (int)((old >> (16 * (vid & 1))) & 0xFFFF); pi[np] = i; pv[np] = vid; np++;
+      }
+      __syncthreads();
+      for (int r = 0; r < np; r++) W.order[pos[r]] = pi[r];
+      __syncthreads();
+      for (int r = 0; r < np; r++) {  // the cursors now hold the voxel ends (= start of the next voxel)
+        const int vid = pv[r];
+        const int b = (int)((tab[vid >> 1] >> (16 * (vid & 1))) & 0xFFFF);
+        const int a = vid > 0 ? (int)((tab[(vid - 1) >> 1] >> (16 * ((vid - 1) & 1))) & 0xFFFF) : 0;
+        int c = 0;
+        for (int q = a; q < b; q++) c += W.order[q] < pi[r] ? 1 : 0;
+        pos[r] = a + c;
+      }
+      __syncthreads();
+      for (int r = 0; r < np; r++) W.order[pos[r]] = pi[r];
+      __syncthreads();
+    }
+    if (pt) pt->mark();
+  } else {
   for (int i = tid; i < p2; i += nt) {
     uint64_t key = ~0ull;
     if (i < n) {
@@ -219,6 +286,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     }
     if (tid == 0) { W.vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
+  }
   }
   const int nv = S->n_samples;
   // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)

@@ -89,7 +89,7 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   } else {
     W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
   }
-  W.vcur = B.vcur;
+  W.vcur = B.vcur; W.lds = LDS;
   W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
   W.red_i = reinterpret_cast<int*>(lds + FeatLds::red_i);
   W.red_f = reinterpret_cast<float*>(lds + FeatLds::red_f);
