@@ -116,7 +116,7 @@ def lib():
         "cfear_odometry_summary": (C.c_int, [vp, vp, C.c_int, C.POINTER(RegSummary), C.POINTER(C.c_int),
                                              C.POINTER(C.c_int)]),
         "cfear_odometry_profile": (C.c_int, [vp, vp, C.c_int]),
-        "cfear_odometry_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "cfear_odometry_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "cfear_time_kstrongest": (C.c_int, [vp, u8p, C.c_int, u32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -353,10 +353,11 @@ class Odometry:
         self._ctx._check(self._ctx._L.cfear_odometry_profile(self._ctx._h, self._h, int(enable)), "cfear_odometry_profile")
 
     def profile_read(self):
-        tf, to, n = C.c_double(), C.c_double(), C.c_int()
-        self._ctx._check(self._ctx._L.cfear_odometry_profile_read(self._ctx._h, self._h, C.byref(tf), C.byref(to), C.byref(n)),
+        """-> (filter seconds, filter launches)"""
+        tf, nf = C.c_double(), C.c_int()
+        self._ctx._check(self._ctx._L.cfear_odometry_profile_read(self._ctx._h, self._h, C.byref(tf), C.byref(nf)),
                          "cfear_odometry_profile_read")
-        return tf.value, to.value, n.value
+        return tf.value, nf.value
 
     def poses(self):
         out = np.zeros((self.B, 3))

@@ -107,12 +107,13 @@ int cfear_set_params(cfear_ctx* ctx, const cfear_params* p) {
 int cfear_synchronize(cfear_ctx* ctx) {
   if (!ctx) return CFEAR_ERR_INVALID;
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (hipStream_t st : ctx->aux_streams) CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(st));
   return CFEAR_OK;
 }
 
 int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots) {
   if (!ctx) return CFEAR_ERR_INVALID;
-  return cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+  return cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots, ctx->stream);
 }
 
 int cfear_ensure_staging(cfear_ctx* ctx, int n_scans) {
@@ -141,7 +142,7 @@ int cfear_kstrongest_host(cfear_ctx* ctx, const uint8_t* h_polar, int n_scans, u
   const size_t pb = (size_t)n_scans * ctx->A * ctx->R;
   const size_t sb = (size_t)n_scans * ctx->A * ctx->par.k_strongest * sizeof(uint32_t);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, pb, hipMemcpyHostToDevice, ctx->stream));
-  rc = cfear_launch_kstrongest(ctx, ctx->d_polar, n_scans, ctx->d_slots);
+  rc = cfear_launch_kstrongest(ctx, ctx->d_polar, n_scans, ctx->d_slots, ctx->stream);
   if (rc != CFEAR_OK) return rc;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(h_slots, ctx->d_slots, sb, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -153,12 +154,12 @@ int cfear_time_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, u
   if (!ctx || !avg_seconds || iters <= 0) return CFEAR_ERR_INVALID;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < warmup; i++) {
-    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots, ctx->stream);
     if (rc != CFEAR_OK) return rc;
   }
   CFEAR_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int i = 0; i < iters; i++) {
-    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots);
+    int rc = cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots, ctx->stream);
     if (rc != CFEAR_OK) return rc;
   }
   CFEAR_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));

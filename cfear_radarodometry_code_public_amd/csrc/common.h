@@ -31,6 +31,8 @@ struct cfear_ctx {
   // scratch for the per-call feature / registration kernels
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  // streams of the batched odometry objects of this context (cfear_synchronize waits for them too)
+  std::vector<hipStream_t> aux_streams;
 };
 
 static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -54,4 +56,4 @@ static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_
 // cabi.hip
 extern "C" int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
 // kstrongest.hip
-int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots);
+int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);

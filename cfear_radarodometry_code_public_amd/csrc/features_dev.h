@@ -26,6 +26,10 @@ struct ScanDev {
   int* gstart;        // [cap_grid + 1]
   int* gorder;        // [cap_cells] cell indices bucketed by grid cell
   float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
+  // registration views of the cells (the association is bound by the number of scattered load instructions,
+  // so the fields it needs are packed): mean x, mean y, normal x, normal y, nsamples, scale
+  double* rsrc;       // [6][cap_cells] SoA: read with consecutive cell indices when the scan is the source
+  double* rtar;       // [cap_cells][8] 64-byte records: read at random cell indices when the scan is a target
 };
 
 struct FeatureParams {
@@ -38,9 +42,10 @@ struct FeatureParams {
 
 // optional per-block phase timestamps (bring-up / tuning): thread 0 stores wall_clock64() ticks (100 MHz)
 struct PhaseTimer {
-  long long* t;
-  int n;
-  __device__ inline void mark() { if (t && threadIdx.x == 0 && n < 32) t[n++] = (long long)wall_clock64(); }
+  long long* t;    // next free tick slot of this kernel's share of the 32 per sequence
+  int n, cap;
+  long long* acc;  // three accumulators (slots 29..31 of the sequence) or null
+  __device__ inline void mark() { if (t && threadIdx.x == 0 && n < cap) t[n++] = (long long)wall_clock64(); }
 };
 
 // Working memory of one block. For clouds up to CFEAR_LDS_POINT_CAP points keys/order/vstart/vlist
@@ -61,6 +66,10 @@ struct FeatureScratch {
   int* red_i;       // LDS, >= 64 ints
   float* red_f;     // LDS, >= 64 floats
   bool lds;         // keys/order/vstart/vlist/spts are LDS arrays (enables the LDS counting sort)
+  int* rng;         // global [cap_points][8] candidate row ranges of every sample point
+  double* part;     // global [7][cap_points] partial moments of the candidate chunks
+  int* tmpi;        // global [2 * cap + 16] copies of vlist/vstart (only used when leaf < radius)
+  int cap;          // capacity (entries) of order/vstart/vlist/rng/part
 };
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
@@ -195,7 +204,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const long long Gll = (long long)div0 * (long long)div1;
   if (W.lds && Gll <= 32768) {
     // ---- LDS counting sort over the dense voxel grid: 16-bit counters packed two per word in the (not yet
-    // used) key region; the atomic scatter is unordered, a per-voxel insertion sort restores the point order,
+    // used) key region; the atomic scatter is unordered, ranking by point index inside each voxel restores the point order,
     // which makes the whole sort stable ([3P] std::sort on the voxel index, pinned as stable) ----
     const int G = (int)Gll;
     uint32_t* tab = reinterpret_cast<uint32_t*>(W.keys);
@@ -314,47 +323,127 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const float rq = P.radius * 1.0001f;
   // Groups of 8 lanes share one sample point (candidate counts range from 1 to ~1000 per voxel, so a
   // thread-per-voxel mapping is badly imbalanced); fixed xor-tree reduction keeps the result deterministic.
-  constexpr int GS = 2;
-  const int sub = tid & (GS - 1);
-  for (int v0 = 0; v0 < nv; v0 += nt / GS) {  // uniform trip count: the shuffles below need all lanes
-    const int v = v0 + tid / GS;
-    const bool live = v < nv;
-    const float cx = live ? W.samples[3 * v] : 0.f, cy = live ? W.samples[3 * v + 1] : 0.f;
+  // Candidate counts range from 1 to ~1000 per sample point, so the work is cut into chunks of at most C
+  // candidates: (1) per sample the candidate row ranges and their total, (2) a scan turns them into a chunk
+  // list, (3) one lane per chunk accumulates partial moments, (4) the epilogue adds a sample's partials in
+  // chunk order (deterministic).
+  int* __restrict__ T = W.order;  // the sorted order has been consumed by the staging above
+  for (int v = tid; v < nv; v += nt) {
+    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+    int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
+    int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
+    gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
+    int tot = 0, nr = 0;
+    int R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int gy = gy0; gy <= gy1 && gx0 <= gx1; gy++) {
+      // voxels gx0..gx1 of this row are contiguous in the sorted order: search the voxel list
+      const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
+      const int p0 = lower_bound_int(W.vlist, nv, k0);
+      int p1 = p0;
+      while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
+      const int a = W.vstart[p0], b = W.vstart[p1];
+      if (b > a) {
+        if (nr < 4) { R[2 * nr] = a; R[2 * nr + 1] = b; }
+        nr++; tot += b - a;
+      }
+    }
+    if (nr > 4) R[0] = -1;  // only with leaf < radius: the chunk lanes search again (copies made below)
+    int4* Rg = reinterpret_cast<int4*>(W.rng + 8 * (size_t)v);
+    Rg[0] = make_int4(R[0], R[1], R[2], R[3]); Rg[1] = make_int4(R[4], R[5], R[6], R[7]);
+    T[v] = tot;
+  }
+  const bool wide = (int)(2.0f * rq * inv) + 2 > 4;  // block-uniform
+  if (wide) {
+    for (int i = tid; i < nv; i += nt) { W.tmpi[i] = W.vlist[i]; W.tmpi[W.cap + 8 + i] = W.vstart[i]; }
+    if (tid == 0) W.tmpi[W.cap + 8 + nv] = W.vstart[nv];
+  }
+  __syncthreads();
+  if (pt) pt->mark();
+  int C = 32, NC;
+  {
+    const int ipt = (nv + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
+    int o;
+    for (;;) {  // block-uniform: double the chunk size until the chunk list fits
+      int cnt = 0;
+      for (int i = i0; i < i1; i++) cnt += (T[i] + C - 1) / C;
+      o = block_exclusive_scan(cnt, W.red_i, &NC);
+      if (NC <= W.cap) break;
+      C <<= 1;
+    }
+    for (int i = i0; i < i1; i++) {  // vstart/vlist are free now: chunk start per sample, sample per chunk
+      const int c = (T[i] + C - 1) / C;
+      W.vstart[i] = o;
+      for (int j = 0; j < c; j++) W.vlist[o + j] = i;
+      o += c;
+    }
+    if (tid == 0) W.vstart[nv] = NC;
+    __syncthreads();
+  }
+  if (pt) pt->mark();
+  for (int w = tid; w < NC; w += nt) {
+    const int v = W.vlist[w];
+    const int j = w - W.vstart[v];
+    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+    const int* R = W.rng + 8 * (size_t)v;
+    const int4 r0 = *reinterpret_cast<const int4*>(R), r1 = *reinterpret_cast<const int4*>(R + 4);
+    const int tot = T[v];
+    int skip = j * C, left = min(C, tot - skip);
     CellAcc A = {0, 0, 0, 0, 0, 0, 0};
-    if (live) {
+    if (r0.x >= 0) {
+      const int ra[4] = {r0.x, r0.z, r1.x, r1.z}, rb[4] = {r0.y, r0.w, r1.y, r1.w};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int len = rb[r] - ra[r];
+        if (left > 0 && len > 0) {
+          if (skip >= len) { skip -= len; }
+          else {
+            const int s = ra[r] + skip, e = min(rb[r], s + left);
+            accumulate_range(sp, s, e, cx, cy, r2, P.weight_intensity, A, 0, 1);
+            left -= e - s; skip = 0;
+          }
+        }
+      }
+    } else {  // more than four candidate rows (leaf < radius): the ranges are searched again
       int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
       int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
       gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
-      for (int gy = gy0; gy <= gy1 && gx0 <= gx1; gy++) {
-        // voxels gx0..gx1 of this row are contiguous in the sorted order: search the (LDS) voxel list
+      const int* vl = W.tmpi;  // copies of vlist/vstart made before they were reused
+      const int* vs = W.tmpi + W.cap + 8;
+      for (int gy = gy0; gy <= gy1 && left > 0; gy++) {
         const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
-        const int p0 = lower_bound_int(W.vlist, nv, k0);
+        const int p0 = lower_bound_int(vl, nv, k0);
         int p1 = p0;
-        while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
-        if (p1 > p0) accumulate_range(sp, W.vstart[p0], W.vstart[p1], cx, cy, r2, P.weight_intensity, A, sub, GS);
+        while (p1 < nv && (long long)vl[p1] <= k1) p1++;
+        const int a = vs[p0], b = vs[p1], len = b - a;
+        if (skip >= len) { skip -= len; continue; }
+        const int s = a + skip, e = min(b, s + left);
+        accumulate_range(sp, s, e, cx, cy, r2, P.weight_intensity, A, 0, 1);
+        left -= e - s; skip = 0;
       }
     }
-#pragma unroll
-    for (int off = 1; off < GS; off <<= 1) {
-      A.m += __shfl_xor(A.m, off);
-      A.s0 += __shfl_xor(A.s0, off); A.s1x += __shfl_xor(A.s1x, off); A.s1y += __shfl_xor(A.s1y, off);
-      A.sxx += __shfl_xor(A.sxx, off); A.sxy += __shfl_xor(A.sxy, off); A.syy += __shfl_xor(A.syy, off);
-    }
-    if (live && sub == 0) {  // park the reduced moments in the cell slot; the f64 epilogue runs thread-per-voxel below
-      cfear_cell* c = &W.tmp[v];
-      c->mean[0] = A.s0; c->mean[1] = A.s1x; c->cov[0] = A.s1y; c->cov[1] = A.sxx; c->cov[2] = A.sxy; c->normal[0] = A.syy;
-      c->nsamples = A.m;
-    }
+    const size_t cs = (size_t)W.cap;
+    W.part[w] = (double)A.m; W.part[cs + w] = A.s0; W.part[2 * cs + w] = A.s1x; W.part[3 * cs + w] = A.s1y;
+    W.part[4 * cs + w] = A.sxx; W.part[5 * cs + w] = A.sxy; W.part[6 * cs + w] = A.syy;
   }
   __syncthreads();
   if (pt) pt->mark();
   for (int v = tid; v < nv; v += nt) {
     cfear_cell* c = &W.tmp[v];
-    const int m = c->nsamples;
+    double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
+    {
+      const size_t cs = (size_t)W.cap;
+      for (int w = W.vstart[v]; w < W.vstart[v + 1]; w++) {
+        md += W.part[w]; s0 += W.part[cs + w]; s1x += W.part[2 * cs + w]; s1y += W.part[3 * cs + w];
+        sxx += W.part[4 * cs + w]; sxy += W.part[5 * cs + w]; syy += W.part[6 * cs + w];
+      }
+    }
+    const int m = (int)md;
+    c->nsamples = m;
+    c->valid = 0;
     int valid = 0;
     if (m >= 6) {  // :291
       const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
-      const double s0 = c->mean[0], s1x = c->mean[1], s1y = c->cov[0], sxx = c->cov[1], sxy = c->cov[2], syy = c->normal[0];
       const double m1x = s1x / s0, m1y = s1y / s0;
       const double ux = (double)cx + m1x, uy = (double)cy + m1y;
       const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
@@ -393,6 +482,15 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         S->cells[o] = c;
         S->mean_f[2 * o] = (float)c.mean[0];
         S->mean_f[2 * o + 1] = (float)c.mean[1];
+        {
+          const size_t cc = (size_t)S->cap_cells;
+          double* rs = S->rsrc + o;
+          rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
+          rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
+          double2* rt = reinterpret_cast<double2*>(S->rtar + 8 * (size_t)o);
+          rt[0] = make_double2(c.mean[0], c.mean[1]); rt[1] = make_double2(c.normal[0], c.normal[1]);
+          rt[2] = make_double2((double)c.nsamples, c.scale);
+        }
         o++;
       }
     if (tid == 0) S->n_cells = nc < S->cap_cells ? nc : S->cap_cells;
@@ -456,37 +554,56 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
 
 // GetClosestIdx (pointnormal.cpp:238-254): 1-NN over the float cell means, accepted iff d2 < d*d.
 // Exact-distance ties resolve to the lowest cell index (same rule as the oracle).
-__device__ inline int scan_closest(const ScanDev* __restrict__ S, double px, double py, double d) {
+// what the 1-NN search needs from a scan (the registration keeps one per keyframe in LDS: no pointer chasing)
+struct GridView {
+  const int* gs; const float4* gp; const double* rtar;
+  float gminx, gminy, gcell;
+  int gw, gh, n_cells;
+};
+__device__ __forceinline__ GridView grid_view(const ScanDev* S) {
+  GridView G;
+  G.gs = S->gstart; G.gp = S->gpts; G.rtar = S->rtar; G.gminx = S->gminx; G.gminy = S->gminy; G.gcell = S->gcell;
+  G.gw = S->gw; G.gh = S->gh; G.n_cells = S->n_cells;
+  return G;
+}
+__device__ inline int scan_closest(const GridView& S, double px, double py, double d) {
   const float qx = (float)px, qy = (float)py;
-  const int gw = S->gw, gh = S->gh;
-  if (S->n_cells <= 0 || gw <= 0) return -1;
+  const int gw = S.gw, gh = S.gh;
+  if (S.n_cells <= 0 || gw <= 0) return -1;
   const double m = d * (1.0 + 1e-6) + 1e-6;
-  const double gc = (double)S->gcell, gmx = (double)S->gminx, gmy = (double)S->gminy;
+  const double gc = (double)S.gcell, gmx = (double)S.gminx, gmy = (double)S.gminy;
   int gx0 = (int)floor(((double)qx - m - gmx) / gc), gx1 = (int)floor(((double)qx + m - gmx) / gc);
   int gy0 = (int)floor(((double)qy - m - gmy) / gc), gy1 = (int)floor(((double)qy + m - gmy) / gc);
   // the builder clamps bucket coordinates, so clamp the query window the same way
   gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
   if (gx0 > gx1 || gy0 > gy1) return -1;
-  const int* __restrict__ gs = S->gstart;
-  const float4* __restrict__ gp = S->gpts;
+  const int* __restrict__ gs = S.gs;
+  const float4* __restrict__ gp = S.gp;
   int best = -1;
   float bd = 3.4e38f;
-  for (int gy = gy0; gy <= gy1; gy += 3) {  // three rows at a time: all six bucket bounds in flight together
+  struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
+  const bool narrow = gx1 - gx0 <= 1;  // the usual case (bucket size = window size): both bounds of a row in one 12-byte load
+  for (int gy = gy0; gy <= gy1; gy += 3) {  // three rows at a time: all bucket bounds in flight together
     int ra[3], rb[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const int row = min(gy + r, gy1);
-      ra[r] = gs[row * gw + gx0]; rb[r] = gs[row * gw + gx1 + 1];
+      if (narrow) {
+        const Int3 v = *reinterpret_cast<const Int3*>(gs + row * gw + gx0);  // gstart has two spare entries at the end
+        ra[r] = v.a; rb[r] = (gx1 == gx0) ? v.b : v.c;
+      } else {
+        ra[r] = gs[row * gw + gx0]; rb[r] = gs[row * gw + gx1 + 1];
+      }
       if (gy + r > gy1) rb[r] = ra[r];
     }
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      for (int q = ra[r]; q < rb[r]; q += 4) {
-        float4 c[4];
+      for (int q = ra[r]; q < rb[r]; q += 2) {
+        float4 c[2];
 #pragma unroll
-        for (int u = 0; u < 4; u++) c[u] = gp[min(q + u, rb[r] - 1)];
+        for (int u = 0; u < 2; u++) c[u] = gp[min(q + u, rb[r] - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 2; u++) {
           const float dx = qx - c[u].x, dy = qy - c[u].y;
           float d2 = dx * dx; d2 += dy * dy;
           const int i = __float_as_int(c[u].z);
@@ -497,60 +614,6 @@ __device__ inline int scan_closest(const ScanDev* __restrict__ S, double px, dou
   }
   if (best >= 0 && (double)bd < d * d) return best;
   return -1;
-}
-
-// GetClosestIdx of up to four targets at once (one query point each): the bucket bounds of all targets
-// are fetched together, then the candidates; same result as four scan_closest() calls.
-__device__ inline void scan_closest4(const ScanDev* const* S, int nt, const double* qxs, const double* qys, double d, int* out) {
-  int ra[4][3], rb[4][3];
-  float qx[4], qy[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    out[u] = -1;
-#pragma unroll
-    for (int r = 0; r < 3; r++) { ra[u][r] = 0; rb[u][r] = 0; }
-    if (u >= nt) continue;
-    const ScanDev* s = S[u];
-    qx[u] = (float)qxs[u]; qy[u] = (float)qys[u];
-    const int gw = s->gw, gh = s->gh;
-    if (s->n_cells <= 0 || gw <= 0) continue;
-    const double m = d * (1.0 + 1e-6) + 1e-6;
-    const double gc = (double)s->gcell, gmx = (double)s->gminx, gmy = (double)s->gminy;
-    int gx0 = (int)floor(((double)qx[u] - m - gmx) / gc), gx1 = (int)floor(((double)qx[u] + m - gmx) / gc);
-    int gy0 = (int)floor(((double)qy[u] - m - gmy) / gc), gy1 = (int)floor(((double)qy[u] + m - gmy) / gc);
-    gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
-    if (gx0 > gx1 || gy0 > gy1) continue;
-    if (gy1 - gy0 > 2) { out[u] = -2; continue; }  // window taller than three buckets: generic path below
-    const int* __restrict__ gs = s->gstart;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      if (gy0 + r <= gy1) { ra[u][r] = gs[(gy0 + r) * gw + gx0]; rb[u][r] = gs[(gy0 + r) * gw + gx1 + 1]; }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    if (u >= nt) continue;
-    if (out[u] == -2) { out[u] = scan_closest(S[u], qxs[u], qys[u], d); continue; }
-    const float4* __restrict__ gp = S[u]->gpts;
-    int best = -1;
-    float bd = 3.4e38f;
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      for (int q = ra[u][r]; q < rb[u][r]; q += 4) {
-        float4 c[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = gp[min(q + k, rb[u][r] - 1)];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const float dx = qx[u] - c[k].x, dy = qy[u] - c[k].y;
-          float d2 = dx * dx; d2 += dy * dy;
-          const int i = __float_as_int(c[k].z);
-          if (q + k < rb[u][r] && (d2 < bd || (d2 == bd && i < best))) { bd = d2; best = i; }
-        }
-      }
-    }
-    out[u] = (best >= 0 && (double)bd < d * d) ? best : -1;
-  }
 }
 
 }  // namespace cfear_dev

@@ -430,13 +430,17 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 
 // bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 grid oversubscription
 static int g_k1_dbg = 0, g_k1_occ = 8, g_k1_oversub = 4;
-extern "C" void cfear_debug_set(int key, int value) {
+int g_cfear_odo_streams = 0;  // 0 = automatic (pipeline.hip)
+int g_cfear_odo_fork = 1;
+extern "C" void cfear_debug_set(int key, int value) {  // tuning hook of tools/, not part of the ABI
   if (key == 0) g_k1_dbg = value;
   if (key == 1) g_k1_occ = value;
   if (key == 2) g_k1_oversub = value > 0 ? value : 1;
+  if (key == 3) g_cfear_odo_streams = value;
+  if (key == 4) g_cfear_odo_fork = value;
 }
 
-int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots) {
+int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream) {
   const int A = ctx->A, R = ctx->R, k = ctx->par.k_strongest;
   if (!d_polar || !d_slots || n_scans <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "kstrongest: null buffer or n_scans <= 0");
   if (k < 1 || k > 64) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "kstrongest: k_strongest must be in 1..64");
@@ -456,15 +460,15 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const int occ = g_k1_occ;
   if (R + 27 <= 4 * 1024) {
     if (occ >= 8)
-      hipLaunchKernelGGL((kstrongest_kernel<4, 8>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 8>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
     else if (occ <= 5)
-      hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
     else
-      hipLaunchKernelGGL((kstrongest_kernel<4, 6>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 6>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
   } else if (R + 27 <= 8 * 1024)
-    hipLaunchKernelGGL((kstrongest_kernel<8, 3>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    hipLaunchKernelGGL((kstrongest_kernel<8, 3>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
   else if (R + 27 <= 16 * 1024)
-    hipLaunchKernelGGL((kstrongest_kernel<16, 2>), grid, block, 0, ctx->stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    hipLaunchKernelGGL((kstrongest_kernel<16, 2>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
   else
     return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "kstrongest: R > 16357 range bins not supported");
   CFEAR_HIP_CHECK(ctx, hipGetLastError());

@@ -37,8 +37,8 @@ struct FeatLds {  // byte offsets into the static LDS segment of the features ke
   static constexpr size_t total = vlist + CFEAR_LDS_POINT_CAP * sizeof(int);
 };
 struct RegLds {  // registration kernels
-  static constexpr size_t red_d = 0;                                  // 320 doubles
-  static constexpr size_t par = red_d + 320 * sizeof(double);        // 3*MAX_SCANS doubles
+  static constexpr size_t red_d = 0;                                  // 10 sums x CFEAR_RED_STRIDE waves
+  static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*MAX_SCANS doubles
   static constexpr size_t red_i = par + 3 * MAX_SCANS * sizeof(double);  // 64 ints
   static constexpr size_t scanptr = red_i + 64 * sizeof(int);        // MAX_SCANS pointers
   static constexpr size_t regsh = scanptr + MAX_SCANS * sizeof(void*);  // RegShared
@@ -50,6 +50,9 @@ struct BlockScratch {
   uint64_t* keys; float* spts; int* order; int* vstart; int* vlist;  // big-cloud fallbacks of the LDS arrays
   int* vidx;        // [VOXEL_GRID_CAP] dense voxel table, all zero between kernels
   int* vcur;        // [GRID_CAP + 2]
+  int* rng;         // [cap_points][8] candidate row ranges per sample point
+  double* part;     // [7][cap_points] partial cell moments per candidate chunk
+  int* tmpi;        // [2 * cap_points + 16]
   float* samples;   // [cap_points * 3]
   cfear_cell* tmp;  // [cap_points]
   int* flags;       // [cap_points]
@@ -71,6 +74,7 @@ struct OdoParams {
   int A, k, compensate, ccw, use_keyframe, submap;
   double min_keyframe_dist, min_keyframe_rot_deg;
   long long* phase_times;  // optional [B][32] wall_clock64 ticks (tools/)
+  int seq0;  // first sequence of this launch (sub-batches run on their own streams)
 };
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -90,6 +94,8 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
     W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
   }
   W.vcur = B.vcur; W.lds = LDS;
+  W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
+  W.cap = (LDS && B.cap_points > CFEAR_LDS_POINT_CAP) ? CFEAR_LDS_POINT_CAP : B.cap_points;
   W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
   W.red_i = reinterpret_cast<int*>(lds + FeatLds::red_i);
   W.red_f = reinterpret_cast<float*>(lds + FeatLds::red_f);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const flo
 
 __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) idx[i] = scan_closest(S, q[2 * i], q[2 * i + 1], d);
+  if (i < nq) idx[i] = scan_closest(grid_view(S), q[2 * i], q[2 * i + 1], d);
 }
 
 __global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
@@ -160,12 +166,12 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
                                                                 const SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::total];
-  const int q = blockIdx.x;
+  const int q = OP.seq0 + blockIdx.x;
   const SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
   ScanDev* cur = scan_slots[(size_t)q * (OP.submap + 1) + st->free_slot];
   const Aff2 TprevMot = st->Tmot;  // :146
-  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0;
+  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   pt.mark();
   // stage 1 (second half): slots -> cloud (radar_driver.cpp:59)
   const int n = cloud_build_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance, 0,
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  const int q = blockIdx.x, tid = threadIdx.x;
+  const int q = OP.seq0 + blockIdx.x, tid = threadIdx.x;
   SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
   const int nslots = OP.submap + 1;
@@ -193,7 +199,8 @@ __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP,
   ScanDev* cur = my_slots[cur_slot];
   const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
   const int nkf = st->nkf;
-  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 12 : nullptr; pt.n = 0;
+  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
+  pt.acc = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
   pt.mark();
   const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
   cfear_reg_summary* sum = &summaries[q];
@@ -291,7 +298,7 @@ RegParams reg_params(const cfear_ctx* ctx) {
 
 constexpr int GRID_CAP = 128 * 128;
 
-struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, gpts, total; };
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, gpts, rsrc, rtar, total; };
 ScanLayout scan_layout(int cap_points) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
@@ -301,6 +308,8 @@ ScanLayout scan_layout(int cap_points) {
   L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
   L.gorder = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
+  L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
+  L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);
   L.total = o;
   return L;
 }
@@ -317,11 +326,13 @@ ScanDev scan_header(unsigned char* d_base, int cap_points) {
   h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
   h.gorder = reinterpret_cast<int*>(d_base + L.gorder);
   h.gpts = reinterpret_cast<float4*>(d_base + L.gpts);
+  h.rsrc = reinterpret_cast<double*>(d_base + L.rsrc);
+  h.rtar = reinterpret_cast<double*>(d_base + L.rtar);
   h.gcell = 1.f;
   return h;
 }
 
-struct ScratchLayout { size_t keys, spts, order, vstart, vlist, vidx, vcur, samples, tmp, flags, match, assoc, total; int p2cap; bool big; };
+struct ScratchLayout { size_t keys, spts, order, vstart, vlist, vidx, vcur, rng, part, tmpi, samples, tmp, flags, match, assoc, total; int p2cap; bool big; };
 ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   ScratchLayout L;
   int p2 = 1; while (p2 < cap_points) p2 <<= 1;
@@ -336,6 +347,9 @@ ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   L.vlist = o; o = align_up(o + sizeof(int) * cp, 256);
   L.vidx = o; o = align_up(o + sizeof(int) * VOXEL_GRID_CAP, 256);
   L.vcur = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
+  L.rng = o; o = align_up(o + sizeof(int) * 8 * (size_t)cap_points, 256);
+  L.part = o; o = align_up(o + sizeof(double) * 7 * (size_t)cap_points, 256);
+  L.tmpi = o; o = align_up(o + sizeof(int) * (2 * (size_t)cap_points + 16), 256);
   L.samples = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.tmp = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.flags = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
@@ -354,6 +368,9 @@ BlockScratch scratch_header(unsigned char* d_base, int cap_points, int pair_cap)
   B.vlist = reinterpret_cast<int*>(d_base + L.vlist);
   B.vidx = reinterpret_cast<int*>(d_base + L.vidx);
   B.vcur = reinterpret_cast<int*>(d_base + L.vcur);
+  B.rng = reinterpret_cast<int*>(d_base + L.rng);
+  B.part = reinterpret_cast<double*>(d_base + L.part);
+  B.tmpi = reinterpret_cast<int*>(d_base + L.tmpi);
   B.samples = reinterpret_cast<float*>(d_base + L.samples);
   B.tmp = reinterpret_cast<cfear_cell*>(d_base + L.tmp);
   B.flags = reinterpret_cast<int*>(d_base + L.flags);
@@ -390,9 +407,26 @@ struct cfear_odometry {
   uint32_t* d_slots = nullptr;
   uint8_t* d_polar = nullptr;  // staging for step_host
   long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
-  bool profile = false;        // record HIP events around both kernels of every step
-  std::vector<hipEvent_t> events;  // 3 per profiled step
+  // Sub-batches of sequences run filter -> features -> registration on their own streams. A step forks them from
+  // the context stream (input ready) but the context stream only joins them when results are read, so the
+  // sub-batches drift apart over the steps: the HBM-bound filter of one overlaps the latency-bound features /
+  // registration kernels of the others, and partial last rounds of workgroups get filled.
+  int nsub = 1;
+  std::vector<hipStream_t> sub_streams;
+  std::vector<hipEvent_t> sub_done;
+  hipEvent_t fork = nullptr;
+  bool profile = false;        // record HIP events around the filter launches
+  std::vector<hipEvent_t> filter_events;  // 2 per profiled filter launch
 };
+extern int g_cfear_odo_streams, g_cfear_odo_fork;  // kstrongest.hip (cfear_debug_set)
+// make everything the sub-batch streams have been given so far visible to the context stream
+static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
+  for (size_t i = 0; i < o->sub_streams.size(); i++) {
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->sub_done[i], o->sub_streams[i]));
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->sub_done[i], 0));
+  }
+  return CFEAR_OK;
+}
 
 // per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
 static int ensure_ctx_scratch(cfear_ctx* ctx, int cap_points, int pair_cap) {
@@ -440,7 +474,7 @@ int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_clou
   if (cloud_peaks) *cloud_peaks = nullptr;
   int rc = cfear_ensure_staging(ctx, 1);
   if (rc != CFEAR_OK) return rc;
-  rc = cfear_launch_kstrongest(ctx, d_polar, 1, ctx->d_slots);  // radar_driver.cpp:58
+  rc = cfear_launch_kstrongest(ctx, d_polar, 1, ctx->d_slots, ctx->stream);  // radar_driver.cpp:58
   if (rc != CFEAR_OK) return rc;
   const int A = ctx->A, k = ctx->par.k_strongest, cap = A * k;
   for (int peaks = 0; peaks < (cloud_peaks ? 2 : 1); peaks++) {  // radar_driver.cpp:59-60
@@ -646,17 +680,29 @@ int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* pose
 // ---- batched odometry --------------------------------------------------------------------------
 void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   if (!o) return;
-  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    for (hipStream_t st : o->sub_streams) {
+      (void)hipStreamSynchronize(st);
+      for (size_t i = 0; i < ctx->aux_streams.size(); i++)
+        if (ctx->aux_streams[i] == st) { ctx->aux_streams.erase(ctx->aux_streams.begin() + i); break; }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+  }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar, o->d_phase_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (hipEvent_t e : o->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : o->sub_done) (void)hipEventDestroy(e);
+  for (hipStream_t st : o->sub_streams) (void)hipStreamDestroy(st);
+  if (o->fork) (void)hipEventDestroy(o->fork);
   delete o;
 }
 
 int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_reset: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   std::vector<SeqState> st((size_t)o->B);
   for (auto& s : st) {
     memset(&s, 0, sizeof(s));
@@ -711,6 +757,23 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry state upload"); }
   rc = cfear_odometry_reset(ctx, o);
   if (rc != CFEAR_OK) { cfear_odometry_destroy(ctx, o); return rc; }
+  // one stream by default; tools/ can ask for sub-batches (cfear_debug_set key 3), at most 8
+  o->nsub = g_cfear_odo_streams > 0 ? g_cfear_odo_streams : 1;
+  if (o->nsub > 8) o->nsub = 8;
+  if (o->nsub > B) o->nsub = B;
+  if (o->nsub < 1) o->nsub = 1;
+  if (o->nsub > 1) {
+    ok = hipEventCreateWithFlags(&o->fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < o->nsub; i++) {
+      hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+      if (ok) o->sub_streams.push_back(st);
+      ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+      if (ok) o->sub_done.push_back(ev);
+    }
+    if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry stream creation"); }
+    for (hipStream_t st : o->sub_streams) ctx->aux_streams.push_back(st);
+  }
   *out = o;
   return CFEAR_OK;
 }
@@ -719,26 +782,53 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  if (o->profile) {
-    for (int i = 0; i < 3; i++) { CFEAR_HIP_CHECK(ctx, hipEventCreate(&ev[i])); o->events.push_back(ev[i]); }
-    CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[0], ctx->stream));
-  }
-  int rc = cfear_launch_kstrongest(ctx, d_polar, o->B, o->d_slots);  // radar_driver.cpp:58
-  if (rc != CFEAR_OK) return rc;
-  if (o->profile) CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[1], ctx->stream));
   OdoParams OP;
   OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
   OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
   OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
   OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
   OP.phase_times = o->d_phase_times;
-  hipLaunchKernelGGL(features_step_kernel, dim3(o->B), dim3(BLOCK_F), 0, ctx->stream, o->d_slots, ctx->d_trig, OP, o->d_states,
-                     o->d_scan_ptrs, o->d_scratch_hdr);
-  hipLaunchKernelGGL(register_step_kernel, dim3(o->B), dim3(BLOCK_R), 0, ctx->stream, OP, o->d_states, o->d_scan_ptrs,
-                     o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  OP.seq0 = 0;
+  auto timed_event = [&](std::vector<hipEvent_t>& list, hipStream_t st) -> int {
+    hipEvent_t e = nullptr;
+    CFEAR_HIP_CHECK(ctx, hipEventCreate(&e));
+    list.push_back(e);
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(e, st));
+    return CFEAR_OK;
+  };
+  auto launch_filter = [&](int seq0, int count, hipStream_t st) -> int {  // radar_driver.cpp:58
+    int rc = CFEAR_OK;
+    if (o->profile && (rc = timed_event(o->filter_events, st)) != CFEAR_OK) return rc;
+    rc = cfear_launch_kstrongest(ctx, d_polar + (size_t)seq0 * ctx->A * ctx->R, count,
+                                 o->d_slots + (size_t)seq0 * ctx->A * ctx->par.k_strongest, st);
+    if (rc != CFEAR_OK) return rc;
+    if (o->profile && (rc = timed_event(o->filter_events, st)) != CFEAR_OK) return rc;
+    return CFEAR_OK;
+  };
+  auto launch_odometry = [&](int seq0, int count, hipStream_t st) {
+    OdoParams P = OP; P.seq0 = seq0;
+    hipLaunchKernelGGL(features_step_kernel, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
+                       o->d_scan_ptrs, o->d_scratch_hdr);
+    hipLaunchKernelGGL(register_step_kernel, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  };
+  int rc = CFEAR_OK;
+  if (o->nsub <= 1) {
+    if ((rc = launch_filter(0, o->B, ctx->stream)) != CFEAR_OK) return rc;
+    launch_odometry(0, o->B, ctx->stream);
+  } else {
+    if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipEventRecord(o->fork, ctx->stream));  // the sweeps are ready at this point of the context stream
+    const int per = (o->B + o->nsub - 1) / o->nsub;
+    for (int i = 0; i < o->nsub; i++) {
+      const int seq0 = i * per, count = std::min(per, o->B - seq0);
+      if (count <= 0) break;
+      hipStream_t st = o->sub_streams[i];
+      if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(st, o->fork, 0));
+      if ((rc = launch_filter(seq0, count, st)) != CFEAR_OK) return rc;
+      launch_odometry(seq0, count, st);
+    }
+  }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  if (o->profile) CFEAR_HIP_CHECK(ctx, hipEventRecord(ev[2], ctx->stream));
   return CFEAR_OK;
 }
 
@@ -751,6 +841,7 @@ int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, long long* hos
     CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
     return CFEAR_OK;
   }
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (host_ticks) CFEAR_HIP_CHECK(ctx, hipMemcpy(host_ticks, o->d_phase_times, sizeof(long long) * 32 * (size_t)o->B, hipMemcpyDeviceToHost));
   CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
@@ -759,27 +850,27 @@ int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, long long* hos
 
 int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* o, int enable) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile: bad argument");
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (hipEvent_t e : o->events) (void)hipEventDestroy(e);
-  o->events.clear();
+  for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
+  o->filter_events.clear();
   o->profile = enable != 0;
   return CFEAR_OK;
 }
 
-int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filter_seconds, double* odometry_seconds, int* steps) {
+int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filter_seconds, int* filter_launches) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile_read: bad argument");
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  double tf = 0, to = 0;
-  const int n = (int)(o->events.size() / 3);
-  for (int i = 0; i < n; i++) {
-    float a = 0.f, b = 0.f;
-    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&a, o->events[3 * i], o->events[3 * i + 1]));
-    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&b, o->events[3 * i + 1], o->events[3 * i + 2]));
-    tf += a * 1e-3; to += b * 1e-3;
+  double tf = 0;
+  const int nf = (int)(o->filter_events.size() / 2);
+  for (int i = 0; i < nf; i++) {
+    float a = 0.f;
+    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&a, o->filter_events[2 * i], o->filter_events[2 * i + 1]));
+    tf += a * 1e-3;
   }
   if (filter_seconds) *filter_seconds = tf;
-  if (odometry_seconds) *odometry_seconds = to;
-  if (steps) *steps = n;
+  if (filter_launches) *filter_launches = nf;
   return CFEAR_OK;
 }
 
@@ -787,6 +878,7 @@ int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h
   if (!ctx || !o || !h_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_host: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)o->B * ctx->A * ctx->R;
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }  // the staging buffer is reused
   if (!o->d_polar && hipMalloc(&o->d_polar, bytes + 64) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc polar batch");
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->d_polar, h_polar, bytes, hipMemcpyHostToDevice, ctx->stream));
   return cfear_odometry_step_device(ctx, o, o->d_polar);
@@ -795,6 +887,7 @@ int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {
   if (!ctx || !o || !poses_xyt) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_poses: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, o->d_poses_out, sizeof(double) * 3 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
@@ -804,6 +897,7 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfea
                            int* n_keyframes) {
   if (!ctx || !o || sequence < 0 || sequence >= o->B) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_summary: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpy(summary, o->d_summaries + sequence, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost));
   if (n_cells || n_keyframes) {

@@ -110,6 +110,7 @@ struct NormalEq { double cost, g0, g1, g2, h00, h01, h02, h11, h12, h22; };
 struct SolveSummary { int num_iterations; int termination; double final_cost; double last_relative_decrease; };
 
 #define CFEAR_REG_MAX_SCANS 64
+#define CFEAR_RED_STRIDE 8  // partial sums of up to 8 waves per quantity (W.red)
 #define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
 
 enum { REG_CMD_BUILD = 1, REG_CMD_EVAL = 2, REG_CMD_DONE = 3 };
@@ -124,6 +125,7 @@ struct RegShared {
   double c, s;  // cos/sin of x[2], computed once by the controller
   double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
   double Trel[CFEAR_REG_MAX_SCANS][6];  // Ttar^-1 * Tsrc (n_scan_normal.cpp:224)
+  GridView kf[CFEAR_REG_MAX_SCANS];      // 1-NN search view of every scan (filled once per Register call)
   // ---- controller state: outer association loop (n_scan_normal.cpp:82-187)
   int success, nres, ret, pad0;
   double xcur[3], prev_par[3], tsrc_last[3], prev_score;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
   for (int i = 0; i < 10; i++) v[i] = wave_sum_dpp(v[i]);
   if (lane_id() == 0) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) W.red[i * 32 + wave] = v[i];
+    for (int i = 0; i < 10; i++) W.red[i * CFEAR_RED_STRIDE + wave] = v[i];
   }
 }
 template <int COST>
@@ -226,7 +228,7 @@ __device__ inline NormalEq gather_partials(const RegScratch& W) {
 #pragma unroll
   for (int i = 0; i < 10; i++) {
     double t = 0;
-    for (int j = 0; j < nw; j++) t += W.red[i * 32 + j];
+    for (int j = 0; j < nw; j++) t += W.red[i * CFEAR_RED_STRIDE + j];
     r[i] = t;
   }
   NormalEq o;
@@ -249,18 +251,33 @@ __device__ inline bool chol3_solve(const double A[6], const double b[3], double 
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
+// the association's view of a cell (ScanDev::rsrc / rtar)
+struct RCell { double mx, my, nx, ny, ns, scale; };
+__device__ __forceinline__ RCell rcell_src(const ScanDev* S, int j) {  // consecutive lanes read consecutive cells
+  const size_t cc = (size_t)S->cap_cells;
+  const double* r = S->rsrc + j;
+  RCell c; c.mx = r[0]; c.my = r[cc]; c.nx = r[2 * cc]; c.ny = r[3 * cc]; c.ns = r[4 * cc]; c.scale = r[5 * cc];
+  return c;
+}
+__device__ __forceinline__ RCell rcell_tar(const ScanDev* S, int ti) {  // one 64-byte record, three 16-byte loads
+  const double2* r = reinterpret_cast<const double2*>(S->rtar + 8 * (size_t)ti);
+  const double2 a = r[0], b = r[1], c2 = r[2];
+  RCell c; c.mx = a.x; c.my = a.y; c.nx = b.x; c.ny = b.y; c.ns = c2.x; c.scale = c2.y;
+  return c;
+}
+
 // one match record (AddScanPairCost :266-320) written at position o of the destination SoA
 __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const RegParams& P, const double* T, const double* Tt,
-                                            const cfear_cell* cs, const cfear_cell* ct) {
-  const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
-  const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
-  const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
-  m.w[o] = get_weight(P.weight_opt, (double)cs->nsamples, (double)ct->nsamples, sim, cs->scale, ct->scale);
-  m.tmx[o] = (Tt[0] * ct->mean[0] + Tt[1] * ct->mean[1]) + Tt[4];
-  m.tmy[o] = (Tt[2] * ct->mean[0] + Tt[3] * ct->mean[1]) + Tt[5];
-  m.sx[o] = cs->mean[0]; m.sy[o] = cs->mean[1];
+                                            const RCell& cs, const RCell& ct, const cfear_cell* ct_full) {
+  const double nx = T[0] * cs.nx + T[1] * cs.ny;
+  const double ny = T[2] * cs.nx + T[3] * cs.ny;
+  const double sim = fmax(nx * ct.nx + ny * ct.ny, 0.0);
+  m.w[o] = get_weight(P.weight_opt, cs.ns, ct.ns, sim, cs.scale, ct.scale);
+  m.tmx[o] = (Tt[0] * ct.mx + Tt[1] * ct.my) + Tt[4];
+  m.tmy[o] = (Tt[2] * ct.mx + Tt[3] * ct.my) + Tt[5];
+  m.sx[o] = cs.mx; m.sy[o] = cs.my;
   if (P.cost == CFEAR_COST_P2D) {  // :290-299
-    const double a = ct->cov[0], b = ct->cov[1], c = ct->cov[2];
+    const double a = ct_full->cov[0], b = ct_full->cov[1], c = ct_full->cov[2];
     const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
     const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
     const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
@@ -274,59 +291,94 @@ __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const Reg
     const double l11 = sqrt(i11 - l10 * l10);
     m.a0[o] = l00; m.a1[o] = l10; m.a2[o] = l11;
   } else {
-    m.a0[o] = Tt[0] * ct->normal[0] + Tt[1] * ct->normal[1];
-    m.a1[o] = Tt[2] * ct->normal[0] + Tt[3] * ct->normal[1];
+    m.a0[o] = Tt[0] * ct.nx + Tt[1] * ct.ny;
+    m.a1[o] = Tt[2] * ct.nx + Tt[3] * ct.ny;
     m.a2[o] = 0;
   }
 }
 
+// association of one (keyframe i, source cell j) pair (n_scan_normal.cpp:228-247): index of the matched target
+// cell or -1. Out of line: the kernel's register budget is the maximum over its callees.
+__device__ __noinline__ int associate_pair(const ScanDev* src, const RegShared* sh, int nsrc, int p, double curr_radius) {
+  const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
+  const int i = p / nsrc, j = p - i * nsrc;
+  const double* T = sh->Trel[i];
+  const size_t cc = (size_t)src->cap_cells;
+  const double* rs = src->rsrc + j;
+  const double mx = rs[0], my = rs[cc];
+  const double snx = rs[2 * cc], sny = rs[3 * cc];
+  const double qx = (T[0] * mx + T[1] * my) + T[4];
+  const double qy = (T[2] * mx + T[3] * my) + T[5];
+  int ti = scan_closest(sh->kf[i], qx, qy, curr_radius);
+  if (ti >= 0) {
+    const double2 tn = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti)[1];
+    const double nx = T[0] * snx + T[1] * sny;
+    const double ny = T[2] * snx + T[3] * sny;
+    const double sim = fmax(nx * tn.x + ny * tn.y, 0.0);
+    if (!(sim > angle_outlier)) ti = -1;  // :247
+  }
+  return ti;
+}
+__device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, const RegParams& P,
+                                        const RegScratch& W, int nsrc, int p, int ti, int o, bool use_lds) {
+  const int i = p / nsrc, j = p - i * nsrc;
+  const RCell cs = rcell_src(src, j);
+  const RCell ct = rcell_tar(scans[i], ti);
+  const cfear_cell* ctf = &scans[i]->cells[ti];
+  if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
+  else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
+}
+
 // AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
-// Transforms come precomputed from the controller (sh->Ttar, sh->Trel). All threads; returns the number of
-// matches, compacted in reference residual-block order into the LDS match array if they fit, else into
-// W's global arrays. (A four-keyframes-at-a-time variant with batched bucket loads measured slower end to
-// end: it needs 248 VGPRs and halves the number of resident workgroups.)
+// Transforms and 1-NN grid views come from the controller (sh->Ttar, sh->Trel, sh->kf). All threads; returns the
+// number of matches, compacted in reference residual-block order (pair index ascending) into the LDS match array
+// if they fit, else into W's global arrays. Pairs are dealt round-robin (pair p -> thread p mod blockDim), so
+// the source-cell reads of a wave are contiguous; one packed scan of four 16-bit counters orders the matches.
 __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, const RegParams& P, int itr,
                                                 const RegScratch& W) {
-  const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
-  const int ipt = (pairs + blockDim.x - 1) / blockDim.x;
-  const int p0 = threadIdx.x * ipt, p1 = min(pairs, p0 + ipt);
-  int cnt = 0;
-  for (int p = p0; p < p1; p++) {
-    const int i = p / nsrc, j = p - i * nsrc;
-    const double* T = sh->Trel[i];
-    const cfear_cell* cs = &src->cells[j];
-    const double mx = cs->mean[0], my = cs->mean[1];
-    const double qx = (T[0] * mx + T[1] * my) + T[4];
-    const double qy = (T[2] * mx + T[3] * my) + T[5];
-    int ti = scan_closest(scans[i], qx, qy, curr_radius);
-    if (ti >= 0) {
-      const cfear_cell* ct = &scans[i]->cells[ti];
-      const double nx = T[0] * cs->normal[0] + T[1] * cs->normal[1];
-      const double ny = T[2] * cs->normal[0] + T[3] * cs->normal[1];
-      const double sim = fmax(nx * ct->normal[0] + ny * ct->normal[1], 0.0);
-      if (!(sim > angle_outlier)) ti = -1;  // :247
-    }
-    W.assoc[p] = ti;
-    cnt += (ti >= 0) ? 1 : 0;
-  }
+  const int nt = blockDim.x, tid = threadIdx.x;
   int M;
-  int o = block_exclusive_scan(cnt, W.red_i, &M);
-  const bool use_lds = M <= CFEAR_MATCH_LDS_CAP;
-  for (int p = p0; p < p1; p++) {
-    const int ti = W.assoc[p];
-    if (ti < 0) continue;
-    const int i = p / nsrc, j = p - i * nsrc;
-    const cfear_cell* cs = &src->cells[j];
-    const cfear_cell* ct = &scans[i]->cells[ti];
-    if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, sh->Trel[i], sh->Ttar[i], cs, ct);
-    else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, sh->Trel[i], sh->Ttar[i], cs, ct);
-    o++;
+  bool use_lds;
+  if (pairs <= 4 * nt) {
+    int ti[4];
+    unsigned long long c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int p = r * nt + tid;
+      ti[r] = (p < pairs) ? associate_pair(src, sh, nsrc, p, curr_radius) : -1;
+      c |= (unsigned long long)(ti[r] >= 0 ? 1 : 0) << (16 * r);
+    }
+    unsigned long long tot;
+    const unsigned long long ex = block_exclusive_scan64(c, reinterpret_cast<unsigned long long*>(W.red), &tot);
+    M = (int)((tot & 0xFFFF) + ((tot >> 16) & 0xFFFF) + ((tot >> 32) & 0xFFFF) + ((tot >> 48) & 0xFFFF));
+    use_lds = M <= CFEAR_MATCH_LDS_CAP;
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (ti[r] >= 0) emit_match(scans, src, sh, P, W, nsrc, r * nt + tid, ti[r], base + (int)((ex >> (16 * r)) & 0xFFFF), use_lds);
+      base += (int)((tot >> (16 * r)) & 0xFFFF);
+    }
+  } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
+    const int ipt = (pairs + nt - 1) / nt;
+    const int p0 = tid * ipt, p1 = min(pairs, p0 + ipt);
+    int cnt = 0;
+    for (int p = p0; p < p1; p++) {
+      const int ti = associate_pair(src, sh, nsrc, p, curr_radius);
+      W.assoc[p] = ti;
+      cnt += (ti >= 0) ? 1 : 0;
+    }
+    int o = block_exclusive_scan(cnt, W.red_i, &M);
+    use_lds = M <= CFEAR_MATCH_LDS_CAP;
+    for (int p = p0; p < p1; p++) {
+      const int ti = W.assoc[p];
+      if (ti >= 0) emit_match(scans, src, sh, P, W, nsrc, p, ti, o++, use_lds);
+    }
   }
-  if (threadIdx.x == 0) sh->lds_match = use_lds ? 1 : 0;
+  if (tid == 0) sh->lds_match = use_lds ? 1 : 0;
   __syncthreads();
   return M;
 }
@@ -563,6 +615,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     double v[3]; aff_to_xyt(T, v);
     par_lds[3 * i] = v[0]; par_lds[3 * i + 1] = v[1]; par_lds[3 * i + 2] = v[2];
   }
+  for (int i = tid; i < n; i += blockDim.x) sh->kf[i] = grid_view(scans[i]);
   if (tid == 0 && out) {
     out->success = 0; out->usable = 0; out->outer_iterations = 0; out->num_residuals = 0; out->num_residual_blocks = 0;
     out->reserved = 0; out->final_cost = 0; out->score = 0;

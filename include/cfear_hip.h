@@ -162,7 +162,10 @@ typedef struct cfear_odometry cfear_odometry;
 int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** odo);
 void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* odo);
 int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* odo);
-/* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous. */
+/* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous: the sweeps must be ready at this
+ * point of the context stream; the work itself runs on internal streams (one per sub-batch of sequences) that the
+ * context stream joins only in the reading calls below (poses / summary / profile_read / reset / step_host) and in
+ * cfear_synchronize(). Keep d_polar valid and unmodified until one of those has returned. */
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_polar);
 int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_polar);
 /* Tcurrent of every sequence as (x, y, theta); synchronises the stream. */
@@ -171,11 +174,11 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt)
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);
 
-/* Per-step kernel timing with HIP events recorded on the context stream: enable, run steps, read the
- * accumulated seconds of the filter kernel and of the odometry kernel (bench.py roofline leg). */
+/* Filter-kernel timing with HIP events (bench.py roofline leg): enable, run steps, read. filter_seconds is the sum
+ * of the durations of the filter launches, each measured on the stream it ran on (a step launches the filter once
+ * per sub-batch of sequences). */
 int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* odo, int enable);
-int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* odo, double* filter_seconds, double* odometry_seconds,
-                                int* steps);
+int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* odo, double* filter_seconds, int* filter_launches);
 
 /* Timing hook used by bench.py: seconds of the filter kernel measured with HIP events on the
  * context stream over `iters` launches (after `warmup`). */
