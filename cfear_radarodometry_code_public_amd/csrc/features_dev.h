@@ -428,74 +428,66 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   __syncthreads();
   if (pt) pt->mark();
-  for (int v = tid; v < nv; v += nt) {
-    cfear_cell* c = &W.tmp[v];
-    double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
-    {
-      const size_t cs = (size_t)W.cap;
-      for (int w = W.vstart[v]; w < W.vstart[v + 1]; w++) {
-        md += W.part[w]; s0 += W.part[cs + w]; s1x += W.part[2 * cs + w]; s1y += W.part[3 * cs + w];
-        sxx += W.part[4 * cs + w]; sxy += W.part[5 * cs + w]; syy += W.part[6 * cs + w];
-      }
-    }
-    const int m = (int)md;
-    c->nsamples = m;
-    c->valid = 0;
-    int valid = 0;
-    if (m >= 6) {  // :291
-      const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
-      const double m1x = s1x / s0, m1y = s1y / s0;
-      const double ux = (double)cx + m1x, uy = (double)cy + m1y;
-      const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
-      double lmin, lmax, vmin[2], vmax[2];
-      eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
-      const double cond = fabs(lmax / lmin);  // :53
-      const double det = lmax * lmin;         // :54
-      valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
-      if (valid) {
-        if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
-        c->mean[0] = ux; c->mean[1] = uy;
-        c->cov[0] = cxx; c->cov[1] = cyx; c->cov[2] = cyy;
-        c->normal[0] = vmin[0]; c->normal[1] = vmin[1];
-        c->orth[0] = vmax[0]; c->orth[1] = vmax[1];
-        c->lambda_min = lmin; c->lambda_max = lmax;
-        c->scale = log(1.0 + cond / 2);  // :57
-        c->sum_intensity = s0; c->avg_intensity = s0 / m;
-        c->valid = 1;
-      }
-    }
-    W.flags[v] = valid;
-  }
-  __syncthreads();
-  if (pt) pt->mark();
-  // ---- keep valid cells in sample order (pointnormal.cpp:292-294) ----
+  // ---- cell epilogue + compaction: a cell is built in registers and, if it is valid, written straight to
+  // its final slot; one block scan per round of blockDim samples keeps the sample order (pointnormal.cpp:292-294)
   {
-    const int ipt = (nv + nt - 1) / nt;
-    const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
-    int cnt = 0;
-    for (int i = i0; i < i1; i++) cnt += W.flags[i];
-    int nc;
-    int o = block_exclusive_scan(cnt, W.red_i, &nc);
-    for (int i = i0; i < i1; i++)
-      if (W.flags[i] && o < S->cap_cells) {
-        const cfear_cell c = W.tmp[i];
+    int base = 0;
+    const int cap_cells = S->cap_cells;
+    for (int v0 = 0; v0 < nv; v0 += nt) {
+      const int v = v0 + tid;
+      cfear_cell c;
+      int valid = 0;
+      if (v < nv) {
+        double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
+        const size_t cs = (size_t)W.cap;
+        for (int w = W.vstart[v]; w < W.vstart[v + 1]; w++) {
+          md += W.part[w]; s0 += W.part[cs + w]; s1x += W.part[2 * cs + w]; s1y += W.part[3 * cs + w];
+          sxx += W.part[4 * cs + w]; sxy += W.part[5 * cs + w]; syy += W.part[6 * cs + w];
+        }
+        const int m = (int)md;
+        if (m >= 6) {  // :291
+          const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+          const double m1x = s1x / s0, m1y = s1y / s0;
+          const double ux = (double)cx + m1x, uy = (double)cy + m1y;
+          const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
+          double lmin, lmax, vmin[2], vmax[2];
+          eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
+          const double cond = fabs(lmax / lmin);  // :53
+          const double det = lmax * lmin;         // :54
+          valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
+          if (valid) {
+            if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
+            c.mean[0] = ux; c.mean[1] = uy;
+            c.cov[0] = cxx; c.cov[1] = cyx; c.cov[2] = cyy;
+            c.normal[0] = vmin[0]; c.normal[1] = vmin[1];
+            c.orth[0] = vmax[0]; c.orth[1] = vmax[1];
+            c.lambda_min = lmin; c.lambda_max = lmax;
+            c.scale = log(1.0 + cond / 2);  // :57
+            c.sum_intensity = s0; c.avg_intensity = s0 / m;
+            c.nsamples = m; c.valid = 1;
+          }
+        }
+      }
+      int round_total;
+      const int o = base + block_exclusive_scan(valid, W.red_i, &round_total);
+      if (valid && o < cap_cells) {
         S->cells[o] = c;
         S->mean_f[2 * o] = (float)c.mean[0];
         S->mean_f[2 * o + 1] = (float)c.mean[1];
-        {
-          const size_t cc = (size_t)S->cap_cells;
-          double* rs = S->rsrc + o;
-          rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
-          rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
-          double2* rt = reinterpret_cast<double2*>(S->rtar + 8 * (size_t)o);
-          rt[0] = make_double2(c.mean[0], c.mean[1]); rt[1] = make_double2(c.normal[0], c.normal[1]);
-          rt[2] = make_double2((double)c.nsamples, c.scale);
-        }
-        o++;
+        const size_t cc = (size_t)cap_cells;
+        double* rs = S->rsrc + o;
+        rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
+        rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
+        double2* rt = reinterpret_cast<double2*>(S->rtar + 8 * (size_t)o);
+        rt[0] = make_double2(c.mean[0], c.mean[1]); rt[1] = make_double2(c.normal[0], c.normal[1]);
+        rt[2] = make_double2((double)c.nsamples, c.scale);
       }
-    if (tid == 0) S->n_cells = nc < S->cap_cells ? nc : S->cap_cells;
+      base += round_total;
+    }
+    if (tid == 0) S->n_cells = base < cap_cells ? base : cap_cells;
     __syncthreads();
   }
+  if (pt) pt->mark();
   if (pt) pt->mark();
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
   const int nc = S->n_cells;
