@@ -126,6 +126,53 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
   __syncthreads();
 }
 
+// cloud_build_block + compensate_block + the bounding box the voxel grid needs, in one pass over the slots
+// (batched odometry step). bounds = {min x, max x, min y, max y} of the final points.
+__device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
+                                       float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
+                                       double m0, double m1, double m2, int ccw, int* red_i, float* red_f, float bounds[4]) {
+  const double range_res = (double)range_res_f;
+  const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // radar_filters.cpp:315
+  const double range_res_half = range_res / 2.0;
+  const int items = A * k;
+  const int ipt = (items + blockDim.x - 1) / blockDim.x;
+  const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) {
+    const uint32_t s = slots[i];
+    cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
+  }
+  int total;
+  int o = block_exclusive_scan(cnt, red_i, &total);
+  float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+  for (int i = i0; i < i1; i++) {
+    const uint32_t s = slots[i];
+    const int range = CFEAR_SLOT_RANGE(s);
+    if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
+      const int b = i / k;
+      const double rad = range_res_half + range_res * range;
+      float x = (float)(rad * trig[2 * b]);      // :329
+      float y = (float)(rad * trig[2 * b + 1]);  // :330
+      if (compensate) {  // utils.cpp:96-107, utils.h:28-32
+        const double px = (double)x, py = (double)y;
+        const double a = atan2(py, px);
+        const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+        const double s1 = sin(d * m2), c1 = cos(d * m2);
+        x = (float)((c1 * px + (-s1) * py) + d * m0);
+        y = (float)((s1 * px + c1 * py) + d * m1);
+      }
+      xyi[3 * o + 0] = x; xyi[3 * o + 1] = y; xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
+      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+      o++;
+    }
+  }
+  bounds[0] = block_min(mnx, red_f); bounds[1] = block_max(mxx, red_f);
+  bounds[2] = block_min(mny, red_f); bounds[3] = block_max(mxy, red_f);
+  __syncthreads();
+  return total < cap ? total : cap;
+}
+
 // closed-form symmetric 2x2 eigen-decomposition; identical formulas to the oracle's eig2()
 __device__ inline void eig2(double a, double b, double c, double* lmin, double* lmax, double vmin[2], double vmax[2]) {
   const double t1 = 0.5 * (a + c);
@@ -180,7 +227,7 @@ __device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, i
 // MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi.
 // p2 = power of two >= n with p2 <= capacity of W.keys.
 __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2,
-                                      PhaseTimer* pt = nullptr) {
+                                      PhaseTimer* pt = nullptr, const float* bounds = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const float* __restrict__ xyi = S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
@@ -192,12 +239,16 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const float leaf = (float)((double)P.radius / P.downsample_factor);
   const float inv = 1.0f / leaf;
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
-  for (int i = tid; i < n; i += nt) {
-    const float x = xyi[3 * i], y = xyi[3 * i + 1];
-    mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+  if (bounds) {  // block-uniform: the caller already knows the bounding box
+    mnx = bounds[0]; mxx = bounds[1]; mny = bounds[2]; mxy = bounds[3];
+  } else {
+    for (int i = tid; i < n; i += nt) {
+      const float x = xyi[3 * i], y = xyi[3 * i + 1];
+      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    mnx = block_min(mnx, W.red_f); mxx = block_max(mxx, W.red_f);
+    mny = block_min(mny, W.red_f); mxy = block_max(mxy, W.red_f);
   }
-  mnx = block_min(mnx, W.red_f); mxx = block_max(mxx, W.red_f);
-  mny = block_min(mny, W.red_f); mxy = block_max(mxy, W.red_f);
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;

@@ -102,13 +102,13 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   return W;
 }
 __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
-                                                  unsigned char* lds, PhaseTimer* pt) {
+                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds = nullptr) {
   if (n <= CFEAR_LDS_POINT_CAP) {  // block-uniform
     const FeatureScratch W = make_fscratch<true>(B, lds);
-    features_block(S, n, P, W, next_pow2(n), pt);
+    features_block(S, n, P, W, next_pow2(n), pt, bounds);
   } else {
     const FeatureScratch W = make_fscratch<false>(B, lds);
-    features_block(S, n, P, W, next_pow2(n), pt);
+    features_block(S, n, P, W, next_pow2(n), pt, bounds);
   }
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
@@ -173,16 +173,15 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   const Aff2 TprevMot = st->Tmot;  // :146
   PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   pt.mark();
-  // stage 1 (second half): slots -> cloud (radar_driver.cpp:59)
-  const int n = cloud_build_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance, 0,
-                                  cur->xyi, cur->cap_points, reinterpret_cast<int*>(lds + FeatLds::red_i));
+  // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
+  double mot[3]; aff_to_xyt(TprevMot, mot);
+  float bounds[4];
+  const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
+                                 cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
+                                 reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f), bounds);
   pt.mark();
-  if (OP.compensate) {  // :147-150
-    double mot[3]; aff_to_xyt(TprevMot, mot);
-    compensate_block(cur->xyi, n, mot[0], mot[1], mot[2], OP.ccw);
-  }
   pt.mark();
-  features_dispatch(cur, n, OP.fp, B, lds, &pt);  // :161
+  features_dispatch(cur, n, OP.fp, B, lds, &pt, n > 0 ? bounds : nullptr);  // :161
 }
 
 __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
