@@ -169,8 +169,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "kstrongest_kernel<4,8>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": ALGO_BYTES_PER_SCAN * scans_per_launch, "avg_launch_us": filt * 1e6,
-                         "launches_per_step": launches_per_step,
-                         "note": "filter launches of one sub-batch run concurrently with the features/registration kernels of the others"},
+                         "launches_per_step": launches_per_step},
             "kernels": {"kstrongest_launch_us": filt * 1e6, "kstrongest_launches": n_filter},
             "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,
                       "pose_seq0": [float(x) for x in poses[0]], "datagen_s": t_gen},
