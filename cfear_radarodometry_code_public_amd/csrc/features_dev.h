@@ -158,7 +158,8 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
         const double a = atan2(py, px);
         const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
         const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-        const double s1 = sin(d * m2), c1 = cos(d * m2);
+        double s1, c1;
+        sincos(d * m2, &s1, &c1);
         x = (float)((c1 * px + (-s1) * py) + d * m0);
         y = (float)((s1 * px + c1 * py) + d * m1);
       }

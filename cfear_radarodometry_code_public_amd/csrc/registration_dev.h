@@ -236,18 +236,21 @@ __device__ inline NormalEq gather_partials(const RegScratch& W) {
   return o;
 }
 
+// 3x3 Cholesky solve. The triangular solves multiply by reciprocal square roots of the pivots instead of dividing
+// (three rsqrt instead of three sqrt + nine divisions on the controller's serial chain; differs from the oracle's
+// division form by a few ulp).
 __device__ inline bool chol3_solve(const double A[6], const double b[3], double y[3]) {
   const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
   if (!(a00 > 0)) return false;
-  const double l00 = sqrt(a00), l10 = a01 / l00, l20 = a02 / l00;
+  const double r0 = rsqrt(a00), l10 = a01 * r0, l20 = a02 * r0;
   const double d1 = a11 - l10 * l10;
   if (!(d1 > 0)) return false;
-  const double l11 = sqrt(d1), l21 = (a12 - l20 * l10) / l11;
+  const double r1 = rsqrt(d1), l21 = (a12 - l20 * l10) * r1;
   const double d2 = a22 - l20 * l20 - l21 * l21;
   if (!(d2 > 0)) return false;
-  const double l22 = sqrt(d2);
-  const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
-  y[2] = z2 / l22; y[1] = (z1 - l21 * y[2]) / l11; y[0] = (z0 - l10 * y[1] - l20 * y[2]) / l00;
+  const double r2 = rsqrt(d2);
+  const double z0 = b[0] * r0, z1 = (b[1] - l10 * z0) * r1, z2 = (b[2] - l20 * z0 - l21 * z1) * r2;
+  y[2] = z2 * r2; y[1] = (z1 - l21 * y[2]) * r1; y[0] = (z0 - l10 * y[1] - l20 * y[2]) * r0;
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
@@ -497,8 +500,9 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
       sh->dg1 = fmin(fmax(Hs[3], min_lm_diagonal), max_lm_diagonal);
       sh->dg2 = fmin(fmax(Hs[5], min_lm_diagonal), max_lm_diagonal);
     }
-    const double lm0 = sqrt(sh->dg0 / sh->radius), lm1 = sqrt(sh->dg1 / sh->radius), lm2 = sqrt(sh->dg2 / sh->radius);
-    const double Am[6] = {Hs[0] + lm0 * lm0, Hs[1], Hs[2], Hs[3] + lm1 * lm1, Hs[4], Hs[5] + lm2 * lm2};
+    // D^T D of the LM diagonal D = sqrt(diag / radius): the square root is squared again, so it is left out
+    const double inv_radius = 1.0 / sh->radius;
+    const double Am[6] = {Hs[0] + sh->dg0 * inv_radius, Hs[1], Hs[2], Hs[3] + sh->dg1 * inv_radius, Hs[4], Hs[5] + sh->dg2 * inv_radius};
     const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
     double y[3];
     bool valid = chol3_solve(Am, rhs, y);
