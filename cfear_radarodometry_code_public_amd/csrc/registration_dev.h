@@ -75,33 +75,35 @@ __device__ inline double get_weight(int opt, double n1, double n2, double sim, d
 
 #define CFEAR_DBL_MIN 2.2250738585072014e-308
 // ceres::LossFunction::Evaluate restatement (registration.cpp:78-97)
-__device__ __noinline__ void loss_eval(int loss, double a, double s, double rho[3]) {
+struct Rho { double v, d1; };  // rho(s), rho'(s), returned in registers
+__device__ __noinline__ Rho loss_eval(int loss, double a, double s) {
   const double b = a * a;
+  Rho o;
   switch (loss) {
     case CFEAR_LOSS_HUBER:
-      if (s > b) { const double r = sqrt(s); rho[0] = 2.0 * a * r - b; rho[1] = fmax(CFEAR_DBL_MIN, a / r); rho[2] = -rho[1] / (2.0 * s); }
-      else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
-      return;
+      if (s > b) { const double r = sqrt(s); o.v = 2.0 * a * r - b; o.d1 = fmax(CFEAR_DBL_MIN, a / r); }
+      else { o.v = s; o.d1 = 1.0; }
+      return o;
     case CFEAR_LOSS_CAUCHY: {
       const double c = 1.0 / b, sum = 1.0 + s * c, inv = 1.0 / sum;
-      rho[0] = b * log(sum); rho[1] = fmax(CFEAR_DBL_MIN, inv); rho[2] = -c * (inv * inv);
-      return; }
+      o.v = b * log(sum); o.d1 = fmax(CFEAR_DBL_MIN, inv);
+      return o; }
     case CFEAR_LOSS_SOFTLONE: {
       const double c = 1.0 / b, sum = 1.0 + s * c, tmp = sqrt(sum);
-      rho[0] = 2.0 * b * (tmp - 1.0); rho[1] = fmax(CFEAR_DBL_MIN, 1.0 / tmp); rho[2] = -(c * rho[1]) / (2.0 * sum);
-      return; }
+      o.v = 2.0 * b * (tmp - 1.0); o.d1 = fmax(CFEAR_DBL_MIN, 1.0 / tmp);
+      return o; }
     case CFEAR_LOSS_TUKEY:
-      if (s <= b) { const double v = 1.0 - s / b, v2 = v * v; rho[0] = b / 3.0 * (1.0 - v2 * v); rho[1] = v2; rho[2] = -2.0 / b * v; }
-      else { rho[0] = b / 3.0; rho[1] = 0.0; rho[2] = 0.0; }
-      return;
+      if (s <= b) { const double v = 1.0 - s / b, v2 = v * v; o.v = b / 3.0 * (1.0 - v2 * v); o.d1 = v2; }
+      else { o.v = b / 3.0; o.d1 = 0.0; }
+      return o;
     case CFEAR_LOSS_COMBINED: {
-      double g[3], f[3];
-      { const double sum = 1.0 + s, inv = 1.0 / sum; g[0] = log(sum); g[1] = fmax(CFEAR_DBL_MIN, inv); g[2] = -(inv * inv); }
-      if (g[0] > 1.0) { const double r = sqrt(g[0]); f[0] = 2.0 * r - 1.0; f[1] = fmax(CFEAR_DBL_MIN, 1.0 / r); f[2] = -f[1] / (2.0 * g[0]); }
-      else { f[0] = g[0]; f[1] = 1.0; f[2] = 0.0; }
-      rho[0] = f[0]; rho[1] = f[1] * g[1]; rho[2] = f[2] * g[1] * g[1] + f[1] * g[2];
-      return; }
-    default: rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return;
+      double g0, g1, f0, f1;
+      { const double sum = 1.0 + s, inv = 1.0 / sum; g0 = log(sum); g1 = fmax(CFEAR_DBL_MIN, inv); }
+      if (g0 > 1.0) { const double r = sqrt(g0); f0 = 2.0 * r - 1.0; f1 = fmax(CFEAR_DBL_MIN, 1.0 / r); }
+      else { f0 = g0; f1 = 1.0; }
+      o.v = f0; o.d1 = f1 * g1;
+      return o; }
+    default: o.v = s; o.d1 = 1.0; return o;
   }
 }
 
@@ -158,11 +160,17 @@ template <bool LDS, int COST>
 __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
   const int wave = threadIdx.x >> 6;
   if (wave >= CFEAR_EVAL_WAVES) return;
-  const MatchPtrs m = LDS ? match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP) : match_ptrs(W.tmx, (size_t)W.cap);
+  // the LDS variant reads through an LDS-typed pointer (ds_read); a generic pointer costs flat loads
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  struct Rd {
+    lds_cdouble* l; const double* g; size_t cap;
+    __device__ __forceinline__ double operator()(int arr, int i) const { return LDS ? l[arr * CFEAR_MATCH_LDS_CAP + i] : g[arr * cap + i]; }
+  } rd;
+  rd.l = (lds_cdouble*)lds_match_base(); rd.g = W.tmx; rd.cap = (size_t)W.cap;
   const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < M; i += nthr) {
-    const double sx = m.sx[i], sy = m.sy[i], tmx = m.tmx[i], tmy = m.tmy[i], wgt = m.w[i];
+  for (int i = threadIdx.x; i < M; i += nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
+    const double sx = rd(5, i), sy = rd(6, i), tmx = rd(0, i), tmy = rd(1, i), wgt = rd(7, i);
     const double px = (c * sx - s * sy) + x0;
     const double py = (s * sx + c * sy) + x1;
     const double dtx = -s * sx - c * sy;
@@ -170,13 +178,13 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     double r[2], J[2][3];
     int nr;
     if (COST == CFEAR_COST_P2L) {
-      const double nx = m.a0[i], ny = m.a1[i];
+      const double nx = rd(2, i), ny = rd(3, i);
       nr = 1;
       r[0] = (px - tmx) * nx + (py - tmy) * ny;
       J[0][0] = nx; J[0][1] = ny; J[0][2] = dtx * nx + dty * ny;
       r[1] = 0; J[1][0] = J[1][1] = J[1][2] = 0;
     } else if (COST == CFEAR_COST_P2D) {
-      const double l00 = m.a0[i], l10 = m.a1[i], l11 = m.a2[i];
+      const double l00 = rd(2, i), l10 = rd(3, i), l11 = rd(4, i);
       nr = 2;
       const double dx = px - tmx, dy = py - tmy;
       r[0] = l00 * dx; r[1] = l10 * dx + l11 * dy;
@@ -190,11 +198,9 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     }
     double sq = r[0] * r[0];
     if (nr == 2) sq += r[1] * r[1];
-    double rho[3];
-    loss_eval(P.loss, P.loss_limit, sq, rho);
-    rho[0] *= wgt; rho[1] *= wgt;  // ScaledLoss (n_scan_normal.cpp:277)
-    a.cost += 0.5 * rho[0];
-    const double sr = sqrt(rho[1]);
+    const Rho rho = loss_eval(P.loss, P.loss_limit, sq);  // rho'' <= 0 for every loss here: the corrector's alpha is 0
+    a.cost += 0.5 * (rho.v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
+    const double sr = sqrt(rho.d1 * wgt);
     for (int k = 0; k < nr; k++) {
       const double rk = sr * r[k];
       const double j0 = sr * J[k][0], j1 = sr * J[k][1], j2 = sr * J[k][2];
