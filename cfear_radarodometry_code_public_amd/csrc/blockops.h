@@ -53,6 +53,19 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
   for (int i = 1; i < nw; i++) r = fmaxf(r, scratch[i]);
   return r;
 }
+// bounding box in one go: v = {min x, max x, min y, max y} per thread -> block-wide values in every thread.
+// scratch: >= 4 * 32 floats... uses 4 floats per wave (<= 16 waves -> 64 floats).
+__device__ __forceinline__ void block_bounds(float v[4], float* scratch) {
+  v[0] = wave_min(v[0]); v[1] = wave_max(v[1]); v[2] = wave_min(v[2]); v[3] = wave_max(v[3]);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane_id() == 0) { scratch[4 * w] = v[0]; scratch[4 * w + 1] = v[1]; scratch[4 * w + 2] = v[2]; scratch[4 * w + 3] = v[3]; }
+  __syncthreads();
+  for (int i = 0; i < nw; i++) {
+    v[0] = fminf(v[0], scratch[4 * i]); v[1] = fmaxf(v[1], scratch[4 * i + 1]);
+    v[2] = fminf(v[2], scratch[4 * i + 2]); v[3] = fmaxf(v[3], scratch[4 * i + 3]);
+  }
+}
 __device__ __forceinline__ int block_sum(int v, int* scratch) {
   v = wave_sum(v);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -70,6 +70,7 @@ struct FeatureScratch {
   double* part;     // global [7][cap_points] partial moments of the candidate chunks
   int* tmpi;        // global [2 * cap + 16] copies of vlist/vstart (only used when leaf < radius)
   int cap;          // capacity (entries) of order/vstart/vlist/rng/part
+  int tab_voxels;   // voxels the dense counting-sort table may cover (two 16-bit counters per word of the key region)
 };
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
@@ -128,32 +129,54 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
 
 // cloud_build_block + compensate_block + the bounding box the voxel grid needs, in one pass over the slots
 // (batched odometry step). bounds = {min x, max x, min y, max y} of the final points.
+//
+// Compensation needs atan2(y, x), sin and cos per point in f64 (utils.cpp:96-107) - hundreds of instructions each.
+// Here the points of bearing b lie on the ray theta_b up to the float rounding of (x, y), so these are expanded
+// around per-bearing values kept in LDS (tab: 3 doubles per bearing):
+//   atan2(y, x) = theta_b + atan((y c_b - x s_b) / (x c_b + y s_b)),  argument ~1e-7 => atan(t) = t to f64 precision
+//   sin/cos(arg) around arg_b = d_b * m2 to second order in (arg - arg_b) ~ 1e-9
+// which agrees with evaluating the reference's expressions to within f64 rounding (the test tolerance on
+// compensated points stays one float ulp, as for any two libm implementations).
 __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
                                        float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
-                                       double m0, double m1, double m2, int ccw, int* red_i, float* red_f, float bounds[4]) {
+                                       double m0, double m1, double m2, int ccw, int* red_i, float* red_f, double* tab,
+                                       int tab_bearings, float bounds[4]) {
   const double range_res = (double)range_res_f;
   const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // radar_filters.cpp:315
   const double range_res_half = range_res / 2.0;
   const int items = A * k;
   const int ipt = (items + blockDim.x - 1) / blockDim.x;
   const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
+  const bool expand = compensate && A <= tab_bearings;  // block-uniform; more bearings than the table holds: plain formulas
+  if (expand) {
+    for (int b = threadIdx.x; b < A; b += blockDim.x) {
+      const double theta = ((double)(b + 1) / A) * CFEAR_TWO_PI;                   // radar_filters.cpp:317
+      const double a = theta > 3.14159265358979323846 ? theta - CFEAR_TWO_PI : theta;  // principal value, as atan2 returns it
+      const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);   // utils.h:28-32
+      const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+      double sb, cb;
+      sincos(d * m2, &sb, &cb);
+      tab[3 * b] = a; tab[3 * b + 1] = sb; tab[3 * b + 2] = cb;
+    }
+  }
   int cnt = 0;
   for (int i = i0; i < i1; i++) {
     const uint32_t s = slots[i];
     cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
   }
   int total;
-  int o = block_exclusive_scan(cnt, red_i, &total);
+  int o = block_exclusive_scan(cnt, red_i, &total);  // (its barriers also publish tab)
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
   for (int i = i0; i < i1; i++) {
     const uint32_t s = slots[i];
     const int range = CFEAR_SLOT_RANGE(s);
     if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
       const int b = i / k;
+      const double cb = trig[2 * b], sb = trig[2 * b + 1];
       const double rad = range_res_half + range_res * range;
-      float x = (float)(rad * trig[2 * b]);      // :329
-      float y = (float)(rad * trig[2 * b + 1]);  // :330
-      if (compensate) {  // utils.cpp:96-107, utils.h:28-32
+      float x = (float)(rad * cb);  // :329
+      float y = (float)(rad * sb);  // :330
+      if (compensate && !expand) {  // utils.cpp:96-107 as written
         const double px = (double)x, py = (double)y;
         const double a = atan2(py, px);
         const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
@@ -162,14 +185,26 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
         sincos(d * m2, &s1, &c1);
         x = (float)((c1 * px + (-s1) * py) + d * m0);
         y = (float)((s1 * px + c1 * py) + d * m1);
+      } else if (compensate) {
+        const double px = (double)x, py = (double)y;
+        const double ab = tab[3 * b], s_b = tab[3 * b + 1], c_b = tab[3 * b + 2];
+        const double a = ab + (py * cb - px * sb) / (px * cb + py * sb);
+        const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+        const double ddb = ((ab > 0.00001 ? ab : (CFEAR_TWO_PI + ab)) / CFEAR_TWO_PI);
+        const double d_b = ccw ? -(ddb - 0.5) : (ddb - 0.5);
+        const double e = d * m2 - d_b * m2;
+        const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
+        x = (float)((c1 * px + (-s1) * py) + d * m0);
+        y = (float)((s1 * px + c1 * py) + d * m1);
       }
       xyi[3 * o + 0] = x; xyi[3 * o + 1] = y; xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       o++;
     }
   }
-  bounds[0] = block_min(mnx, red_f); bounds[1] = block_max(mxx, red_f);
-  bounds[2] = block_min(mny, red_f); bounds[3] = block_max(mxy, red_f);
+  bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
+  block_bounds(bounds, red_f);
   __syncthreads();
   return total < cap ? total : cap;
 }
@@ -247,14 +282,15 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       const float x = xyi[3 * i], y = xyi[3 * i + 1];
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
     }
-    mnx = block_min(mnx, W.red_f); mxx = block_max(mxx, W.red_f);
-    mny = block_min(mny, W.red_f); mxy = block_max(mxy, W.red_f);
+    float bb[4] = {mnx, mxx, mny, mxy};
+    block_bounds(bb, W.red_f);
+    mnx = bb[0]; mxx = bb[1]; mny = bb[2]; mxy = bb[3];
   }
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
   const long long Gll = (long long)div0 * (long long)div1;
-  if (W.lds && Gll <= 32768) {
+  if (W.lds && Gll <= (long long)W.tab_voxels && n <= 8 * nt) {
     // ---- LDS counting sort over the dense voxel grid: 16-bit counters packed two per word in the (not yet
     // used) key region; the atomic scatter is unordered, ranking by point index inside each voxel restores the point order,
     // which makes the whole sort stable ([3P] std::sort on the voxel index, pinned as stable) ----
@@ -548,8 +584,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     const float x = S->mean_f[2 * i], y = S->mean_f[2 * i + 1];
     gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
   }
-  gx0 = block_min(gx0, W.red_f); gx1 = block_max(gx1, W.red_f);
-  gy0 = block_min(gy0, W.red_f); gy1 = block_max(gy1, W.red_f);
+  { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
   if (nc == 0) {
     if (tid == 0) { S->gw = 0; S->gh = 0; S->gcell = 1.f; S->gminx = 0.f; S->gminy = 0.f; }
     __syncthreads();

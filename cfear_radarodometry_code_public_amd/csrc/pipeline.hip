@@ -94,6 +94,7 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
     W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
   }
   W.vcur = B.vcur; W.lds = LDS;
+  W.tab_voxels = LDS ? (LDS_P2 * 4 < 32768 ? LDS_P2 * 4 - 2 : 32768) : 0;  // 16-bit counters over the key region, values < 65536
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
   W.cap = (LDS && B.cap_points > CFEAR_LDS_POINT_CAP) ? CFEAR_LDS_POINT_CAP : B.cap_points;
   W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   float bounds[4];
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
-                                 reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f), bounds);
+                                 reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f),
+                                 reinterpret_cast<double*>(lds + FeatLds::keys), (int)(LDS_P2 * sizeof(uint64_t) / (3 * sizeof(double))), bounds);  // 3 doubles per bearing in the (still unused) key region
   pt.mark();
   pt.mark();
   features_dispatch(cur, n, OP.fp, B, lds, &pt, n > 0 ? bounds : nullptr);  // :161
