@@ -70,6 +70,7 @@ struct FeatureScratch {
   double* part;     // global [7][cap_points] partial moments of the candidate chunks
   int* tmpi;        // global [2 * cap + 16] copies of vlist/vstart (only used when leaf < radius)
   int cap;          // capacity (entries) of order/vstart/vlist/rng/part
+  bool tab_zeroed;  // the caller already cleared the whole key region (saves a barrier)
   int tab_voxels;   // voxels the dense counting-sort table may cover (two 16-bit counters per word of the key region)
 };
 
@@ -296,8 +297,10 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     // which makes the whole sort stable ([3P] std::sort on the voxel index, pinned as stable) ----
     const int G = (int)Gll;
     uint32_t* tab = reinterpret_cast<uint32_t*>(W.keys);
-    for (int g = tid; g <= (G >> 1); g += nt) tab[g] = 0u;
-    __syncthreads();
+    if (!W.tab_zeroed) {  // block-uniform
+      for (int g = tid; g <= (G >> 1); g += nt) tab[g] = 0u;
+      __syncthreads();
+    }
     for (int i = tid; i < n; i += nt) {
       const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
       const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
@@ -313,9 +316,11 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       const int g0 = tid * ipt, g1 = min(G, g0 + ipt);
       int cnt = 0, occ = 0;
       for (int g = g0; g < g1; g++) { const int c = (tab[g >> 1] >> (16 * (g & 1))) & 0xFFFF; cnt += c; occ += c > 0 ? 1 : 0; }
-      int tot;
-      int o = block_exclusive_scan(cnt, W.red_i, &tot);
-      int ov = block_exclusive_scan(occ, W.red_i, &nvv);
+      unsigned long long tot;  // points and occupied voxels scanned together (32 bits each)
+      const unsigned long long ex = block_exclusive_scan64((unsigned long long)(unsigned)cnt | ((unsigned long long)(unsigned)occ << 32),
+                                                           reinterpret_cast<unsigned long long*>(W.red_i), &tot);
+      int o = (int)(unsigned)ex, ov = (int)(ex >> 32);
+      nvv = (int)(tot >> 32);
       for (int g = g0; g < g1; g += 2) {
         const uint32_t w = tab[g >> 1];
         const int c0 = w & 0xFFFF, c1 = (g + 1 < g1) ? (int)(w >> 16) : 0;
@@ -599,6 +604,37 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     gcell *= 2.f;
   }
   const int G = gw * gh;
+  if (W.lds && G + 1 <= W.tab_voxels / 2) {
+    // bucket counters / cursors in LDS (the key region: the staged points are not needed any more)
+    int* gc = reinterpret_cast<int*>(W.keys);
+    for (int g = tid; g <= G; g += nt) gc[g] = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += nt) {
+      int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+      atomicAdd(&gc[cy * gw + cx + 1], 1);
+    }
+    __syncthreads();
+    {
+      const int ipt = (G + nt - 1) / nt;
+      const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
+      int cnt = 0;
+      for (int g = i0; g < i1; g++) cnt += gc[g + 1];
+      int tot;
+      int o = block_exclusive_scan(cnt, W.red_i, &tot);
+      for (int g = i0; g < i1; g++) { const int c = gc[g + 1]; gc[g + 1] = o; S->gstart[g + 1] = o + c; o += c; }  // cursor / end offset
+      if (tid == 0) S->gstart[0] = 0;
+      __syncthreads();
+    }
+    for (int i = tid; i < nc; i += nt) {
+      const float mx = S->mean_f[2 * i], my = S->mean_f[2 * i + 1];
+      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
+      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+      const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
+      S->gorder[pos] = i;
+      S->gpts[pos] = make_float4(mx, my, __int_as_float(i), 0.f);
+    }
+  } else {
   for (int g = tid; g <= G; g += nt) S->gstart[g] = 0;
   __syncthreads();
   for (int i = tid; i < nc; i += nt) {
@@ -625,6 +661,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
     S->gorder[pos] = i;
     S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
+  }
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
   __syncthreads();

@@ -82,7 +82,7 @@ __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; retur
 // LDS = true: keys/order/vstart/vlist and the staged points are LDS arrays (ds_* instructions after
 // inlining); LDS = false: their global twins for clouds above CFEAR_LDS_POINT_CAP points.
 template <bool LDS>
-__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds) {
+__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds, bool tab_zeroed = false) {
   FeatureScratch W;
   if (LDS) {
     W.keys = reinterpret_cast<uint64_t*>(lds + FeatLds::keys);
@@ -93,7 +93,7 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   } else {
     W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
   }
-  W.vcur = B.vcur; W.lds = LDS;
+  W.vcur = B.vcur; W.lds = LDS; W.tab_zeroed = LDS && tab_zeroed;
   W.tab_voxels = LDS ? (LDS_P2 * 4 < 32768 ? LDS_P2 * 4 - 2 : 32768) : 0;  // 16-bit counters over the key region, values < 65536
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
   W.cap = (LDS && B.cap_points > CFEAR_LDS_POINT_CAP) ? CFEAR_LDS_POINT_CAP : B.cap_points;
@@ -103,9 +103,10 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   return W;
 }
 __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
-                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds = nullptr) {
+                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds = nullptr,
+                                                  bool tab_zeroed = false) {
   if (n <= CFEAR_LDS_POINT_CAP) {  // block-uniform
-    const FeatureScratch W = make_fscratch<true>(B, lds);
+    const FeatureScratch W = make_fscratch<true>(B, lds, tab_zeroed);
     features_block(S, n, P, W, next_pow2(n), pt, bounds);
   } else {
     const FeatureScratch W = make_fscratch<false>(B, lds);
@@ -174,16 +175,22 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   const Aff2 TprevMot = st->Tmot;  // :146
   PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   pt.mark();
+  // the dense voxel table of the counting sort starts all-zero (cleared here: the barriers of the cloud pass publish it)
+  {
+    uint4* kz = reinterpret_cast<uint4*>(lds + FeatLds::keys);
+    for (int i = threadIdx.x; i < (int)(LDS_P2 * sizeof(uint64_t) / sizeof(uint4)); i += BLOCK_F) kz[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
   double mot[3]; aff_to_xyt(TprevMot, mot);
   float bounds[4];
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
                                  reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f),
-                                 reinterpret_cast<double*>(lds + FeatLds::keys), (int)(LDS_P2 * sizeof(uint64_t) / (3 * sizeof(double))), bounds);  // 3 doubles per bearing in the (still unused) key region
+                                 reinterpret_cast<double*>(lds + FeatLds::order),  // 3 doubles per bearing in the (still unused) order array
+                                 (int)(CFEAR_LDS_POINT_CAP * sizeof(int) / (3 * sizeof(double))), bounds);
   pt.mark();
   pt.mark();
-  features_dispatch(cur, n, OP.fp, B, lds, &pt, n > 0 ? bounds : nullptr);  // :161
+  features_dispatch(cur, n, OP.fp, B, lds, &pt, n > 0 ? bounds : nullptr, true);  // :161
 }
 
 __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
