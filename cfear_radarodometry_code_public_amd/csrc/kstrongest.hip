@@ -37,6 +37,21 @@ __device__ __forceinline__ int wave_sum_small(int v) {
   return total;
 }
 
+// wave64 inclusive prefix sum with DPP adds (Hillis-Steele inside the 16-lane rows, then two row broadcasts)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);  // lanes without a source add 0
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v = dpp_add_i<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add_i<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add_i<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add_i<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add_i<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
+  v = dpp_add_i<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
+  return v;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   constexpr int WIN = NCH * 1024;  // LDS window bytes per wave
   constexpr int SUMBITS = NCH == 4 ? 7 : (NCH == 8 ? 8 : 9);
   __shared__ uint4 lds_win[4][NCH * 64];
-  __shared__ uint32_t lds_keys[4][64];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_keys[4][64];
   __shared__ uint32_t lds_ge[20];  // lds_ge[n] = candidate-mask bits of the chunk bytes with index >= n (n = 0..16)
   if (threadIdx.x <= 16) lds_ge[threadIdx.x] = chunk_range_mask((int)threadIdx.x, 16);
   __syncthreads();  // the only block-level barrier: before the waves go their own way
@@ -325,35 +340,38 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       cnt += need;
     }
 
-    // ---- compaction of the <= 64 candidates into LDS keys (one round per candidate of the fullest lane) ----
+    // ---- compaction of the <= 64 candidates into LDS keys: a lane's candidates take consecutive slots after
+    // those of the lower lanes (DPP prefix sum of the per-lane counts); the ranking below orders them ----
     uint32_t w[NCH / 2];
     pack_masks<NCH>(m, w);
-    int nbase = 0;
-    while (true) {
+    {
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) c += __popc(w[i]);
+      int slot = wave_inclusive_scan(c) - c;
       uint32_t any = 0;
 #pragma unroll
       for (int i = 0; i < NCH / 2; i++) any |= w[i];
-      const unsigned long long b = __ballot(any != 0);
-      if (b == 0) break;
-      if (any != 0) {
+      while (any != 0) {  // per-lane loop: as many rounds as the fullest lane has candidates
         int wi = 0;
         uint32_t cur = w[0];
 #pragma unroll
         for (int i = 1; i < NCH / 2; i++)
           if (cur == 0) { cur = w[i]; wi = i; }
         const int t = __ffs(cur) - 1;
-        const int j = 2 * wi + ((t >> 2) & 1);
-        const int bi = 4 * (t & 3) + (t >> 3);  // byte index inside the chunk
-        const int woff = 16 * (j * 64 + lane) + bi;
-        const int slot = nbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        if (slot < 64) keys[slot] = (uint32_t)woff;  // window offset; the intensity is fetched after the loop
+        // compact code (bit t of word wi of this lane); decoded once per row by the lane that owns the slot
+        if (slot < 64) keys[slot] = (uint32_t)((t << 9) | (wi << 6) | lane);
+        slot++;
         const uint32_t cleared = cur & (cur - 1);
+        any = 0;
 #pragma unroll
-        for (int i = 0; i < NCH / 2; i++)
+        for (int i = 0; i < NCH / 2; i++) {
           if (i == wi) w[i] = cleared;
+          any |= w[i];
+        }
       }
-      nbase += __popcll(b);
     }
+    const int nbase = cnt;
     wave_lds_fence();
     if (dbg == 3) {
       if (nbase == 0x1234567) slots[g * (long long)k] = (uint32_t)nbase;
@@ -363,7 +381,11 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     const int kk = k < C ? k : C;  // number of emitted points
     uint32_t key = 0u;
     if (lane < C) {
-      const uint32_t woff = keys[lane];
+      const uint32_t code = keys[lane];
+      const int t = (int)(code >> 9), wi = (int)((code >> 6) & 7u), ln = (int)(code & 63u);
+      const int j = 2 * wi + ((t >> 2) & 1);
+      const int bi = 4 * (t & 3) + (t >> 3);  // byte index inside the chunk
+      const uint32_t woff = (uint32_t)(16 * (j * 64 + ln) + bi);  // window offset
       key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
     }
     int rank = 0;
@@ -420,8 +442,12 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     }
     // ---- emit: ascending (intensity, range), unused slots 0 ----
     uint32_t* out = slots + g * (long long)k;
+    if (dbg == 6) {  // bring-up: cost of the stores
+      if (__ballot(kept && (key | peak) == 0x7777u) != 0) out[0] = 1u;
+    } else {
     if (kept) out[kk - 1 - rank] = key | peak;
     if (lane >= kk && lane < k) out[lane] = 0u;
+    }
     wave_lds_fence();
   }
 }
