@@ -60,7 +60,7 @@ class RegSummary(C.Structure):
 EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
     "cfear_set_params", "cfear_synchronize", "cfear_kstrongest_device", "cfear_kstrongest_host",
-    "cfear_filter_polar", "cfear_filter_polar_device", "cfear_cloud_upload", "cfear_cloud_size",
+    "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
@@ -78,6 +78,10 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    try:  # PyTorch bundles its own HIP runtime: when both live in one process, torch's must be loaded first
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise CfearError("libcfear_hip.so is not built: run __graft_entry__.build() "
@@ -96,6 +100,8 @@ def lib():
         "cfear_kstrongest_host": (C.c_int, [vp, u8p, C.c_int, u32p]),
         "cfear_filter_polar": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
         "cfear_filter_polar_device": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
+        "cfear_filter_cfar": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_float, C.c_double, C.POINTER(vp)]),
+        "cfear_filter_cfar_device": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_float, C.c_double, C.POINTER(vp)]),
         "cfear_cloud_upload": (C.c_int, [vp, f32p, C.c_int, C.POINTER(vp)]),
         "cfear_cloud_size": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
         "cfear_cloud_download": (C.c_int, [vp, vp, f32p, C.c_int, C.POINTER(C.c_int)]),
@@ -219,6 +225,19 @@ class Context:
             rc = self._L.cfear_filter_polar_device(self._h, _addr(polar), C.byref(c), C.byref(cp) if peaks else None)
         self._check(rc, "cfear_filter_polar")
         return Cloud(self, c), (Cloud(self, cp) if peaks else None)
+
+    def filter_cfar(self, polar, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0):
+        """radarDriver::Process with filter_type CA-CFAR (defaults of radarDriver::Parameters, radar_driver.h:43-44)."""
+        c = C.c_void_p()
+        args = (int(window_size), int(nb_guard_cells), C.c_float(false_alarm_rate), C.c_double(max_distance), C.byref(c))
+        if isinstance(polar, np.ndarray):
+            polar = np.ascontiguousarray(polar, dtype=np.uint8)
+            assert polar.shape == (self.A, self.R)
+            rc = self._L.cfear_filter_cfar(self._h, polar.ctypes.data, *args)
+        else:
+            rc = self._L.cfear_filter_cfar_device(self._h, _addr(polar), *args)
+        self._check(rc, "cfear_filter_cfar")
+        return Cloud(self, c)
 
     def cloud_upload(self, xyi):
         xyi = np.ascontiguousarray(xyi, dtype=np.float32).reshape(-1, 3)

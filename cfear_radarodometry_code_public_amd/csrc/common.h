@@ -53,7 +53,15 @@ static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_
     if (_e != hipSuccess) return cfear_fail((ctx), CFEAR_ERR_HIP, #call, _e); \
   } while (0)
 
+struct cfear_cloud {  // pcl::PointCloud<pcl::PointXYZI> on the device
+  int cap = 0;
+  float* d_xyi = nullptr;  // [cap][3] x, y, intensity
+  int* d_n = nullptr;      // point count
+};
+
 // cabi.hip
 extern "C" int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
+// pipeline.hip
+extern "C" int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);
 // kstrongest.hip
 int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);

@@ -392,11 +392,6 @@ int set_kernel_attributes(cfear_ctx*) { return CFEAR_OK; }  // LDS is static (up
 
 }  // namespace
 
-struct cfear_cloud {
-  int cap = 0;
-  float* d_xyi = nullptr;
-  int* d_n = nullptr;
-};
 struct cfear_scan {
   unsigned char* d_block = nullptr;  // ScanDev header + arrays
   int cap_points = 0;
@@ -454,7 +449,7 @@ static int ensure_ctx_scratch(cfear_ctx* ctx, int cap_points, int pair_cap) {
 extern "C" {
 
 // ---- clouds ------------------------------------------------------------------------------------
-static int cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out) {
+int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out) {
   cfear_cloud* c = new (std::nothrow) cfear_cloud();
   if (!c) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "cloud alloc");
   c->cap = cap > 0 ? cap : 1;
@@ -487,7 +482,7 @@ int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_clou
   const int A = ctx->A, k = ctx->par.k_strongest, cap = A * k;
   for (int peaks = 0; peaks < (cloud_peaks ? 2 : 1); peaks++) {  // radar_driver.cpp:59-60
     cfear_cloud* c = nullptr;
-    rc = cloud_alloc(ctx, cap, &c);
+    rc = cfear_cloud_alloc(ctx, cap, &c);
     if (rc != CFEAR_OK) return rc;
     hipLaunchKernelGGL(cloud_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
                        ctx->par.range_res, ctx->par.min_distance, peaks, c->d_xyi, cap, c->d_n);
@@ -510,7 +505,7 @@ int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cl
   if (!ctx || !cloud || n < 0 || (n > 0 && !xyi)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cloud_upload: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   cfear_cloud* c = nullptr;
-  int rc = cloud_alloc(ctx, n, &c);
+  int rc = cfear_cloud_alloc(ctx, n, &c);
   if (rc != CFEAR_OK) return rc;
   if (n > 0) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_xyi, xyi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_n, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));

@@ -101,28 +101,61 @@ inline DeviceCloudPtr UploadCloud(const DevicePtr& dev, const PointCloudXYZI& c)
 }
 
 // ---- radarDriver (radar_driver.h:32-120) ----------------------------------------------------------
+typedef enum filter_type { kstrong, CACFAR } filtertype;  // radar_driver.h:24
+inline filtertype Str2filter(const std::string& str) { return str == "CA-CFAR" ? filtertype::CACFAR : filtertype::kstrong; }  // radar_driver.cpp:6-12
+inline std::string Filter2str(const filtertype& filter) { return filter == filtertype::CACFAR ? "CA-CFAR" : "kstrong"; }       // :13-20
+
+// ---- AzimuthCACFAR (cfar.h:31-46, cfar.cpp:27-87) -------------------------------------------------------
+class AzimuthCACFAR {
+ public:
+  AzimuthCACFAR(const DevicePtr& dev, int window_size = 40, double false_alarm_rate = 0.01, int nb_guard_cells = 5, double range_resolution = 0.0438,
+                double static_threshold = 60.0, double min_distance = 2.5, double max_distance = 200.0)
+      : dev_(dev), window_size_(window_size), nb_guard_cells_(nb_guard_cells), false_alarm_rate_(false_alarm_rate), max_distance_(max_distance) {
+    cfear_params p = dev_->params(); p.range_res = (float)range_resolution; p.z_min = (float)static_threshold; p.min_distance = (float)min_distance;
+    dev_->set_params(p);
+  }
+  // void getFilteredPointCloud(const cv_bridge::CvImagePtr&, PointCloud::Ptr& output) const (cfar.cpp:35)
+  DeviceCloudPtr getFilteredPointCloud(const PolarImage& img, CloudPtr& output_pointcloud) const {
+    DeviceCloudPtr d(new DeviceCloud()); d->dev = dev_;
+    dev_->check(cfear_filter_cfar(dev_->ctx(), img.data, window_size_, nb_guard_cells_, (float)false_alarm_rate_, max_distance_, &d->h), "cfear_filter_cfar");
+    output_pointcloud = DownloadCloud(dev_, d->h);
+    return d;
+  }
+ private:
+  DevicePtr dev_; int window_size_, nb_guard_cells_; double false_alarm_rate_, max_distance_;
+};
+
 class radarDriver {
  public:
-  class Parameters {  // radar_driver.h:35-84 (filter_type CA-CFAR is out of scope)
+  class Parameters {  // radar_driver.h:35-84
    public:
     float z_min = 60; float range_res = 0.0438f; int azimuths = 400, k_strongest = 12;
     float min_distance = 2.5f, max_distance = 200; std::string dataset = "oxford";
+    int nb_guard_cells = 20, window_size = 10; float false_alarm_rate = 0.01f;  // :43-44
+    filtertype filter_type_ = filtertype::kstrong;                               // :48
   };
   radarDriver(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) {
     (void)disable_callback;
     cfear_params p = dev_->params(); p.z_min = par.z_min; p.range_res = par.range_res; p.min_distance = par.min_distance; p.k_strongest = par.k_strongest;
     dev_->set_params(p);
   }
-  // void CallbackOffline(const sensor_msgs::ImageConstPtr&, PointCloud::Ptr& cloud, PointCloud::Ptr& cloud_peaks) (radar_driver.cpp:163-176).
-  // The image is rows = azimuth x cols = range (the reference rotates non-Oxford input first, radar_driver.cpp:84).
+  // void CallbackOffline(const sensor_msgs::ImageConstPtr&, PointCloud::Ptr& cloud, PointCloud::Ptr& cloud_peaks) (radar_driver.cpp:163-176)
+  // -> Process() (:48-73). The image is rows = azimuth x cols = range (the reference rotates non-Oxford input first, :84).
   void CallbackOffline(const PolarImage& img, CloudPtr& cloud, CloudPtr& cloud_peaks) {
     if (!img.data) throw std::runtime_error("Radar image NULL");  // radar_driver.cpp:75-78
     if (img.rows != dev_->A() || img.cols != dev_->R()) throw std::runtime_error("polar image shape differs from the device context");
     cv_polar_image = img;
-    last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
-    last_cloud_->dev = dev_; last_peaks_->dev = dev_;
-    dev_->check(cfear_filter_polar(dev_->ctx(), img.data, &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
-    cloud = DownloadCloud(dev_, last_cloud_->h); cloud_peaks = DownloadCloud(dev_, last_peaks_->h);
+    if (par.filter_type_ == filtertype::CACFAR) {  // :52-56: max_distance 400.0, the peaks cloud stays empty
+      AzimuthCACFAR filter(dev_, par.window_size, par.false_alarm_rate, par.nb_guard_cells, par.range_res, par.z_min, par.min_distance, 400.0);
+      last_cloud_ = filter.getFilteredPointCloud(img, cloud);
+      last_peaks_.reset(new DeviceCloud()); last_peaks_->dev = dev_;
+      cloud_peaks.reset(new PointCloudXYZI());
+    } else {
+      last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
+      last_cloud_->dev = dev_; last_peaks_->dev = dev_;
+      dev_->check(cfear_filter_polar(dev_->ctx(), img.data, &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
+      cloud = DownloadCloud(dev_, last_cloud_->h); cloud_peaks = DownloadCloud(dev_, last_peaks_->h);
+    }
     cloud->stamp = cloud_peaks->stamp = img.stamp;
   }
   DeviceCloudPtr device_cloud() const { return last_cloud_; }  // avoids a round trip when the fuser runs on the same device

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
            "       [--min_distance 2.5] [--submap_scan_size 3] [--weight_intensity 1] [--k_strongest 12] [--z-min 65]\n"
            "       [--radar_ccw 0] [--disable_compensate 0] [--cost_type P2L] [--loss_type Huber] [--loss_limit 0.1]\n"
            "       [--covar_scale 1] [--regularization 1] [--weight_option 0] [--registered_min_keyframe_dist 1.5]\n"
-           "       [--est_directory .] [--device 0]\n");
+           "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR]\n");
     return argc < 2;
   }
   const std::string frames = arg(argc, argv, "--frames", "");
@@ -42,6 +42,12 @@ int main(int argc, char** argv) {
   rad_par.k_strongest = atoi(arg(argc, argv, "--k_strongest", "12"));
   rad_par.z_min = (float)atof(arg(argc, argv, "--z-min", "65"));
   rad_par.azimuths = A;
+  rad_par.filter_type_ = Str2filter(arg(argc, argv, "--filter-type", "kstrong"));  // offline_odometry.cpp:269
+  // the reference's option reuse for the CA-CFAR sweeps (offline_odometry.cpp:260-265): nb_guard_cells <- k_strongest,
+  // false_alarm_rate <- regularization, window_size <- covar_scale
+  rad_par.nb_guard_cells = rad_par.k_strongest;
+  rad_par.false_alarm_rate = (float)atof(arg(argc, argv, "--regularization", "1"));
+  rad_par.window_size = (int)atof(arg(argc, argv, "--covar_scale", "1"));
   OdometryKeyframeFuser::Parameters par;
   par.res = atof(arg(argc, argv, "--res", "3.5"));
   par.submap_scan_size = atoi(arg(argc, argv, "--submap_scan_size", "3"));

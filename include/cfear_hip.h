@@ -96,6 +96,16 @@ typedef struct cfear_cloud cfear_cloud; /* pcl::PointCloud<pcl::PointXYZI> on th
 int cfear_filter_polar(cfear_ctx* ctx, const uint8_t* h_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks);
 /* Same from a device-resident image (no copy). */
 int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks);
+/* radarDriver::Process with filter_type "CA-CFAR" (radar_driver.cpp:52-56): AzimuthCACFAR(window_size,
+ * false_alarm_rate, nb_guard_cells, range_res, z_min, min_distance, max_distance = 400.0)
+ * .getFilteredPointCloud (cfar.cpp:27-87) -> filtered cloud, row-major over (azimuth, range bin). range_res, z_min
+ * (static threshold) and min_distance come from the context parameters; the defaults of
+ * radarDriver::Parameters are window_size 10, nb_guard_cells 20, false_alarm_rate 0.01 (radar_driver.h:43-44).
+ * Synchronous (the cloud is sized by the detection count). */
+int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, int nb_guard_cells, float false_alarm_rate,
+                      double max_distance, cfear_cloud** cloud);
+int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_guard_cells,
+                             float false_alarm_rate, double max_distance, cfear_cloud** cloud);
 /* Upload an existing cloud: xyi = n x (x, y, intensity) floats. */
 int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cloud);
 int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* cloud, int* n);

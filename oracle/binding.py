@@ -79,6 +79,9 @@ def lib():
     L.cfo_filter_bruteforce.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
     L.cfo_cloud.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p]
     L.cfo_compensate.argtypes = [f32p, C.c_int, f64p, C.c_int]
+    L.cfo_cfar_scaling.argtypes = [C.c_int, C.c_double]
+    L.cfo_cfar_scaling.restype = C.c_double
+    L.cfo_cfar.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, C.c_int, C.c_int, C.c_float, f32p, C.c_int]
     L.cfo_scan_create.argtypes = [f32p, C.c_int, C.POINTER(Params), C.c_int]
     L.cfo_scan_create.restype = C.c_void_p
     L.cfo_scan_free.argtypes = [C.c_void_p]
@@ -138,6 +141,18 @@ def cloud(slots, range_res, min_distance, peaks=False):
     xyi = np.zeros((A * k, 3), dtype=np.float32)
     n = lib().cfo_cloud(_ptr(slots, C.c_uint32), A, k, np.float32(range_res), np.float32(min_distance),
                         int(peaks), _ptr(xyi, C.c_float))
+    return xyi[:n].copy()
+
+
+def cfar(img, range_res, static_threshold, min_distance, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0):
+    """AzimuthCACFAR::getFilteredPointCloud with the defaults of radarDriver::Parameters (radar_driver.h:43-44)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    A, R = img.shape
+    args = (_ptr(img, C.c_uint8), A, R, np.float32(range_res), np.float32(static_threshold), np.float32(min_distance),
+            float(max_distance), int(window_size), int(nb_guard_cells), np.float32(false_alarm_rate))
+    n = lib().cfo_cfar(*args, None, 0)
+    xyi = np.zeros((max(n, 1), 3), dtype=np.float32)
+    lib().cfo_cfar(*args, _ptr(xyi, C.c_float), n)
     return xyi[:n].copy()
 
 

@@ -192,6 +192,64 @@ int cfo_cloud(const uint32_t* slots, int A, int k, float range_res_f, float min_
   return n;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Stage 1, alternative filter: azimuth CA-CFAR (cfar.cpp:12-16, 27-87; selected by
+ * filter_type "CA-CFAR", radar_driver.cpp:52-56 with max_distance = 400.0)
+ * ------------------------------------------------------------------------------------------ */
+/* CFARFilter::getCAScalingFactor (cfar.cpp:12-16) for the two windows together (cfar.cpp:32) */
+double cfo_cfar_scaling(int window_size, double false_alarm_rate) {
+  const double N = (double)(window_size * 2);
+  return N * (pow(false_alarm_rate, -1. / N) - 1.);
+}
+
+/* AzimuthCACFAR::getMean (cfar.cpp:76-86): mean of the squared intensities of [start, end). The reference runs a
+ * size_t index up to an int bound; a negative bound (range_bin < nb_guard_cells, only reachable when min_distance
+ * is below the guard distance) is undefined behaviour there and an empty window here. Empty window: 0/0 = NaN. */
+static double cfar_mean(const uint8_t* row, int start, int end) {
+  double sum = 0., N = 0.;
+  for (int i = start; i < end; i++) { sum += pow((double)row[i], 2.); N += 1.; }
+  return sum / N;
+}
+
+/* AzimuthCACFAR::getFilteredPointCloud (cfar.cpp:35-74). Returns the number of detections; the first `cap` are
+ * written to xyi (x, y, intensity), row-major over (azimuth, range bin). */
+int cfo_cfar(const uint8_t* img, int A, int R, float range_res_f, float static_threshold_f, float min_distance_f,
+             double max_distance, int window_size, int nb_guard_cells, float false_alarm_rate_f, float* xyi, int cap) {
+  /* float members of radarDriver::Parameters bound to const double& (radar_driver.cpp:54) */
+  const double range_resolution = (double)range_res_f, static_threshold = (double)static_threshold_f;
+  const double min_distance = (double)min_distance_f;
+  const double scaling_factor = cfo_cfar_scaling(window_size, (double)false_alarm_rate_f);
+  int n = 0;
+  for (int az = 0; az < A; az++) {
+    const uint8_t* row = img + (size_t)az * R;
+    const double theta = ((double)(az + 1) / A) * 2. * M_PI; /* :40 */
+    for (int bin = 0; bin < R; bin++) {
+      const double range = range_resolution * (double)bin;
+      const double intensity = (double)row[bin];
+      if (range > min_distance && range < max_distance && intensity > static_threshold) { /* :45 */
+        const int t0 = bin - nb_guard_cells - window_size > 0 ? bin - nb_guard_cells - window_size : 0; /* :48 */
+        const int t1 = bin - nb_guard_cells;
+        const double trailing_mean = cfar_mean(row, t0, t1);
+        const int f0 = bin + nb_guard_cells; /* :52 */
+        const int f1 = R < bin + nb_guard_cells + window_size ? R : bin + nb_guard_cells + window_size;
+        const double forwarding_mean = cfar_mean(row, f0, f1);
+        const double mean = (trailing_mean + forwarding_mean) / 2.0; /* :56 */
+        const double threshold = scaling_factor * mean;
+        const double squared_intensity = pow(intensity, 2.);
+        if (squared_intensity > threshold) { /* :60 (false for NaN) */
+          if (n < cap) {
+            xyi[3 * n + 0] = (float)(range * cos(theta));
+            xyi[3 * n + 1] = (float)(range * sin(theta));
+            xyi[3 * n + 2] = (float)intensity;
+          }
+          n++;
+        }
+      }
+    }
+  }
+  return n;
+}
+
 /* utils.h:28-32 */
 static double rel_time_stamp(double x, double y, int ccw) {
   double a = atan2(y, x);

@@ -76,6 +76,11 @@ int cfo_filter_bruteforce(const uint8_t* img, int A, int R, int z_min, int k, ui
 
 /* getPeaksFilteredPointCloud (radar_filters.cpp:309-337). peaks!=0 -> only slots with the peak flag.
  * xyi = 3 floats per point (x, y, intensity); returns number of points. */
+/* azimuth CA-CFAR, the alternative stage-1 filter (cfar.cpp:27-87, radar_driver.cpp:52-56); returns the number
+ * of detections, writes at most cap of them */
+double cfo_cfar_scaling(int window_size, double false_alarm_rate);
+int cfo_cfar(const uint8_t* img, int A, int R, float range_res, float static_threshold, float min_distance,
+             double max_distance, int window_size, int nb_guard_cells, float false_alarm_rate, float* xyi, int cap);
 int cfo_cloud(const uint32_t* slots, int A, int k, float range_res, float min_distance, int peaks,
               float* xyi);
 

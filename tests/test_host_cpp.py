@@ -51,3 +51,30 @@ def test_offline_odometry_matches_oracle(oracle, tmp_path):
         got = np.array([est[t, 3], est[t, 7], np.arctan2(est[t, 4], est[t, 0])])
         assert np.all(np.abs(got[:2] - exp[:2]) < 1e-4 + 5e-7), (t, got, exp)  # +5e-7: 6-decimal KITTI text
         assert abs(got[2] - exp[2]) < 1e-5 + 2e-6
+
+
+@pytest.mark.gpu
+def test_offline_odometry_with_ca_cfar_filter_matches_oracle(oracle, tmp_path):
+    """filter_type CA-CFAR (radar_driver.cpp:52-56): detections -> fuser, through the C++ mirror classes. The harness
+    reuses options like the reference's sweeps do (offline_odometry.cpp:260-265)."""
+    exe = build_harness()
+    imgs, gt = synth.world_sequence(6, seed=33)
+    f = tmp_path / "sweeps.u8"
+    imgs.tofile(f)
+    guard, pfa, window = 20, 0.01, 10
+    args = [exe, "--frames", str(f), "--range-res", "0.0595238", "--res", "3.0", "--submap_scan_size", "3", "--z-min", "60",
+            "--weight_option", "4", "--est_directory", str(tmp_path), "--filter-type", "CA-CFAR",
+            "--k_strongest", str(guard), "--regularization", str(pfa), "--covar_scale", str(window)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    est = np.loadtxt(tmp_path / "est_00.txt")
+    assert est.shape == (6, 12)
+    fu = oracle.Fuser(oracle.default_params(range_res=RR, z_min=60.0, res=3.0, submap_scan_size=3, weight_opt=4, weight_intensity=1,
+                                            compensate=1, radar_ccw=0, cost=1, loss=1, regularization=pfa, covar_scale=float(window)))
+    for t in range(6):
+        cloud = oracle.cfar(imgs[t], RR, 60.0, 2.5, window, guard, pfa)
+        assert len(cloud) > 1000
+        exp = fu.process_cloud(cloud)
+        got = np.array([est[t, 3], est[t, 7], np.arctan2(est[t, 4], est[t, 0])])
+        assert np.all(np.abs(got[:2] - exp[:2]) < 1e-4 + 5e-7), (t, got, exp)
+        assert abs(got[2] - exp[2]) < 1e-5 + 2e-6
