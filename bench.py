@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--sequences", type=int, default=1024, help="independent sequences resident per GPU")
     ap.add_argument("--unique", type=int, default=4, help="distinct synthetic sequences generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-steps", type=int, default=3, help="extra steps fed from pinned host memory (PCIe-inclusive rate, N=1 only; 0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,6 +176,20 @@ def main():
             "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,
                       "pose_seq0": [float(x) for x in poses[0]], "datagen_s": t_gen},
         }
+        if world == 1 and args.stream_steps > 0:
+            # the boundary also takes host buffers (cfear_odometry_step_host): PCIe-inclusive rate, reported beside
+            # the resident-input `value`, never as it
+            h = d_polar[W + K - 1].cpu().pin_memory()
+            hp = h.numpy()
+            odo.step_host(hp); ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.stream_steps):
+                odo.step_host(hp)
+            ctx.synchronize()
+            dt = time.perf_counter() - t1
+            out["stream_mode"] = {"value": B * args.stream_steps / dt, "unit": "scans/s", "steps": args.stream_steps,
+                                  "note": "host -> device copy of every sweep inside the timed region (pinned memory, cfear_odometry_step_host)",
+                                  "h2d_GBps": B * A * R * args.stream_steps / dt / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(streams)
         print(json.dumps(out), flush=True)
