@@ -6,6 +6,10 @@
 
 namespace cfear_dev {
 
+// every scratch array handed to the block primitives below is LDS: an LDS-typed pointer turns the partial-sum
+// loops into independent ds_read instructions (through a generic pointer they are dependent flat loads)
+#define CFEAR_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
 __device__ __forceinline__ int lane_id() {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
@@ -34,51 +38,56 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // scratch: >= 32 elements of T in LDS. Result broadcast to all threads.
 __device__ __forceinline__ float block_min(float v, float* scratch) {
+  auto* sl = CFEAR_LDS_PTR(float, scratch);
   v = wave_min(v);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
-  if (lane_id() == 0) scratch[w] = v;
+  if (lane_id() == 0) sl[w] = v;
   __syncthreads();
-  float r = scratch[0];
-  for (int i = 1; i < nw; i++) r = fminf(r, scratch[i]);
+  float r = sl[0];
+  for (int i = 1; i < nw; i++) r = fminf(r, sl[i]);
   return r;
 }
 __device__ __forceinline__ float block_max(float v, float* scratch) {
+  auto* sl = CFEAR_LDS_PTR(float, scratch);
   v = wave_max(v);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
-  if (lane_id() == 0) scratch[w] = v;
+  if (lane_id() == 0) sl[w] = v;
   __syncthreads();
-  float r = scratch[0];
-  for (int i = 1; i < nw; i++) r = fmaxf(r, scratch[i]);
+  float r = sl[0];
+  for (int i = 1; i < nw; i++) r = fmaxf(r, sl[i]);
   return r;
 }
 // bounding box in one go: v = {min x, max x, min y, max y} per thread -> block-wide values in every thread.
 // scratch: >= 4 * 32 floats... uses 4 floats per wave (<= 16 waves -> 64 floats).
 __device__ __forceinline__ void block_bounds(float v[4], float* scratch) {
+  auto* sl = CFEAR_LDS_PTR(float, scratch);
   v[0] = wave_min(v[0]); v[1] = wave_max(v[1]); v[2] = wave_min(v[2]); v[3] = wave_max(v[3]);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
-  if (lane_id() == 0) { scratch[4 * w] = v[0]; scratch[4 * w + 1] = v[1]; scratch[4 * w + 2] = v[2]; scratch[4 * w + 3] = v[3]; }
+  if (lane_id() == 0) { sl[4 * w] = v[0]; sl[4 * w + 1] = v[1]; sl[4 * w + 2] = v[2]; sl[4 * w + 3] = v[3]; }
   __syncthreads();
   for (int i = 0; i < nw; i++) {
-    v[0] = fminf(v[0], scratch[4 * i]); v[1] = fmaxf(v[1], scratch[4 * i + 1]);
-    v[2] = fminf(v[2], scratch[4 * i + 2]); v[3] = fmaxf(v[3], scratch[4 * i + 3]);
+    v[0] = fminf(v[0], sl[4 * i]); v[1] = fmaxf(v[1], sl[4 * i + 1]);
+    v[2] = fminf(v[2], sl[4 * i + 2]); v[3] = fmaxf(v[3], sl[4 * i + 3]);
   }
 }
 __device__ __forceinline__ int block_sum(int v, int* scratch) {
+  auto* sl = CFEAR_LDS_PTR(int, scratch);
   v = wave_sum(v);
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
-  if (lane_id() == 0) scratch[w] = v;
+  if (lane_id() == 0) sl[w] = v;
   __syncthreads();
   int r = 0;
-  for (int i = 0; i < nw; i++) r += scratch[i];
+  for (int i = 0; i < nw; i++) r += sl[i];
   return r;
 }
 
 // Exclusive prefix sum of one int per thread; *total = block sum. scratch: >= 32 ints in LDS.
 __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
+  auto* sl = CFEAR_LDS_PTR(int, scratch);
   const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   int inc = v;
 #pragma unroll
@@ -87,11 +96,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
     if (lane >= off) inc += t;
   }
   __syncthreads();
-  if (lane == 63) scratch[w] = inc;
+  if (lane == 63) sl[w] = inc;
   __syncthreads();
   int base = 0, tot = 0;
   for (int i = 0; i < nw; i++) {
-    const int s = scratch[i];
+    const int s = sl[i];
     if (i < w) base += s;
     tot += s;
   }
@@ -103,6 +112,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
 // *total = block sum. scratch: >= 32 unsigned long long in LDS.
 __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long* scratch,
                                                                       unsigned long long* total) {
+  auto* sl = CFEAR_LDS_PTR(unsigned long long, scratch);
   const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   unsigned long long inc = v;
 #pragma unroll
@@ -111,11 +121,11 @@ __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned lo
     if (lane >= off) inc += t;
   }
   __syncthreads();
-  if (lane == 63) scratch[w] = inc;
+  if (lane == 63) sl[w] = inc;
   __syncthreads();
   unsigned long long base = 0, tot = 0;
   for (int i = 0; i < nw; i++) {
-    const unsigned long long s = scratch[i];
+    const unsigned long long s = sl[i];
     if (i < w) base += s;
     tot += s;
   }
