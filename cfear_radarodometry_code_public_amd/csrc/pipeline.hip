@@ -164,6 +164,8 @@ __global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans
 
 // ---- batched odometry: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all
 // state on the device, split after the feature build (:161) ------------------------------------------
+// TIMED: per-phase timestamps (tools/); the production instantiation carries no timer at all
+template <bool TIMED>
 __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
                                                                 const SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch) {
@@ -173,8 +175,8 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   const BlockScratch B = scratch[q];
   ScanDev* cur = scan_slots[(size_t)q * (OP.submap + 1) + st->free_slot];
   const Aff2 TprevMot = st->Tmot;  // :146
-  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
-  pt.mark();
+  PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
+  if (TIMED) pt.mark();
   // the dense voxel table of the counting sort starts all-zero (cleared here: the barriers of the cloud pass publish it)
   {
     uint4* kz = reinterpret_cast<uint4*>(lds + FeatLds::keys);
@@ -188,11 +190,11 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
                                  reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f),
                                  reinterpret_cast<double*>(lds + FeatLds::order),  // 3 doubles per bearing in the (still unused) order array
                                  (int)(CFEAR_LDS_POINT_CAP * sizeof(int) / (3 * sizeof(double))), bounds);
-  pt.mark();
-  pt.mark();
-  features_dispatch(cur, n, OP.fp, B, lds, &pt, n > 0 ? bounds : nullptr, true);  // :161
+  if (TIMED) { pt.mark(); pt.mark(); }
+  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true);  // :161
 }
 
+template <bool TIMED>
 __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
@@ -207,9 +209,9 @@ __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP,
   ScanDev* cur = my_slots[cur_slot];
   const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
   const int nkf = st->nkf;
-  PhaseTimer pt; pt.t = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
-  pt.acc = OP.phase_times ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
-  pt.mark();
+  PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
+  pt.acc = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
+  if (TIMED) pt.mark();
   const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
   cfear_reg_summary* sum = &summaries[q];
   __syncthreads();  // every thread has read the state before thread 0 rewrites it
@@ -240,9 +242,9 @@ __global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP,
   __syncthreads();
   const RegScratch RW = make_rscratch(B, lds);
   register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),
-                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), sum, &pt);  // :186 (result ignored, :184-186)
+                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), sum, TIMED ? &pt : nullptr);  // :186 (result ignored, :184-186)
   __syncthreads();
-  pt.mark();
+  if (TIMED) pt.mark();
   if (tid == 0) {
     Aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]);  // :195
     const Aff2 Tpi = aff_inv(T_prev);
@@ -810,10 +812,17 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   };
   auto launch_odometry = [&](int seq0, int count, hipStream_t st) {
     OdoParams P = OP; P.seq0 = seq0;
-    hipLaunchKernelGGL(features_step_kernel, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
-                       o->d_scan_ptrs, o->d_scratch_hdr);
-    hipLaunchKernelGGL(register_step_kernel, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    if (o->d_phase_times) {
+      hipLaunchKernelGGL(features_step_kernel<true>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
+                         o->d_scan_ptrs, o->d_scratch_hdr);
+      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    } else {
+      hipLaunchKernelGGL(features_step_kernel<false>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
+                         o->d_scan_ptrs, o->d_scratch_hdr);
+      hipLaunchKernelGGL(register_step_kernel<false>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    }
   };
   int rc = CFEAR_OK;
   if (o->nsub <= 1) {
