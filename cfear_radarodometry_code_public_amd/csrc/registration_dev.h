@@ -118,6 +118,10 @@ struct SolveSummary { int num_iterations; int termination; double final_cost; do
 enum { REG_CMD_BUILD = 1, REG_CMD_EVAL = 2, REG_CMD_DONE = 3 };
 enum { REG_ST_BUILD = 0, REG_ST_LM_IT0 = 1, REG_ST_LM_CAND = 2, REG_ST_COV = 3 };
 
+struct RegIo {  // where the controller reads/writes the caller-visible data
+  double* poses; double* cov6; cfear_reg_summary* out; double* par; int n;
+};
+
 // Block-shared state of one registration (LDS). The controller fields are only touched by wave 0.
 struct RegShared {
   // command published by the controller (wave 0) to all waves
@@ -128,6 +132,9 @@ struct RegShared {
   double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
   double Trel[CFEAR_REG_MAX_SCANS][6];  // Ttar^-1 * Tsrc (n_scan_normal.cpp:224)
   GridView kf[CFEAR_REG_MAX_SCANS];      // 1-NN search view of every scan (filled once per Register call)
+  // parameter blocks the out-of-line functions take by reference: kept here so that they are LDS reads, not reads
+  // of a per-thread stack copy
+  RegParams rp; RegScratch rw; RegIo rio;
   // ---- controller state: outer association loop (n_scan_normal.cpp:82-187)
   int success, nres, ret, pad0;
   double xcur[3], prev_par[3], tsrc_last[3], prev_score;
@@ -410,9 +417,6 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, Re
 // Controller (wave 0 only, all 64 lanes redundantly): a state machine advanced once per command.
 // Same arithmetic, in the same order, as the CPU oracle's register / LM routines (tests compare iteration counts).
 // ---------------------------------------------------------------------------------------------
-struct RegIo {  // where the controller reads/writes the caller-visible data
-  double* poses; double* cov6; cfear_reg_summary* out; double* par; int n;
-};
 
 __device__ __noinline__ void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
   sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
@@ -628,10 +632,18 @@ __device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const R
 // n_scan_normal_reg::Register. poses: n x 3 in global memory (in/out); cov6: 36 doubles or null;
 // out: summary in global memory. par_lds: >= 3*n doubles of LDS; sh: RegShared in LDS.
 // Wave 0 is the controller; every wave executes the published commands (two barriers per command).
-__device__ inline int register_block(ScanDev* const* scans, int n, double* poses, double* cov6, const RegParams& P,
-                                     const RegScratch& W, double* par_lds, RegShared* sh, cfear_reg_summary* out,
+__device__ inline int register_block(ScanDev* const* scans, int n, double* poses, double* cov6, const RegParams& P_in,
+                                     const RegScratch& W_in, double* par_lds, RegShared* sh, cfear_reg_summary* out,
                                      PhaseTimer* pt = nullptr) {
   const int tid = threadIdx.x;
+  if (tid == 0) {
+    sh->rp = P_in; sh->rw = W_in;
+    sh->rio.poses = poses; sh->rio.cov6 = cov6; sh->rio.out = out; sh->rio.par = par_lds; sh->rio.n = n;
+  }
+  __syncthreads();
+  const RegParams& P = sh->rp;
+  const RegScratch& W = sh->rw;
+  const RegIo& io = sh->rio;
   const bool master = (tid >> 6) == 0;
   // Affine3dToVectorXYeZ(Tsrc[i]) (:88-92): theta -> atan2(sin, cos)
   for (int i = tid; i < n; i += blockDim.x) {
@@ -646,7 +658,6 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     for (int i = 0; i < CFEAR_MAX_OUTER; i++) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
   }
   __syncthreads();
-  RegIo io; io.poses = poses; io.cov6 = cov6; io.out = out; io.par = par_lds; io.n = n;
   if (master) {
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
