@@ -236,6 +236,18 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     // Branch-free: out-of-range chunks read a clamped (valid) address and are zeroed afterwards, so
     // the NCH loads of 1 KiB each are all in flight together.
     uint4 v[NCH];
+    if (!edge_row && c_lo == 0) {
+      // common case (398 of 400 azimuths): everything the window needs lies inside this scan's image. Chunks past
+      // the halo re-read the last needed chunk (no extra HBM traffic); what they hold is never looked at: the
+      // selection masks them (vtail) and the suppression reads at most 6 bytes past the row.
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int cc = min(j * 64 + lane, c_hi - 1);
+        v[j] = *reinterpret_cast<const uint4*>(wp + (uint32_t)(16 * cc));
+      }
+#pragma unroll
+      for (int j = 0; j < NCH; j++) reinterpret_cast<uint4*>(win)[j * 64 + lane] = v[j];
+    } else {
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       const int c = j * 64 + lane;
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
         if (slo > 0 || shi < 16) staged = chunk_keep(staged, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
       }
       reinterpret_cast<uint4*>(win)[c] = staged;
+    }
     }
     // validity of the chunk bytes w.r.t. the row [0, R): only the first chunk group and the group(s)
     // holding the row end can be partial
