@@ -168,7 +168,7 @@ def main():
                                    "k=12, CFEAR-3 features (r=3.0), P2L + Huber 0.1, 4 keyframes, motion compensation on",
                        "sequences_per_gpu": B, "sweeps_per_step": B * world, "unique_sequences_per_gpu": args.unique,
                        "parallelism": "independent sequences per GPU; per sweep: 1 wavefront per azimuth row (filter), 1 workgroup per sequence (features, registration)"},
-            "roofline": {"bound": "hbm", "kernel": "kstrongest_kernel<4,8>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "kstrongest_kernel<4,7>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": ALGO_BYTES_PER_SCAN * scans_per_launch, "avg_launch_us": filt * 1e6,
                          "launches_per_step": launches_per_step},

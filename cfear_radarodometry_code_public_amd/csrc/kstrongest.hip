@@ -401,11 +401,15 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       const uint32_t woff = (uint32_t)(16 * (j * 64 + ln) + bi);  // window offset
       key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
     }
+    // rank = number of larger keys: every lane reads the same four keys per LDS instruction (broadcast), a compare and
+    // an add per key; lanes >= C hold key 0, so reading past C is harmless.
+    wave_lds_fence();  // every lane has fetched its slot code
+    keys[lane] = key;
+    wave_lds_fence();
     int rank = 0;
-    // lanes >= C hold key 0, so the loop may overrun C harmlessly: unrolled by 8, no per-key branch
-    for (int j = 0; j < C; j += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; u++) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j + u) > key) ? 1 : 0;
+    for (int j = 0; j < C; j += 4) {
+      const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
+      rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
     }
     const bool kept = lane < C && rank < kk;
     const int mpos = (int)(key & 0xFFFFu);
@@ -467,14 +471,14 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 
 }  // namespace
 
-// bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 grid oversubscription
-static int g_k1_dbg = 0, g_k1_occ = 8, g_k1_oversub = 4;
+// bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 rows per wave
+static int g_k1_dbg = 0, g_k1_occ = 7, g_k1_rows = 4;
 int g_cfear_odo_streams = 0;  // 0 = automatic (pipeline.hip)
 int g_cfear_odo_fork = 1;
 extern "C" void cfear_debug_set(int key, int value) {  // tuning hook of tools/, not part of the ABI
   if (key == 0) g_k1_dbg = value;
   if (key == 1) g_k1_occ = value;
-  if (key == 2) g_k1_oversub = value > 0 ? value : 1;
+  if (key == 2) g_k1_rows = value > 0 ? value : 1;
   if (key == 3) g_cfear_odo_streams = value;
   if (key == 4) g_cfear_odo_fork = value;
 }
@@ -489,9 +493,13 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const int u_zmin = (int)(uint8_t)(int)ctx->par.z_min;  // float -> int (radar_filters.cpp:198) -> uchar (:212)
   const int dbg = g_k1_dbg;
   // one resident wave per SIMD slot (256 CUs x 4 SIMDs x occupancy); each wave walks consecutive rows
-  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 8 ? 8 : (g_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
-  const long long slots_total = 1024LL * occ_eff * g_k1_oversub;
+  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 8 ? 8 : (g_k1_occ == 7 ? 7 : (g_k1_occ <= 5 ? 5 : 6))) : (R + 27 <= 8 * 1024 ? 3 : 2);
+  // A wave walks a few consecutive rows (the threshold of one azimuth is the first guess for the next): four rows
+  // per wave measured best from 256-scan to 1024-scan launches (shorter: every row pays the cold threshold search;
+  // longer: fewer, longer workgroups balance worse). Small launches spread their rows over the resident slots.
+  const long long slots_total = 1024LL * occ_eff;
   int rows_per_wave = (int)((n_rows + slots_total - 1) / slots_total);
+  if (rows_per_wave > g_k1_rows) rows_per_wave = g_k1_rows;
   if (rows_per_wave < 1) rows_per_wave = 1;
   const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
   const long long blocks = (n_waves + 3) / 4;
@@ -500,6 +508,8 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   if (R + 27 <= 4 * 1024) {
     if (occ >= 8)
       hipLaunchKernelGGL((kstrongest_kernel<4, 8>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    else if (occ == 7)
+      hipLaunchKernelGGL((kstrongest_kernel<4, 7>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
     else if (occ <= 5)
       hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
     else
