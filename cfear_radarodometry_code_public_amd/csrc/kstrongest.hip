@@ -28,15 +28,6 @@ constexpr uint32_t HI = 0x80808080u;
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// wave-wide sum of a small non-negative per-lane integer (< 2^BITS) by ballot bit-slicing
-template <int BITS>
-__device__ __forceinline__ int wave_sum_small(int v) {
-  int total = 0;
-#pragma unroll
-  for (int b = 0; b < BITS; b++) total += __popcll(__ballot((v >> b) & 1)) << b;
-  return total;
-}
-
 // wave64 inclusive prefix sum with DPP adds (Hillis-Steele inside the 16-lane rows, then two row broadcasts)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add_i(int v) {
@@ -50,6 +41,13 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   v = dpp_add_i<0x142, 0xA>(v);  // row_bcast15 -> rows 1, 3
   v = dpp_add_i<0x143, 0xC>(v);  // row_bcast31 -> rows 2, 3
   return v;
+}
+
+// wave-wide sum of a small non-negative per-lane integer: six DPP adds and a readlane (the ballot bit-slicing
+// it replaces cost two VALU instructions per bit)
+template <int BITS>
+__device__ __forceinline__ int wave_sum_small(int v) {
+  return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63);
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
