@@ -43,6 +43,22 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   return v;
 }
 
+// same shape with max (values >= 0): lane i gets the maximum over lanes 0..i
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_i(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+  v = dpp_max_i<0x111, 0xF>(v);
+  v = dpp_max_i<0x112, 0xF>(v);
+  v = dpp_max_i<0x114, 0xF>(v);
+  v = dpp_max_i<0x118, 0xF>(v);
+  v = dpp_max_i<0x142, 0xA>(v);
+  v = dpp_max_i<0x143, 0xC>(v);
+  return v;
+}
+
 // wave-wide sum of a small non-negative per-lane integer: six DPP adds and a readlane (the ballot bit-slicing
 // it replaces cost two VALU instructions per bit)
 template <int BITS>
@@ -195,12 +211,23 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   __shared__ uint4 lds_win[4][NCH * 64];
   __shared__ __attribute__((aligned(16))) uint32_t lds_keys[4][64];
   __shared__ uint32_t lds_ge[20];  // lds_ge[n] = candidate-mask bits of the chunk bytes with index >= n (n = 0..16)
+  __shared__ uint32_t lds_cmp[4][(1 + NCH / 2) * 64];  // per wave: slot offsets and candidate-mask words of every lane
+  __shared__ uint8_t lds_nth[256 * 8];                 // lds_nth[b * 8 + r] = position of the r-th set bit of byte b
   if (threadIdx.x <= 16) lds_ge[threadIdx.x] = chunk_range_mask((int)threadIdx.x, 16);
+  {
+    const uint32_t b = threadIdx.x;  // 256 threads, one byte value each
+    int r = 0;
+    for (int p = 0; p < 8; p++)
+      if ((b >> p) & 1u) lds_nth[b * 8 + r++] = (uint8_t)p;
+    for (; r < 8; r++) lds_nth[b * 8 + r] = 0;
+  }
   __syncthreads();  // the only block-level barrier: before the waves go their own way
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: keeps all per-row bookkeeping on the SALU
   uint8_t* const win = reinterpret_cast<uint8_t*>(&lds_win[wave][0]);
   uint32_t* const keys = &lds_keys[wave][0];
+  uint32_t* const cmp_ex = &lds_cmp[wave][0];   // [64] first slot of every lane
+  uint32_t* const cmp_w = &lds_cmp[wave][64];   // [NCH/2][64] mask words of every lane
   const long long scan_bytes = (long long)A * (long long)R;
   const int Tfloor = u_zmin > 1 ? u_zmin : 1;
 
@@ -351,53 +378,62 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       cnt += need;
     }
 
-    // ---- compaction of the <= 64 candidates into LDS keys: a lane's candidates take consecutive slots after
-    // those of the lower lanes (DPP prefix sum of the per-lane counts); the ranking below orders them ----
-    uint32_t w[NCH / 2];
-    pack_masks<NCH>(m, w);
-    {
-      int c = 0;
-#pragma unroll
-      for (int i = 0; i < NCH / 2; i++) c += __popc(w[i]);
-      int slot = wave_inclusive_scan(c) - c;
-      uint32_t any = 0;
-#pragma unroll
-      for (int i = 0; i < NCH / 2; i++) any |= w[i];
-      while (any != 0) {  // per-lane loop: as many rounds as the fullest lane has candidates
-        int wi = 0;
-        uint32_t cur = w[0];
-#pragma unroll
-        for (int i = 1; i < NCH / 2; i++)
-          if (cur == 0) { cur = w[i]; wi = i; }
-        const int t = __ffs(cur) - 1;
-        // compact code (bit t of word wi of this lane); decoded once per row by the lane that owns the slot
-        if (slot < 64) keys[slot] = (uint32_t)((t << 9) | (wi << 6) | lane);
-        slot++;
-        const uint32_t cleared = cur & (cur - 1);
-        any = 0;
-#pragma unroll
-        for (int i = 0; i < NCH / 2; i++) {
-          if (i == wi) w[i] = cleared;
-          any |= w[i];
-        }
-      }
-    }
+    // ---- compaction without a per-candidate loop (strong returns cluster: a lane often holds five or more
+    // candidates). Lane l's candidates take the slots ex[l] .. ex[l] + count - 1 (DPP prefix sum). The lane that
+    // owns slot s finds its producer l (producers scatter their id to their first slot, a DPP max-scan spreads it),
+    // fetches l's mask words from LDS and picks set bit number s - ex[l] (popcount split + byte table) ----
     const int nbase = cnt;
-    wave_lds_fence();
-    if (dbg == 3) {
-      if (nbase == 0x1234567) slots[g * (long long)k] = (uint32_t)nbase;
-      continue;
-    }
     const int C = cnt < 64 ? cnt : 64;
     const int kk = k < C ? k : C;  // number of emitted points
     uint32_t key = 0u;
-    if (lane < C) {
-      const uint32_t code = keys[lane];
-      const int t = (int)(code >> 9), wi = (int)((code >> 6) & 7u), ln = (int)(code & 63u);
-      const int j = 2 * wi + ((t >> 2) & 1);
-      const int bi = 4 * (t & 3) + (t >> 3);  // byte index inside the chunk
-      const uint32_t woff = (uint32_t)(16 * (j * 64 + ln) + bi);  // window offset
-      key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
+    {
+      uint32_t w[NCH / 2];
+      pack_masks<NCH>(m, w);
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) c += __popc(w[i]);
+      const int ex = wave_inclusive_scan(c) - c;
+      keys[lane] = 0u;
+      cmp_ex[lane] = (uint32_t)ex;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) cmp_w[i * 64 + lane] = w[i];
+      wave_lds_fence();
+      if (c > 0 && ex < 64) keys[ex] = (uint32_t)(lane + 1);
+      wave_lds_fence();
+      const int owner = wave_inclusive_max((int)keys[lane]) - 1;
+      if (dbg == 3) {
+        if (owner == 0x1234567) slots[g * (long long)k] = (uint32_t)nbase;
+        continue;
+      }
+      if (lane < C) {
+        const int l = owner;
+        int r = lane - (int)cmp_ex[l];
+        uint32_t sel = 0u;
+        int wi = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < NCH / 2; i++) {
+          const uint32_t wv = cmp_w[i * 64 + l];
+          const int ci = __popc(wv);
+          if (!found) {
+            if (r < ci) { sel = wv; wi = i; found = true; } else r -= ci;
+          }
+        }
+        int t = 0;  // position of set bit number r of sel
+        {
+          const uint32_t lo16 = sel & 0xFFFFu;
+          const int c16 = __popc(lo16);
+          if (r >= c16) { r -= c16; t = 16; sel >>= 16; } else sel = lo16;
+          const uint32_t lo8 = sel & 0xFFu;
+          const int c8 = __popc(lo8);
+          if (r >= c8) { r -= c8; t += 8; sel >>= 8; } else sel = lo8;
+          t += lds_nth[sel * 8 + r];
+        }
+        const int j = 2 * wi + ((t >> 2) & 1);
+        const int bi = 4 * (t & 3) + (t >> 3);  // byte index inside the chunk
+        const uint32_t woff = (uint32_t)(16 * (j * 64 + l) + bi);  // window offset
+        key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
+      }
     }
     // rank = number of larger keys: every lane reads the same four keys per LDS instruction (broadcast), a compare and
     // an add per key; lanes >= C hold key 0, so reading past C is harmless.
@@ -491,7 +527,7 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const int u_zmin = (int)(uint8_t)(int)ctx->par.z_min;  // float -> int (radar_filters.cpp:198) -> uchar (:212)
   const int dbg = g_k1_dbg;
   // one resident wave per SIMD slot (256 CUs x 4 SIMDs x occupancy); each wave walks consecutive rows
-  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 8 ? 8 : (g_k1_occ == 7 ? 7 : (g_k1_occ <= 5 ? 5 : 6))) : (R + 27 <= 8 * 1024 ? 3 : 2);
+  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 7 ? 7 : (g_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
   // A wave walks a few consecutive rows (the threshold of one azimuth is the first guess for the next): four rows
   // per wave measured best from 256-scan to 1024-scan launches (shorter: every row pays the cold threshold search;
   // longer: fewer, longer workgroups balance worse). Small launches spread their rows over the resident slots.
@@ -504,9 +540,7 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   dim3 grid((unsigned)blocks), block(256);
   const int occ = g_k1_occ;
   if (R + 27 <= 4 * 1024) {
-    if (occ >= 8)
-      hipLaunchKernelGGL((kstrongest_kernel<4, 8>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
-    else if (occ == 7)
+    if (occ >= 7)
       hipLaunchKernelGGL((kstrongest_kernel<4, 7>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
     else if (occ <= 5)
       hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
