@@ -205,7 +205,14 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     }
     double sq = r[0] * r[0];
     if (nr == 2) sq += r[1] * r[1];
-    const Rho rho = loss_eval(P.loss, P.loss_limit, sq);  // rho'' <= 0 for every loss here: the corrector's alpha is 0
+    Rho rho;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
+    if (P.loss == CFEAR_LOSS_HUBER) {  // the default loss inline (an out-of-line call pays a scratch save/restore), the others out of line
+      const double la = P.loss_limit, lb = la * la;
+      if (sq > lb) { const double r = sqrt(sq); rho.v = 2.0 * la * r - lb; rho.d1 = fmax(CFEAR_DBL_MIN, la / r); }
+      else { rho.v = sq; rho.d1 = 1.0; }
+    } else {
+      rho = loss_eval(P.loss, P.loss_limit, sq);
+    }
     a.cost += 0.5 * (rho.v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
     const double sr = sqrt(rho.d1 * wgt);
     for (int k = 0; k < nr; k++) {
