@@ -425,7 +425,7 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, Re
 // Same arithmetic, in the same order, as the CPU oracle's register / LM routines (tests compare iteration counts).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __noinline__ void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
+__device__ __forceinline__ void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
   sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
   { double sn, cs; sincos(x2, &sn, &cs); sh->c = cs; sh->s = sn; }
   sh->cmd = REG_CMD_EVAL; sh->state = state;
@@ -520,6 +520,7 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
     if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
     if (sh->radius < min_radius) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
     sh->iteration++;
+    __builtin_amdgcn_sched_barrier(0);  // keeps the (scalar) controller from holding all its LDS state in registers at once
     const NormalEq E = sh->E;
     const double sc0 = sh->sc0, sc1 = sh->sc1, sc2 = sh->sc2;
     double Hs[6], gs[3];
@@ -536,7 +537,9 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
     const double Am[6] = {Hs[0] + sh->dg0 * inv_radius, Hs[1], Hs[2], Hs[3] + sh->dg1 * inv_radius, Hs[4], Hs[5] + sh->dg2 * inv_radius};
     const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
     double y[3];
+    __builtin_amdgcn_sched_barrier(0);
     bool valid = chol3_solve(Am, rhs, y);
+    __builtin_amdgcn_sched_barrier(0);
     sh->reuse_diagonal = 1;
     double mcc = 0;
     if (valid) {
@@ -553,6 +556,7 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
       if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
       continue;
     }
+    __builtin_amdgcn_sched_barrier(0);
     sh->num_invalid = 0;
     sh->model_cost_change = mcc;
     sh->xc[0] = sh->xcur[0] + y[0] * sc0; sh->xc[1] = sh->xcur[1] + y[1] * sc1; sh->xc[2] = sh->xcur[2] + y[2] * sc2;
@@ -593,12 +597,14 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
   const NormalEq C = gather_partials(W);
+  __builtin_amdgcn_sched_barrier(0);
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
   const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
   if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
   const double cost_change = sh->x_cost - cand_cost;
   if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  __builtin_amdgcn_sched_barrier(0);
   const double relative_decrease = cost_change / sh->model_cost_change;
   sh->ss.num_iterations++;
   sh->ss.last_relative_decrease = relative_decrease;
@@ -606,6 +612,7 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
     sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
     sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
     sh->E = C; sh->x_cost = cand_cost;
+    __builtin_amdgcn_sched_barrier(0);
     const double t = 2.0 * relative_decrease - 1.0;
     sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
     sh->radius = fmin(max_radius, sh->radius);
@@ -618,6 +625,7 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
     sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
     if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
   }
+  __builtin_amdgcn_sched_barrier(0);
   ctl_lm_next(sh, io, P);
 }
 
