@@ -24,7 +24,6 @@ struct ScanDev {
   cfear_cell* cells;  // [cap_cells]
   float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
   int* gstart;        // [cap_grid + 1]
-  int* gorder;        // [cap_cells] cell indices bucketed by grid cell
   float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
   // registration views of the cells (the association is bound by the number of scattered load instructions,
   // so the fields it needs are packed): mean x, mean y, normal x, normal y, nsamples, scale
@@ -61,8 +60,6 @@ struct FeatureScratch {
   int* vlist;       // [n] voxel index of each occupied voxel, ascending
   int* vcur;        // global [cap_grid + 1] cursors of the cell-mean grid
   float* samples;   // global [cap_points][3] voxel centroids
-  cfear_cell* tmp;  // global [cap_points] candidate cells in sample order
-  int* flags;       // global [cap_points]
   int* red_i;       // LDS, >= 64 ints
   float* red_f;     // LDS, >= 64 floats
   bool lds;         // keys/order/vstart/vlist/spts are LDS arrays (enables the LDS counting sort)
@@ -631,7 +628,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
       cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
       const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
-      S->gorder[pos] = i;
       S->gpts[pos] = make_float4(mx, my, __int_as_float(i), 0.f);
     }
   } else {
@@ -659,7 +655,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
     cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
-    S->gorder[pos] = i;
     S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
   }
   }

@@ -24,7 +24,6 @@ namespace {
 constexpr int BLOCK_F = 1024;  // features / cloud kernels
 constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
 constexpr int MAX_SCANS = 64;  // keyframes + current
-constexpr int VOXEL_GRID_CAP = 65536;  // dense voxel-index table (e.g. 256 x 256 leaves)
 constexpr int LDS_P2 = 8192;   // sort keys held in LDS (clouds up to CFEAR_LDS_POINT_CAP points)
 
 struct FeatLds {  // byte offsets into the static LDS segment of the features kernels
@@ -48,17 +47,14 @@ struct RegLds {  // registration kernels
 // Global per-sequence working memory (also one per context for the per-call API).
 struct BlockScratch {
   uint64_t* keys; float* spts; int* order; int* vstart; int* vlist;  // big-cloud fallbacks of the LDS arrays
-  int* vidx;        // [VOXEL_GRID_CAP] dense voxel table, all zero between kernels
   int* vcur;        // [GRID_CAP + 2]
   int* rng;         // [cap_points][8] candidate row ranges per sample point
   double* part;     // [7][cap_points] partial cell moments per candidate chunk
   int* tmpi;        // [2 * cap_points + 16]
   float* samples;   // [cap_points * 3]
-  cfear_cell* tmp;  // [cap_points]
-  int* flags;       // [cap_points]
   double* match;    // [8][pair_cap]
   int* assoc;       // [pair_cap]
-  int cap_points, p2cap, pair_cap, gcap;
+  int cap_points, p2cap, pair_cap;
 };
 
 struct SeqState {  // OdometryKeyframeFuser members (odometrykeyframefuser.h:203-260) for one sequence
@@ -97,7 +93,7 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   W.tab_voxels = LDS ? (LDS_P2 * 4 < 32768 ? LDS_P2 * 4 - 2 : 32768) : 0;  // 16-bit counters over the key region, values < 65536
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
   W.cap = (LDS && B.cap_points > CFEAR_LDS_POINT_CAP) ? CFEAR_LDS_POINT_CAP : B.cap_points;
-  W.samples = B.samples; W.tmp = B.tmp; W.flags = B.flags;
+  W.samples = B.samples;
   W.red_i = reinterpret_cast<int*>(lds + FeatLds::red_i);
   W.red_f = reinterpret_cast<float*>(lds + FeatLds::red_f);
   return W;
@@ -118,7 +114,7 @@ __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char*
   const size_t c = (size_t)B.pair_cap;
   W.tmx = B.match; W.tmy = B.match + c; W.a0 = B.match + 2 * c; W.a1 = B.match + 3 * c; W.a2 = B.match + 4 * c;
   W.sx = B.match + 5 * c; W.sy = B.match + 6 * c; W.w = B.match + 7 * c;
-  W.assoc = B.assoc; W.sim = nullptr; W.cap = B.pair_cap;
+  W.assoc = B.assoc; W.cap = B.pair_cap;
   W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
   W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
   return W;
@@ -308,7 +304,7 @@ RegParams reg_params(const cfear_ctx* ctx) {
 
 constexpr int GRID_CAP = 128 * 128;
 
-struct ScanLayout { size_t xyi, cells, mean_f, gstart, gorder, gpts, rsrc, rtar, total; };
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, total; };
 ScanLayout scan_layout(int cap_points) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
@@ -316,7 +312,6 @@ ScanLayout scan_layout(int cap_points) {
   L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
   L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
-  L.gorder = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);
@@ -334,7 +329,6 @@ ScanDev scan_header(unsigned char* d_base, int cap_points) {
   h.cells = reinterpret_cast<cfear_cell*>(d_base + L.cells);
   h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
   h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
-  h.gorder = reinterpret_cast<int*>(d_base + L.gorder);
   h.gpts = reinterpret_cast<float4*>(d_base + L.gpts);
   h.rsrc = reinterpret_cast<double*>(d_base + L.rsrc);
   h.rtar = reinterpret_cast<double*>(d_base + L.rtar);
@@ -342,7 +336,7 @@ ScanDev scan_header(unsigned char* d_base, int cap_points) {
   return h;
 }
 
-struct ScratchLayout { size_t keys, spts, order, vstart, vlist, vidx, vcur, rng, part, tmpi, samples, tmp, flags, match, assoc, total; int p2cap; bool big; };
+struct ScratchLayout { size_t keys, spts, order, vstart, vlist, vcur, rng, part, tmpi, samples, match, assoc, total; int p2cap; bool big; };
 ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   ScratchLayout L;
   int p2 = 1; while (p2 < cap_points) p2 <<= 1;
@@ -355,14 +349,11 @@ ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   L.order = o; o = align_up(o + sizeof(int) * cp, 256);
   L.vstart = o; o = align_up(o + sizeof(int) * (cp + 2), 256);
   L.vlist = o; o = align_up(o + sizeof(int) * cp, 256);
-  L.vidx = o; o = align_up(o + sizeof(int) * VOXEL_GRID_CAP, 256);
   L.vcur = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
   L.rng = o; o = align_up(o + sizeof(int) * 8 * (size_t)cap_points, 256);
   L.part = o; o = align_up(o + sizeof(double) * 7 * (size_t)cap_points, 256);
   L.tmpi = o; o = align_up(o + sizeof(int) * (2 * (size_t)cap_points + 16), 256);
   L.samples = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
-  L.tmp = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
-  L.flags = o; o = align_up(o + sizeof(int) * (size_t)cap_points, 256);
   L.match = o; o = align_up(o + sizeof(double) * 8 * (size_t)pair_cap, 256);
   L.assoc = o; o = align_up(o + sizeof(int) * (size_t)pair_cap, 256);
   L.total = o;
@@ -376,17 +367,14 @@ BlockScratch scratch_header(unsigned char* d_base, int cap_points, int pair_cap)
   B.order = reinterpret_cast<int*>(d_base + L.order);
   B.vstart = reinterpret_cast<int*>(d_base + L.vstart);
   B.vlist = reinterpret_cast<int*>(d_base + L.vlist);
-  B.vidx = reinterpret_cast<int*>(d_base + L.vidx);
   B.vcur = reinterpret_cast<int*>(d_base + L.vcur);
   B.rng = reinterpret_cast<int*>(d_base + L.rng);
   B.part = reinterpret_cast<double*>(d_base + L.part);
   B.tmpi = reinterpret_cast<int*>(d_base + L.tmpi);
   B.samples = reinterpret_cast<float*>(d_base + L.samples);
-  B.tmp = reinterpret_cast<cfear_cell*>(d_base + L.tmp);
-  B.flags = reinterpret_cast<int*>(d_base + L.flags);
   B.match = reinterpret_cast<double*>(d_base + L.match);
   B.assoc = reinterpret_cast<int*>(d_base + L.assoc);
-  B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap; B.gcap = VOXEL_GRID_CAP;
+  B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap;
   return B;
 }
 
@@ -569,12 +557,6 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
   const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
   const FeatureParams P = feature_params(ctx);
-  if (getenv("CFEAR_DBG_PTRS")) {
-    const ScratchLayout WL = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
-    fprintf(stderr, "scan block %p +%zu | xyi %p cells %p mean_f %p gstart %p gorder %p\n", (void*)s->d_block, L.total, (void*)h.xyi, (void*)h.cells, (void*)h.mean_f, (void*)h.gstart, (void*)h.gorder);
-    fprintf(stderr, "scratch %p +%zu (alloc %zu) | keys %p vstart %p samples %p tmp %p flags %p match %p assoc %p\n", ctx->d_scratch, WL.total, ctx->scratch_bytes, (void*)B.keys, (void*)B.vstart, (void*)B.samples, (void*)B.tmp, (void*)B.flags, (void*)B.match, (void*)B.assoc);
-    fprintf(stderr, "cloud xyi %p cap %d d_n %p\n", (void*)cloud->d_xyi, cloud->cap, (void*)cloud->d_n);
-  }
   hipLaunchKernelGGL(features_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi,
                      cloud->d_n, P, B);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());

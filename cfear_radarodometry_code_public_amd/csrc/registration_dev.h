@@ -26,7 +26,6 @@ struct RegScratch {
   double* sx; double* sy;    // source mean (local frame)
   double* w;                 // weight after loss
   int* assoc;                // [pairs] target cell index or -1
-  float* sim;                // [pairs] direction similarity
   int cap;                   // capacity in pairs
   double* red;               // LDS, >= 10 * 32 doubles
   int* red_i;                // LDS, >= 64 ints (also used as 32 x u64 scan scratch)
