@@ -180,3 +180,41 @@ def test_reference_presets_through_device_fuser(oracle, k, cost, res, submap):
         assert np.all(np.abs(got[:2] - exp[:2]) < POS_TOL) and abs(got[2] - exp[2]) < ROT_TOL, (t, got, exp)
     odo.release()
     ctx.close()
+
+
+def test_sub_batch_streams_give_identical_results(oracle):
+    """The optional sub-batch streams (tuning hook cfear_debug_set(3, n): filter / features / registration of disjoint
+    sequence ranges on their own HIP streams, joined by the reading calls) must not change any result, for device-resident
+    input (free-running streams) and for host input (staging buffer reuse)."""
+    import ctypes as C
+    import torch
+    L = capi.lib()
+    L.cfear_debug_set.argtypes = [C.c_int, C.c_int]
+    imgs, _ = synth.world_sequence(6, seed=13)
+    imgs2, _ = synth.world_sequence(6, seed=14, t0=20)
+    B = 6
+    streams = [imgs, imgs2, imgs[:, ::-1].copy(), imgs2[:, ::-1].copy(), imgs, imgs2]
+    batches = np.stack([np.stack([s[t] for s in streams]) for t in range(6)])  # [T][B][A][R]
+    d_batches = torch.from_numpy(batches).cuda()
+    pg = mk_params(capi)
+    results = {}
+    try:
+        for nsub in (1, 3):
+            L.cfear_debug_set(3, nsub)
+            ctx = capi.Context(pg, 400, 3360)
+            odo = ctx.odometry(B)
+            for t in range(6):
+                if t % 2 == 0:
+                    odo.step_device(d_batches[t].data_ptr())
+                else:
+                    odo.step_host(batches[t])
+            poses = odo.poses()
+            summ = [odo.summary(q) for q in range(B)]
+            results[nsub] = (poses, [(s[0].outer_iterations, list(s[0].inner_iterations[:8]), s[1], s[2]) for s in summ])
+            odo.release()
+            ctx.close()
+    finally:
+        L.cfear_debug_set(3, 0)
+    assert np.array_equal(results[1][0], results[3][0])
+    assert results[1][1] == results[3][1]
+    assert np.all(np.isfinite(results[1][0])) and np.abs(results[1][0][:, :2]).max() > 1.0  # the sequences moved
