@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sequences", type=int, default=1024, help="independent sequences resident per GPU")
+    ap.add_argument("--sequences", type=int, default=1536,
+                    help="independent sequences resident per GPU (a multiple of 768 = 256 CUs x 3 registration workgroups fills whole rounds)")
     ap.add_argument("--unique", type=int, default=4, help="distinct synthetic sequences generated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-steps", type=int, default=3, help="extra steps fed from pinned host memory (PCIe-inclusive rate, N=1 only; 0 = skip)")
