@@ -158,6 +158,17 @@ __global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans
                  reinterpret_cast<RegShared*>(lds + RegLds::regsh), out);
 }
 
+__global__ __launch_bounds__(BLOCK_R) void get_cost_kernel(ScanDev* const* scans, int n, const double* poses, RegParams P, BlockScratch B,
+                                                           int itr, double* score, double* residuals, int cap, int* n_res) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];
+  __syncthreads();
+  const RegScratch W = make_rscratch(B, lds);
+  get_cost_block(sp, n, poses, P, W, reinterpret_cast<double*>(lds + RegLds::par), reinterpret_cast<RegShared*>(lds + RegLds::regsh), itr,
+                 score, residuals, cap, n_res);
+}
+
 // ---- batched odometry: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all
 // state on the device, split after the feature build (:161) ------------------------------------------
 // TIMED: per-phase timestamps (tools/); the production instantiation carries no timer at all
@@ -661,6 +672,51 @@ int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* pose
   if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6_last, d_cov, sizeof(double) * 36, hipMemcpyDeviceToHost, ctx->stream));
   if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(summary, d_sum, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double* score, double* residuals,
+                   int capacity, int* n_residuals) {
+  if (!ctx || !scans || !poses_xyt || !score || !n_residuals || n < 2 || capacity < 0 || (capacity > 0 && !residuals))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "get_cost: need >= 2 scans, poses and output pointers");
+  if (n > MAX_SCANS) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "get_cost: more than 64 scans");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int capmax = ctx->A * ctx->par.k_strongest;
+  for (int i = 0; i < n; i++) {
+    if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "get_cost: null scan");
+    if (scans[i]->cap_points > capmax) capmax = scans[i]->cap_points;
+  }
+  int rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
+  if (rc != CFEAR_OK) return rc;
+  const ScratchLayout L = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
+  unsigned char* base = static_cast<unsigned char*>(ctx->d_scratch);
+  const BlockScratch B = scratch_header(base, capmax, (MAX_SCANS - 1) * capmax);
+  unsigned char* tail = base + L.total;
+  double* d_poses = reinterpret_cast<double*>(tail);
+  double* d_score = d_poses + 3 * MAX_SCANS;  // the covariance slot of cfear_register
+  int* d_nres = reinterpret_cast<int*>(d_score + 1);
+  ScanDev** d_ptrs = reinterpret_cast<ScanDev**>(d_score + 36);
+  double* d_res = nullptr;
+  if (capacity > 0 && hipMalloc(&d_res, sizeof(double) * (size_t)capacity) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc residuals");
+  ScanDev* h_ptrs[MAX_SCANS];
+  for (int i = 0; i < n; i++) h_ptrs[i] = reinterpret_cast<ScanDev*>(scans[i]->d_block);
+  hipError_t e = hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(get_cost_kernel, dim3(1), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, reg_params(ctx), B, itr, d_score, d_res,
+                       capacity, d_nres);
+    e = hipGetLastError();
+  }
+  int nres = -1;
+  if (e == hipSuccess) e = hipMemcpyAsync(score, d_score, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&nres, d_nres, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && nres > 0 && capacity > 0)
+    e = hipMemcpy(residuals, d_res, sizeof(double) * (size_t)(nres < capacity ? nres : capacity), hipMemcpyDeviceToHost);
+  if (d_res) (void)hipFree(d_res);
+  if (e != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "get_cost", e);
+  *n_residuals = nres;
+  if (nres < 0) return cfear_fail(ctx, CFEAR_ERR_EMPTY, "get_cost: too few residuals");  // GetCost returns false (:205-208)
   return CFEAR_OK;
 }
 

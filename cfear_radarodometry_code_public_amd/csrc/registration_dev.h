@@ -163,7 +163,8 @@ __device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
 template <bool LDS, int COST>
-__device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s) {
+__device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s,
+                                                   double* res_out, int res_cap) {
   const int wave = threadIdx.x >> 6;
   if (wave >= CFEAR_EVAL_WAVES) return;
   // the LDS variant reads through an LDS-typed pointer (ds_read); a generic pointer costs flat loads
@@ -214,6 +215,10 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     }
     a.cost += 0.5 * (rho.v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
     const double sr = sqrt(rho.d1 * wgt);
+    if (res_out) {  // GetCost: the robustified residuals in residual-block order
+      for (int k = 0; k < nr; k++)
+        if (i * nr + k < res_cap) res_out[i * nr + k] = sr * r[k];
+    }
     for (int k = 0; k < nr; k++) {
       const double rk = sr * r[k];
       const double j0 = sr * J[k][0], j1 = sr * J[k][1], j2 = sr * J[k][2];
@@ -231,14 +236,16 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
   }
 }
 template <int COST>
-__device__ __noinline__ void evaluate_partial_c(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s) {
-  if (lds_match) evaluate_partial_t<true, COST>(W, M, P, x0, x1, c, s);
-  else evaluate_partial_t<false, COST>(W, M, P, x0, x1, c, s);
+__device__ __noinline__ void evaluate_partial_c(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
+                                                double* res_out, int res_cap) {
+  if (lds_match) evaluate_partial_t<true, COST>(W, M, P, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_t<false, COST>(W, M, P, x0, x1, c, s, res_out, res_cap);
 }
-__device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s) {
-  if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L>(W, M, lds_match, P, x0, x1, c, s);
-  else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D>(W, M, lds_match, P, x0, x1, c, s);
-  else evaluate_partial_c<CFEAR_COST_P2P>(W, M, lds_match, P, x0, x1, c, s);
+__device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
+                                                 double* res_out = nullptr, int res_cap = 0) {
+  if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_c<CFEAR_COST_P2P>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
 }
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
@@ -700,6 +707,48 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   const int ret = sh->ret;
   __syncthreads();
   return ret;
+}
+
+// n_scan_normal_reg::GetCost (n_scan_normal.cpp:188-213): associations and residual blocks at the given poses
+// (BuildOptimizationProblem with the caller's itr_, which only selects the association radius, :222), then
+// ceres::Problem::Evaluate with default options: *score = 1/2 sum rho, residuals = sqrt(rho') r per residual in
+// residual-block order. *n_res = number of residuals, or -1 where the reference returns false (<= 1 residuals).
+__device__ inline void get_cost_block(ScanDev* const* scans, int n, const double* poses, const RegParams& P_in, const RegScratch& W_in,
+                                      double* par_lds, RegShared* sh, int itr, double* score, double* residuals, int cap, int* n_res) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    sh->rp = P_in; sh->rw = W_in;
+    sh->rio.poses = nullptr; sh->rio.cov6 = nullptr; sh->rio.out = nullptr; sh->rio.par = par_lds; sh->rio.n = n;
+  }
+  for (int i = tid; i < n; i += blockDim.x) {  // Affine3dToVectorXYeZ (:196)
+    const Aff2 T = aff_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
+    double v[3]; aff_to_xyt(T, v);
+    par_lds[3 * i] = v[0]; par_lds[3 * i + 1] = v[1]; par_lds[3 * i + 2] = v[2];
+    sh->kf[i] = grid_view(scans[i]);
+  }
+  __syncthreads();
+  const RegParams& P = sh->rp;
+  const RegScratch& W = sh->rw;
+  if ((tid >> 6) == 0) {
+    const int L = 3 * (n - 1);
+    sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
+    ctl_publish_build(sh, sh->rio);
+  }
+  __syncthreads();
+  const int M = build_problem_block(scans, n, sh, P, itr, W);
+  const int nres = M * ((P.cost == CFEAR_COST_P2L) ? 1 : 2);
+  if (nres <= 1) {  // :205-208
+    if (tid == 0) { *n_res = -1; *score = 0.0; }
+    return;
+  }
+  double sn, cs;
+  sincos(sh->xcur[2], &sn, &cs);
+  evaluate_partial(W, M, sh->lds_match, P, sh->xcur[0], sh->xcur[1], cs, sn, residuals, cap);
+  __syncthreads();
+  if (tid == 0) {
+    const NormalEq E = gather_partials(W);
+    *score = E.cost; *n_res = nres;
+  }
 }
 
 }  // namespace cfear_dev

@@ -255,6 +255,27 @@ class n_scan_normal_reg {
     CFEAR_TIMING.Document("itrs", (double)itr_);  // n_scan_normal.cpp:161
     return summary_.success != 0;
   }
+  // bool GetCost(scans, Tsrc, score, residuals) (n_scan_normal.cpp:188-213): cost and robustified residuals at the given poses
+  bool GetCost(std::vector<MapNormalPtr>& scans, std::vector<Affine3d>& Tsrc, double& score, std::vector<double>& residuals) {
+    const size_t n = scans.size();
+    if (Tsrc.size() != n || n < 2) throw std::runtime_error("GetCost: scans/Tsrc size mismatch");  // assert at :190
+    cfear_params p = dev_->params();
+    p.cost = cost_ == P2L ? CFEAR_COST_P2L : (cost_ == P2D ? CFEAR_COST_P2D : CFEAR_COST_P2P); p.loss = (int)loss_; p.loss_limit = loss_limit_;
+    p.weight_opt = (int)weight_opt_; p.covar_scale = cov_scale_; p.regularization = regularization_;
+    dev_->set_params(p);
+    std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
+    for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = Tsrc[i].t[0]; poses[3 * i + 1] = Tsrc[i].t[1]; poses[3 * i + 2] = Tsrc[i].yaw(); }
+    int cap = 0; dev_->check(cfear_scan_size(dev_->ctx(), h.back(), &cap), "cfear_scan_size");
+    cap = 2 * (int)(n - 1) * (cap > 0 ? cap : 1);
+    residuals.assign((size_t)cap, 0.0);
+    int nres = -1;
+    const int rc = cfear_get_cost(dev_->ctx(), h.data(), (int)n, poses.data(), (int)itr_, &score, residuals.data(), cap, &nres);
+    if (rc == CFEAR_ERR_EMPTY) { residuals.clear(); return false; }  // "too few residuals" (:205-208)
+    dev_->check(rc, "cfear_get_cost");
+    residuals.resize((size_t)nres);
+    score_ = score / (double)(nres > 1 ? nres : 1);  // :211
+    return true;
+  }
   double getScore() const { return score_; }
   bool GetCovarianceScaler(double& cov_scale) const {  // n_scan_normal.cpp:435-441
     if (summary_.num_residuals - 3 == 0) return false; cov_scale = summary_.final_cost / (summary_.num_residuals - 3); return true; }

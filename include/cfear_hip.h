@@ -164,6 +164,15 @@ typedef struct cfear_reg_summary {
 int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
                    cfear_reg_summary* summary);
 
+/* bool GetCost(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc, double& score,
+ *              std::vector<double>& residuals) (n_scan_normal.cpp:188-213; called by the cost-sampling covariance,
+ * odometrykeyframefuser.cpp:305): associations and residual blocks at the given poses, no solve. itr = the object's
+ * itr_ (1 = double association radius, n_scan_normal.cpp:222). *score = 1/2 sum rho (ceres::Problem::Evaluate),
+ * residuals = the robustified residuals in residual-block order (at most `capacity` are written), *n_residuals =
+ * their number. Returns CFEAR_ERR_EMPTY (and *n_residuals = -1) where the reference returns false (<= 1 residuals). */
+int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double* score,
+                   double* residuals, int capacity, int* n_residuals);
+
 /* ---- Batched odometry: OdometryKeyframeFuser::pointcloudCallback for B independent sequences ---
  * (odometrykeyframefuser.cpp:143-259, :397-411) with the filter of radar_driver.cpp:48-70 in front.
  * All state (T_prev, Tmot, keyframe ring) lives on the device; one call = one radar sweep of every

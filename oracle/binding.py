@@ -94,6 +94,7 @@ def lib():
     L.cfo_scan_closest.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
     L.cfo_register.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, f64p, C.POINTER(Params), C.c_int,
                                C.POINTER(RegSummary)]
+    L.cfo_get_cost.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(Params), C.c_int, C.c_int, f64p, f64p, C.c_int]
     L.cfo_fuser_create.argtypes = [C.POINTER(Params)]
     L.cfo_fuser_create.restype = C.c_void_p
     L.cfo_fuser_free.argtypes = [C.c_void_p]
@@ -206,6 +207,21 @@ def register(scans, poses, params, brute=False):
     ret = lib().cfo_register(arr, n, _ptr(P, C.c_double), _ptr(cov, C.c_double), C.byref(params), int(brute),
                              C.byref(S))
     return ret, P, cov.reshape(6, 6), S
+
+
+def get_cost(scans, poses, params, itr=2, brute=False):
+    """n_scan_normal_reg::GetCost -> (score, residuals) or None where the reference returns false."""
+    n = len(scans)
+    arr = (C.c_void_p * n)(*[s._h for s in scans])
+    P = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    cap = 2 * (n - 1) * max(len(scans[-1].cells()), 1)
+    res = np.zeros(cap, dtype=np.float64)
+    score = np.zeros(1, dtype=np.float64)
+    m = lib().cfo_get_cost(arr, n, _ptr(P, C.c_double), C.byref(params), int(itr), int(brute), _ptr(score, C.c_double),
+                           _ptr(res, C.c_double), cap)
+    if m < 0:
+        return None
+    return float(score[0]), res[:m].copy()
 
 
 class Fuser:

@@ -631,7 +631,12 @@ typedef struct {
 /* [3P] ceres ResidualBlock::Evaluate + Corrector (rho'' <= 0 for every loss here => r~ = sqrt(rho')r).
  * cost = 1/2 sum rho(s); g = J~^T r~; H = J~^T J~ (00,01,02,11,12,22). Residual functors:
  * n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P). */
-static double evaluate(const problem_t* P, const double x[3], double g[3], double H[6]) {
+static double evaluate_res(const problem_t* P, const double x[3], double g[3], double H[6], double* res_out);
+static double evaluate(const problem_t* P, const double x[3], double g[3], double H[6]) { return evaluate_res(P, x, g, H, NULL); }
+/* res_out (optional): the robustified residuals, sqrt(rho') r, in residual-block order ([3P] what
+ * ceres::Problem::Evaluate returns with apply_loss_function = true) */
+static double evaluate_res(const problem_t* P, const double x[3], double g[3], double H[6], double* res_out) {
+  int nres_out = 0;
   const double c = cos(x[2]), s = sin(x[2]);
   double cost = 0;
   if (g) { g[0] = g[1] = g[2] = 0; for (int i = 0; i < 6; i++) H[i] = 0; }
@@ -665,6 +670,7 @@ static double evaluate(const problem_t* P, const double x[3], double g[3], doubl
     loss_eval(P->loss, P->loss_limit, sq, rho);
     rho[0] *= m->w; rho[1] *= m->w; rho[2] *= m->w; /* ScaledLoss (n_scan_normal.cpp:277) */
     cost += 0.5 * rho[0];
+    if (res_out) { const double sr = sqrt(rho[1]); for (int k = 0; k < nr; k++) res_out[nres_out++] = sr * r[k]; }
     if (g) {
       const double sr = sqrt(rho[1]);
       for (int k = 0; k < nr; k++) {
@@ -841,6 +847,37 @@ static int build_problem(cfo_scan* const* scans, int n, double (*par)[3], const 
 static void default_cov(double* cov6) {
   for (int i = 0; i < 36; i++) cov6[i] = 0;
   cov6[0] = 0.1 * 0.1; cov6[7] = 0.1 * 0.1; cov6[35] = 0.01 * 0.01; /* n_scan_normal.cpp:173 */
+}
+
+/* n_scan_normal_reg::GetCost (n_scan_normal.cpp:188-213): associations and residual blocks for the given poses
+ * (BuildOptimizationProblem with the object's current itr_, which only decides the association radius, :222),
+ * then ceres::Problem::Evaluate with default options: score = 1/2 sum rho, residuals = robustified residuals.
+ * Returns the number of residuals, or -1 where the reference returns false (<= 1 residuals). At most cap residuals
+ * are written. */
+int cfo_get_cost(cfo_scan* const* scans, int n, const double* poses_xyt, const cfo_params* p, int itr, int brute,
+                 double* score, double* residuals, int cap) {
+  if (n < 2 || n > 1024) return -1;
+  double(*par)[3] = (double(*)[3])malloc(sizeof(double) * 3 * (size_t)n);
+  for (int i = 0; i < n; i++) { /* Affine3dToVectorXYeZ (:196) */
+    const aff2 T = aff_from_xyt(poses_xyt[3 * i], poses_xyt[3 * i + 1], poses_xyt[3 * i + 2]);
+    aff_to_xyt(&T, par[i]);
+  }
+  const int nsrc = scans[n - 1]->ncells;
+  match_t* M = (match_t*)malloc(sizeof(match_t) * (size_t)((n - 1) * (nsrc > 0 ? nsrc : 1)));
+  problem_t P; P.m = M; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit;
+  int nres = 0;
+  P.nm = build_problem(scans, n, par, p, itr, brute, M, &nres);
+  int ret = -1;
+  if (nres > 1) { /* :205-208 */
+    double* all = (double*)malloc(sizeof(double) * (size_t)nres);
+    const double c = evaluate_res(&P, par[n - 1], NULL, NULL, all);
+    if (score) *score = c;
+    if (residuals) memcpy(residuals, all, sizeof(double) * (size_t)(nres < cap ? nres : cap));
+    free(all);
+    ret = nres;
+  }
+  free(M); free(par);
+  return ret;
 }
 
 int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
