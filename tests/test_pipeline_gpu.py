@@ -218,3 +218,39 @@ def test_sub_batch_streams_give_identical_results(oracle):
     assert np.array_equal(results[1][0], results[3][0])
     assert results[1][1] == results[3][1]
     assert np.all(np.isfinite(results[1][0])) and np.abs(results[1][0][:, :2]).max() > 1.0  # the sequences moved
+
+
+def _fuser_parity(oracle, imgs, A, R, **kw):
+    po, pg = mk_params(oracle, **kw), mk_params(capi, **kw)
+    fu = oracle.Fuser(po)
+    ctx = capi.Context(pg, A, R)
+    odo = ctx.odometry(1)
+    for t in range(imgs.shape[0]):
+        odo.step_host(imgs[t][None])
+        got = odo.poses()[0]
+        exp = fu.process_polar(imgs[t])
+        S, nc, nk = odo.summary(0)
+        So = fu.last_summary()
+        assert nk == fu.num_keyframes and nc == len(fu.last_cells())
+        assert S.outer_iterations == So.outer_iterations and list(S.inner_iterations[:8]) == list(So.inner_iterations[:8]), t
+        assert np.all(np.abs(got[:2] - exp[:2]) < POS_TOL) and abs(got[2] - exp[2]) < ROT_TOL, (t, got, exp)
+    odo.release()
+    ctx.close()
+    return got
+
+
+def test_baseline_config1_oxford_shape_pair(oracle):
+    """BASELINE configs[0] / SURVEY 8(d) Config 1 with the synthetic-world substitute: a 400 x 3768 sweep pair at
+    range_res 0.0438 (Oxford Navtech geometry), k=12, z_min=60, r=3.0, P2L + Huber 0.1; frame 1 registers against
+    exactly one keyframe (odometrykeyframefuser.cpp:171-177)."""
+    rr = np.float32(0.0438)
+    imgs, gt = synth.world_sequence(2, A=400, R=3768, range_res=rr, seed=41)
+    got = _fuser_parity(oracle, imgs, 400, 3768, range_res=rr, cost=1, loss=1, loss_limit=0.1, submap_scan_size=3, res=3.0)
+    assert np.linalg.norm(got[:2] - gt[-1, :2]) < 0.5
+
+
+def test_baseline_config3_p2d(oracle):
+    """SURVEY 8(d) Config 3: the configs[1] stream with cost P2D, regularization 0.1, covar_scale 1 (params/baseline_p2d)."""
+    imgs, gt = synth.world_sequence(6, seed=43, ccw=True)
+    got = _fuser_parity(oracle, imgs, 400, 3360, cost=2, regularization=0.1, covar_scale=1.0, radar_ccw=1, min_keyframe_dist=1.5)
+    assert np.linalg.norm(got[:2] - gt[-1, :2]) < 0.5
