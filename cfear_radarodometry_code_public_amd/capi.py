@@ -63,7 +63,7 @@ EXPORTS = [
     "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
-    "cfear_register", "cfear_get_cost", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
+    "cfear_register", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_time_kstrongest",
 ]
@@ -114,6 +114,8 @@ def lib():
         "cfear_scan_closest": (C.c_int, [vp, vp, f64p, C.c_int, C.c_double, i32p]),
         "cfear_register": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, f64p, C.POINTER(RegSummary)]),
         "cfear_get_cost": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, C.c_int, f64p, f64p, C.c_int, C.POINTER(C.c_int)]),
+        "cfear_cov_by_sampling": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                            C.c_double, C.c_int, f64p, C.POINTER(C.c_int), f64p]),
         "cfear_odometry_create": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "cfear_odometry_destroy": (None, [vp, vp]),
         "cfear_odometry_reset": (C.c_int, [vp, vp]),
@@ -279,6 +281,17 @@ class Context:
             return None
         self._check(rc, "cfear_get_cost")
         return score.value, res[:m.value].copy()
+
+    def cov_by_sampling(self, scans, poses, final_cost, num_residuals, itr=2, xy_range=0.4, yaw_range=0.0043625, steps=3, cov_scaler=4.0):
+        """approximateCovarianceBySampling -> (success, cov6x6, sampled costs)"""
+        n = len(scans)
+        arr = (C.c_void_p * n)(*[s._h for s in scans])
+        P = np.ascontiguousarray(poses, dtype=np.float64).reshape(n, 3).copy()
+        cov, costs, ok = np.zeros(36), np.zeros(steps ** 3), C.c_int()
+        self._check(self._L.cfear_cov_by_sampling(self._h, arr, n, P.ctypes.data, int(itr), float(xy_range), float(yaw_range), int(steps),
+                                                  float(cov_scaler), float(final_cost), int(num_residuals), cov.ctypes.data, C.byref(ok),
+                                                  costs.ctypes.data), "cfear_cov_by_sampling")
+        return bool(ok.value), cov.reshape(6, 6), costs
 
     def odometry(self, n_sequences):
         return Odometry(self, n_sequences)

@@ -169,6 +169,29 @@ __global__ __launch_bounds__(BLOCK_R) void get_cost_kernel(ScanDev* const* scans
                  score, residuals, cap, n_res);
 }
 
+// GetCost of many candidate poses of the last scan at once (cost-sampling covariance, odometrykeyframefuser.cpp:291-321):
+// one workgroup per sample pose; match arrays of workgroup b at match_base + b * 8 * cap (used when they do not fit in LDS)
+__global__ __launch_bounds__(BLOCK_R) void get_cost_samples_kernel(ScanDev* const* scans, int n, const double* poses, const double* samples,
+                                                                   RegParams P, double* match_base, int* assoc_base, int cap, int itr,
+                                                                   double* costs, int* n_res) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
+  __shared__ double my_poses[3 * MAX_SCANS];
+  const int b = blockIdx.x;
+  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) my_poses[i] = (i >= 3 * (n - 1)) ? samples[3 * b + (i - 3 * (n - 1))] : poses[i];
+  __syncthreads();
+  RegScratch W;
+  const size_t c = (size_t)cap;
+  double* m = match_base + (size_t)b * 8 * c;
+  W.tmx = m; W.tmy = m + c; W.a0 = m + 2 * c; W.a1 = m + 3 * c; W.a2 = m + 4 * c; W.sx = m + 5 * c; W.sy = m + 6 * c; W.w = m + 7 * c;
+  W.assoc = assoc_base + (size_t)b * c; W.cap = cap;
+  W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
+  W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
+  get_cost_block(sp, n, my_poses, P, W, reinterpret_cast<double*>(lds + RegLds::par), reinterpret_cast<RegShared*>(lds + RegLds::regsh), itr,
+                 costs + b, nullptr, 0, n_res + b);
+}
+
 // ---- batched odometry: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all
 // state on the device, split after the feature build (:161) ------------------------------------------
 // TIMED: per-phase timestamps (tools/); the production instantiation carries no timer at all
@@ -717,6 +740,151 @@ int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double
   if (e != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "get_cost", e);
   *n_residuals = nres;
   if (nres < 0) return cfear_fail(ctx, CFEAR_ERR_EMPTY, "get_cost: too few residuals");  // GetCost returns false (:205-208)
+  return CFEAR_OK;
+}
+
+// ---- cost-sampling covariance (odometrykeyframefuser.cpp:261-380) ------------------------------------
+namespace {
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 10): A = V diag(w) V^T
+void jacobi_sym(int n, double* A, double* V, double* w) {
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+        for (int k = 0; k < n; k++) { const double x = A[k * n + p], y = A[k * n + q]; A[k * n + p] = c * x - sn * y; A[k * n + q] = sn * x + c * y; }
+        for (int k = 0; k < n; k++) { const double x = A[p * n + k], y = A[q * n + k]; A[p * n + k] = c * x - sn * y; A[q * n + k] = sn * x + c * y; }
+        for (int k = 0; k < n; k++) { const double x = V[k * n + p], y = V[k * n + q]; V[k * n + p] = c * x - sn * y; V[k * n + q] = sn * x + c * y; }
+      }
+  }
+  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+// minimum-norm least squares of A c = b (A: m x 10), what Eigen's bdcSvd().solve() returns (:337): unit-norm columns,
+// eigen-decomposition of the scaled normal matrix, pseudo-inverse
+void lstsq10(int m, const double* A, const double* b, double c[10]) {
+  double scale[10], N[100], V[100], w[10], rhs[10], y[10];
+  for (int j = 0; j < 10; j++) {
+    double q = 0;
+    for (int i = 0; i < m; i++) q += A[i * 10 + j] * A[i * 10 + j];
+    scale[j] = q > 0 ? 1.0 / sqrt(q) : 0.0;
+  }
+  for (int j = 0; j < 10; j++) {
+    for (int k = 0; k < 10; k++) {
+      double q = 0;
+      for (int i = 0; i < m; i++) q += A[i * 10 + j] * A[i * 10 + k];
+      N[j * 10 + k] = q * scale[j] * scale[k];
+    }
+    double q = 0;
+    for (int i = 0; i < m; i++) q += A[i * 10 + j] * b[i];
+    rhs[j] = q * scale[j];
+  }
+  jacobi_sym(10, N, V, w);
+  double wmax = 0;
+  for (int j = 0; j < 10; j++) if (w[j] > wmax) wmax = w[j];
+  for (int j = 0; j < 10; j++) {
+    double q = 0;
+    for (int k = 0; k < 10; k++) q += V[k * 10 + j] * rhs[k];
+    y[j] = (w[j] > 1e-12 * wmax) ? q / w[j] : 0.0;
+  }
+  for (int k = 0; k < 10; k++) {
+    double q = 0;
+    for (int j = 0; j < 10; j++) q += V[k * 10 + j] * y[j];
+    c[k] = q * scale[k];
+  }
+}
+std::vector<double> linspace(double start, double end, int num) {  // odometrykeyframefuser.cpp:497-524
+  std::vector<double> v;
+  if (num <= 0) return v;
+  if (num == 1) { v.push_back(start); return v; }
+  const double delta = (end - start) / ((double)num - 1);
+  for (int i = 0; i < num - 1; i++) v.push_back(start + delta * i);
+  v.push_back(end);
+  return v;
+}
+}  // namespace
+
+int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double xy_range,
+                          double yaw_range, int samples_per_axis, double covariance_scaler, double final_cost, int num_residuals,
+                          double* cov6, int* success, double* sample_costs) {
+  if (!ctx || !scans || !poses_xyt || !cov6 || !success || n < 2 || samples_per_axis < 1 || samples_per_axis > 32)
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "cov_by_sampling: bad argument");
+  if (n > MAX_SCANS) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "cov_by_sampling: more than 64 scans");
+  *success = 0;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n; i++) if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cov_by_sampling: null scan");
+  int nsrc = 0;
+  int rc = cfear_scan_size(ctx, scans[n - 1], &nsrc);
+  if (rc != CFEAR_OK) return rc;
+  const int steps = samples_per_axis, m = steps * steps * steps, L = 3 * (n - 1);
+  const int cap = (n - 1) * (nsrc > 0 ? nsrc : 1);
+  const std::vector<double> xs = linspace(-xy_range * 0.5, xy_range * 0.5, steps), ths = linspace(-yaw_range * 0.5, yaw_range * 0.5, steps);  // :277-290
+  std::vector<double> samples(3 * (size_t)m), A(10 * (size_t)m), costs((size_t)m);
+  std::vector<int> nres((size_t)m);
+  int k = 0;
+  for (int it = 0; it < steps; it++)      // the reference's loop order (:294-296)
+    for (int ix = 0; ix < steps; ix++)
+      for (int iy = 0; iy < steps; iy++, k++) {
+        samples[3 * k] = xs[ix] + poses_xyt[L]; samples[3 * k + 1] = xs[iy] + poses_xyt[L + 1]; samples[3 * k + 2] = ths[it] + poses_xyt[L + 2];
+        const double x = xs[ix], y = xs[iy], z = ths[it];
+        double* r = &A[10 * (size_t)k];
+        r[0] = x * x; r[1] = y * y; r[2] = z * z; r[3] = x * y; r[4] = y * z; r[5] = z * x; r[6] = x; r[7] = y; r[8] = z; r[9] = 1.0;  // :325-336
+      }
+  // device buffers: poses, samples, scan pointers, costs, residual counts, per-sample match arrays
+  const size_t bytes = sizeof(double) * (3 * (size_t)n + 3 * (size_t)m + (size_t)m) + sizeof(void*) * (size_t)n + sizeof(int) * (size_t)m +
+                       (sizeof(double) * 8 + sizeof(int)) * (size_t)m * cap + 256;
+  unsigned char* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cost samples");
+  double* d_match = reinterpret_cast<double*>(d);
+  double* d_poses = d_match + 8 * (size_t)m * cap;
+  double* d_samples = d_poses + 3 * n;
+  double* d_costs = d_samples + 3 * m;
+  ScanDev** d_ptrs = reinterpret_cast<ScanDev**>(d_costs + m);
+  int* d_nres = reinterpret_cast<int*>(d_ptrs + n);
+  int* d_assoc = d_nres + m;
+  ScanDev* h_ptrs[MAX_SCANS];
+  for (int i = 0; i < n; i++) h_ptrs[i] = reinterpret_cast<ScanDev*>(scans[i]->d_block);
+  hipError_t e = hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_samples, samples.data(), sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(get_cost_samples_kernel, dim3(m), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, d_samples, reg_params(ctx), d_match,
+                       d_assoc, cap, itr, d_costs, d_nres);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(costs.data(), d_costs, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(nres.data(), d_nres, sizeof(int) * m, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "cov_by_sampling", e);
+  double last = 0.0;  // a failed GetCost leaves sample_cost at its previous value (:305: the return value is ignored)
+  for (int i = 0; i < m; i++) { if (nres[i] >= 0) last = costs[i]; costs[i] = last; }
+  if (sample_costs) memcpy(sample_costs, costs.data(), sizeof(double) * m);
+  double c[10];
+  lstsq10(m, A.data(), costs.data(), c);
+  double H[9] = {2 * c[0], c[3], c[5], c[3], 2 * c[1], c[4], c[5], c[4], 2 * c[2]};  // :340-343
+  double V[9], w[3];
+  jacobi_sym(3, H, V, w);
+  if (!(w[0] > 0.0 && w[1] > 0.0 && w[2] > 0.0)) return CFEAR_OK;  // not convex: sampling not used for this scan (:355-358)
+  if (num_residuals - 3 == 0) return CFEAR_OK;                      // GetCovarianceScaler false (n_scan_normal.cpp:435-441)
+  const double score_scale = final_cost / (double)(num_residuals - 3);
+  double C3[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double q = 0;
+      for (int t = 0; t < 3; t++) q += V[i * 3 + t] * V[j * 3 + t] / w[t];
+      C3[i * 3 + j] = 2.0 * q * score_scale * covariance_scaler;  // :363
+    }
+  for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;  // :366-373
+  cov6[0] = C3[0]; cov6[1] = C3[1]; cov6[6] = C3[3]; cov6[7] = C3[4];
+  cov6[35] = C3[8]; cov6[5] = C3[2]; cov6[11] = C3[5]; cov6[30] = C3[6]; cov6[31] = C3[7];
+  *success = 1;
   return CFEAR_OK;
 }
 

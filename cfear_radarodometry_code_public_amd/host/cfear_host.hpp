@@ -295,6 +295,9 @@ class OdometryKeyframeFuser {
     bool use_guess = true, disable_registration = false, soft_constraint = false, compensate = true, radar_ccw = false, use_keyframe = true;
     double res = 3.5, min_keyframe_dist_ = 1.5, min_keyframe_rot_deg_ = 5; std::string loss_type_ = "Huber"; double loss_limit_ = 0.1;
     double covar_scale_ = 1.0, regularization_ = 0.0;
+    // cost-sampling covariance (odometrykeyframefuser.h:104-110; the samples-to-file switch is not mirrored)
+    bool estimate_cov_by_sampling = false; double cov_sampling_xy_range = 0.4, cov_sampling_yaw_range = 0.0043625;
+    unsigned int cov_sampling_samples_per_axis = 3; double cov_sampling_covariance_scaler = 4.0;
   };
   OdometryKeyframeFuser(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) {
     (void)disable_callback;
@@ -348,6 +351,10 @@ class OdometryKeyframeFuser {
     const Affine3d Tmot_current = T_prev.inverse() * Tcurrent;
     if (!AccelerationVelocitySanityCheck(Tmot, Tmot_current)) Tcurrent = Tguess;  // :198-199
     Tmot = T_prev.inverse() * Tcurrent;  // :200
+    if (par.estimate_cov_by_sampling) {  // :203-208
+      Matrix6d cov_sampled;
+      if (approximateCovarianceBySampling(scans_vek, T_vek, cov_sampled)) { cov_current = cov_sampled; cov_vek.back() = cov_sampled; }
+    }
     const Affine3d Tkeydiff = keyframes_.back().pose.inverse() * Tcurrent;  // :227
     const bool fuse = KeyFrameBasedFuse(Tkeydiff, par.use_keyframe, par.min_keyframe_dist_, par.min_keyframe_rot_deg_);
     CFEAR_TIMING.Document("velocity", Tmot.translation_norm() / 0.25);  // :231
@@ -357,6 +364,19 @@ class OdometryKeyframeFuser {
       updated = true;
     }
     T_prev = Tcurrent;  // :257
+  }
+  // bool approximateCovarianceBySampling(scans_vek, T_vek, cov_sampled) (odometrykeyframefuser.cpp:261-380)
+  bool approximateCovarianceBySampling(std::vector<MapNormalPtr>& scans_vek, const std::vector<Affine3d>& T_vek, Matrix6d& cov_sampled) {
+    const size_t n = scans_vek.size();
+    std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
+    for (size_t i = 0; i < n; i++) { h[i] = scans_vek[i]->handle(); poses[3 * i] = T_vek[i].t[0]; poses[3 * i + 1] = T_vek[i].t[1]; poses[3 * i + 2] = T_vek[i].yaw(); }
+    double cov[36]; int ok = 0;
+    dev_->check(cfear_cov_by_sampling(dev_->ctx(), h.data(), (int)n, poses.data(), (int)radar_reg->itr_, par.cov_sampling_xy_range, par.cov_sampling_yaw_range,
+                                      (int)par.cov_sampling_samples_per_axis, par.cov_sampling_covariance_scaler, radar_reg->summary_.final_cost,
+                                      radar_reg->summary_.num_residuals, cov, &ok, nullptr), "cfear_cov_by_sampling");
+    if (!ok) return false;
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) cov_sampled.m[a][b] = cov[6 * a + b];
+    return true;
   }
   DevicePtr dev_; Parameters par;
   Affine3d Tcurrent, T_prev, Tmot; Matrix6d cov_current; std::vector<Keyframe> keyframes_; size_t nr_callbacks_ = 0;

@@ -173,6 +173,17 @@ int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* pose
 int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double* score,
                    double* residuals, int capacity, int* n_residuals);
 
+/* bool OdometryKeyframeFuser::approximateCovarianceBySampling(scans_vek, T_vek, cov_sampled)
+ * (odometrykeyframefuser.cpp:261-380): GetCost on samples_per_axis^3 poses around poses_xyt[n-1] (all samples in one
+ * launch, one workgroup each), least-squares quadratic, Hessian -> covariance scaled by GetCovarianceScaler
+ * (final_cost / (num_residuals - 3) of the preceding Register) and covariance_scaler. Parameters are
+ * par.cov_sampling_xy_range (0.4), cov_sampling_yaw_range (0.0043625), cov_sampling_samples_per_axis (3),
+ * cov_sampling_covariance_scaler (4.0) (odometrykeyframefuser.h:107-110). *success = the reference's bool; cov6 = 36
+ * doubles row-major (written only on success); sample_costs: optional samples_per_axis^3 sampled costs. */
+int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double xy_range,
+                          double yaw_range, int samples_per_axis, double covariance_scaler, double final_cost,
+                          int num_residuals, double* cov6, int* success, double* sample_costs);
+
 /* ---- Batched odometry: OdometryKeyframeFuser::pointcloudCallback for B independent sequences ---
  * (odometrykeyframefuser.cpp:143-259, :397-411) with the filter of radar_driver.cpp:48-70 in front.
  * All state (T_prev, Tmot, keyframe ring) lives on the device; one call = one radar sweep of every

@@ -95,6 +95,8 @@ def lib():
     L.cfo_register.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, f64p, C.POINTER(Params), C.c_int,
                                C.POINTER(RegSummary)]
     L.cfo_get_cost.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(Params), C.c_int, C.c_int, f64p, f64p, C.c_int]
+    L.cfo_cov_by_sampling.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(Params), C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_int, C.c_double, C.c_double, C.c_int, f64p, f64p]
     L.cfo_fuser_create.argtypes = [C.POINTER(Params)]
     L.cfo_fuser_create.restype = C.c_void_p
     L.cfo_fuser_free.argtypes = [C.c_void_p]
@@ -222,6 +224,21 @@ def get_cost(scans, poses, params, itr=2, brute=False):
     if m < 0:
         return None
     return float(score[0]), res[:m].copy()
+
+
+def cov_by_sampling(scans, poses, params, final_cost, num_residuals, itr=2, xy_range=0.4, yaw_range=0.0043625, steps=3,
+                    cov_scaler=4.0, brute=False):
+    """approximateCovarianceBySampling with the defaults of OdometryKeyframeFuser::Parameters (odometrykeyframefuser.h:107-110)
+    -> (success, cov6x6, sampled costs)"""
+    n = len(scans)
+    arr = (C.c_void_p * n)(*[s._h for s in scans])
+    P = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    cov = np.zeros(36)
+    costs = np.zeros(steps ** 3)
+    ok = lib().cfo_cov_by_sampling(arr, n, _ptr(P, C.c_double), C.byref(params), int(itr), int(brute), float(xy_range), float(yaw_range),
+                                   int(steps), float(cov_scaler), float(final_cost), int(num_residuals), _ptr(cov, C.c_double),
+                                   _ptr(costs, C.c_double))
+    return bool(ok), cov.reshape(6, 6), costs
 
 
 class Fuser:

@@ -880,6 +880,141 @@ int cfo_get_cost(cfo_scan* const* scans, int n, const double* poses_xyt, const c
   return ret;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Cost-sampling covariance: OdometryKeyframeFuser::approximateCovarianceBySampling
+ * (odometrykeyframefuser.cpp:261-380) with linspace (:497-524)
+ * ------------------------------------------------------------------------------------------ */
+static int linspace_d(double start, double end, int num, double* out) { /* :497-524 */
+  if (num <= 0) return 0;
+  if (num == 1) { out[0] = start; return 1; }
+  const double delta = (end - start) / ((double)num - 1);
+  for (int i = 0; i < num - 1; i++) out[i] = start + delta * i;
+  out[num - 1] = end;
+  return num;
+}
+
+/* cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 10): A = V diag(w) V^T */
+static void jacobi_sym(int n, double* A, double* V, double* w) {
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = A[p * n + q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
+}
+
+/* minimum-norm least-squares solution of A c = b (A: m x 10), [3P] what Eigen's bdcSvd().solve() returns:
+ * columns are scaled to unit norm, the scaled normal matrix is eigen-decomposed and pseudo-inverted */
+static void lstsq10(int m, const double* A, const double* b, double c[10]) {
+  double scale[10], N[100], V[100], w[10], rhs[10];
+  for (int j = 0; j < 10; j++) {
+    double s = 0;
+    for (int i = 0; i < m; i++) s += A[i * 10 + j] * A[i * 10 + j];
+    scale[j] = s > 0 ? 1.0 / sqrt(s) : 0.0;
+  }
+  for (int j = 0; j < 10; j++) {
+    for (int k = 0; k < 10; k++) {
+      double s = 0;
+      for (int i = 0; i < m; i++) s += A[i * 10 + j] * A[i * 10 + k];
+      N[j * 10 + k] = s * scale[j] * scale[k];
+    }
+    double s = 0;
+    for (int i = 0; i < m; i++) s += A[i * 10 + j] * b[i];
+    rhs[j] = s * scale[j];
+  }
+  jacobi_sym(10, N, V, w);
+  double wmax = 0;
+  for (int j = 0; j < 10; j++) if (w[j] > wmax) wmax = w[j];
+  double y[10];
+  for (int j = 0; j < 10; j++) {
+    double s = 0;
+    for (int k = 0; k < 10; k++) s += V[k * 10 + j] * rhs[k];
+    y[j] = (w[j] > 1e-12 * wmax) ? s / w[j] : 0.0;
+  }
+  for (int k = 0; k < 10; k++) {
+    double s = 0;
+    for (int j = 0; j < 10; j++) s += V[k * 10 + j] * y[j];
+    c[k] = s * scale[k];
+  }
+}
+
+/* Returns 1 and fills cov6 (36 doubles, row-major) where the reference returns true. sample_costs (optional, steps^3
+ * doubles) receives the sampled costs in the reference's loop order (theta outer, x, y inner). final_cost and
+ * num_residuals are those of the preceding Register (GetCovarianceScaler, n_scan_normal.cpp:435-441). */
+int cfo_cov_by_sampling(cfo_scan* const* scans, int n, const double* poses_xyt, const cfo_params* p, int itr, int brute,
+                        double xy_range, double yaw_range, int steps, double cov_scaler, double final_cost, int num_residuals,
+                        double* cov6, double* sample_costs) {
+  if (steps < 1 || steps > 64 || n < 2) return 0;
+  const int m = steps * steps * steps;
+  double* xs = (double*)malloc(sizeof(double) * (size_t)steps);
+  double* ths = (double*)malloc(sizeof(double) * (size_t)steps);
+  linspace_d(-xy_range * 0.5, xy_range * 0.5, steps, xs);   /* :277-289 */
+  linspace_d(-yaw_range * 0.5, yaw_range * 0.5, steps, ths);
+  double* A = (double*)malloc(sizeof(double) * 10 * (size_t)m);
+  double* b = (double*)malloc(sizeof(double) * (size_t)m);
+  double* poses = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+  memcpy(poses, poses_xyt, sizeof(double) * 3 * (size_t)n);
+  const int L = 3 * (n - 1);
+  double sample_cost = 0; /* not reset when GetCost fails: the reference ignores its return value (:305) */
+  int k = 0;
+  for (int it = 0; it < steps; it++)
+    for (int ix = 0; ix < steps; ix++)
+      for (int iy = 0; iy < steps; iy++) {
+        poses[L] = xs[ix] + poses_xyt[L]; poses[L + 1] = xs[iy] + poses_xyt[L + 1];
+        poses[L + 2] = ths[it] + poses_xyt[L + 2]; /* Rz(theta_s) * Rz(yaw) */
+        double sc = 0;
+        if (cfo_get_cost(scans, n, poses, p, itr, brute, &sc, NULL, 0) >= 0) sample_cost = sc;
+        const double x = xs[ix], y = xs[iy], z = ths[it];
+        double* r = A + 10 * (size_t)k;
+        r[0] = x * x; r[1] = y * y; r[2] = z * z; r[3] = x * y; r[4] = y * z; r[5] = z * x; r[6] = x; r[7] = y; r[8] = z; r[9] = 1.0;
+        b[k] = sample_cost;
+        if (sample_costs) sample_costs[k] = sample_cost;
+        k++;
+      }
+  double c[10];
+  lstsq10(m, A, b, c);
+  free(xs); free(ths); free(A); free(b); free(poses);
+  double H[9] = {2 * c[0], c[3], c[5], c[3], 2 * c[1], c[4], c[5], c[4], 2 * c[2]}; /* :340-343 */
+  double Hc[9], V[9], w[3];
+  memcpy(Hc, H, sizeof(H));
+  jacobi_sym(3, Hc, V, w);
+  if (!(w[0] > 0.0 && w[1] > 0.0 && w[2] > 0.0)) return 0; /* not convex (:355-358) */
+  if (num_residuals - 3 == 0) return 0;                     /* GetCovarianceScaler false */
+  const double score_scale = final_cost / (double)(num_residuals - 3);
+  double C3[9]; /* 2 * H^-1 * score_scale * scaler, H^-1 = V diag(1/w) V^T */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0;
+      for (int q = 0; q < 3; q++) s += V[i * 3 + q] * V[j * 3 + q] / w[q];
+      C3[i * 3 + j] = 2.0 * s * score_scale * cov_scaler;
+    }
+  for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0; /* :367-374 */
+  cov6[0] = C3[0]; cov6[1] = C3[1]; cov6[6] = C3[3]; cov6[7] = C3[4];
+  cov6[35] = C3[8]; cov6[5] = C3[2]; cov6[11] = C3[5]; cov6[30] = C3[6]; cov6[31] = C3[7];
+  return 1;
+}
+
 int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
                  int brute, cfo_reg_summary* out) {
   cfo_reg_summary S;

@@ -135,6 +135,11 @@ typedef struct cfo_reg_summary {
  * Returns the number of residuals or -1 (reference: false). */
 int cfo_get_cost(cfo_scan* const* scans, int n, const double* poses_xyt, const cfo_params* p, int itr, int brute,
                  double* score, double* residuals, int cap);
+/* OdometryKeyframeFuser::approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380); returns the
+ * reference's bool, cov6 = 36 doubles row-major; sample_costs (optional) = steps^3 sampled costs */
+int cfo_cov_by_sampling(cfo_scan* const* scans, int n, const double* poses_xyt, const cfo_params* p, int itr, int brute,
+                        double xy_range, double yaw_range, int steps, double cov_scaler, double final_cost, int num_residuals,
+                        double* cov6, double* sample_costs);
 int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6,
                  const cfo_params* p, int brute, cfo_reg_summary* out);
 

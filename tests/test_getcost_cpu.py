@@ -84,3 +84,49 @@ def test_get_cost_false_with_too_few_residuals(oracle):
     poses = gt[:2].copy()
     poses[1, :2] += [500.0, 500.0]  # nothing associates
     assert oracle.get_cost(scans, poses, p) is None
+
+
+def numpy_cov_by_sampling(oracle, scans, poses, p, final_cost, num_residuals, itr, xy_range, yaw_range, steps, scaler):
+    """approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380) with numpy's lstsq / eigh"""
+    def linspace(a, b, n):  # :497-524
+        if n == 1:
+            return [a]
+        d = (b - a) / (n - 1)
+        return [a + d * i for i in range(n - 1)] + [b]
+    xs, ths = linspace(-xy_range * 0.5, xy_range * 0.5, steps), linspace(-yaw_range * 0.5, yaw_range * 0.5, steps)
+    rows, costs, last = [], [], 0.0
+    for th in ths:
+        for x in xs:
+            for y in xs:
+                P = np.array(poses, dtype=np.float64)
+                P[-1] += [x, y, th]
+                got = oracle.get_cost(scans, P, p, itr=itr)
+                if got is not None:
+                    last = got[0]
+                rows.append([x * x, y * y, th * th, x * y, y * th, th * x, x, y, th, 1.0])
+                costs.append(last)
+    c = np.linalg.lstsq(np.array(rows), np.array(costs), rcond=None)[0]
+    H = np.array([[2 * c[0], c[3], c[5]], [c[3], 2 * c[1], c[4]], [c[5], c[4], 2 * c[2]]])
+    if np.any(np.linalg.eigvalsh(H) <= 0) or num_residuals - 3 == 0:
+        return False, None, np.array(costs)
+    C3 = 2.0 * np.linalg.inv(H) * (final_cost / (num_residuals - 3)) * scaler
+    cov = np.eye(6)
+    cov[:2, :2] = C3[:2, :2]; cov[5, 5] = C3[2, 2]; cov[0, 5] = C3[0, 2]; cov[1, 5] = C3[1, 2]; cov[5, 0] = C3[2, 0]; cov[5, 1] = C3[2, 1]
+    return True, cov, np.array(costs)
+
+
+@pytest.mark.parametrize("steps,xy,yaw", [(3, 0.4, 0.0043625), (5, 0.4, 0.0043625), (3, 1.0, 0.02)])
+def test_cov_by_sampling_matches_numpy(oracle, steps, xy, yaw):
+    p = oracle.default_params(range_res=RR, z_min=60.0, res=3.0, cost=1, loss=1, loss_limit=0.1, weight_opt=4, weight_intensity=1)
+    scans, gt = scans_of(oracle, 4, p)
+    poses = gt[:4].copy()
+    ret, P, cov_reg, S = oracle.register(scans, poses, p)  # sample around the registered pose, as processFrame does
+    itr = S.outer_iterations
+    ok, cov, costs = oracle.cov_by_sampling(scans, P, p, S.final_cost, S.num_residuals, itr=itr, xy_range=xy, yaw_range=yaw, steps=steps)
+    ok2, cov2, costs2 = numpy_cov_by_sampling(oracle, scans, P, p, S.final_cost, S.num_residuals, itr, xy, yaw, steps, 4.0)
+    assert np.allclose(costs, costs2, rtol=0, atol=1e-12)
+    assert costs.argmin() == len(costs) // 2 or costs.min() > costs[len(costs) // 2] - 1e-3  # the registered pose is (near) the best sample
+    assert ok == ok2
+    if ok:
+        assert np.allclose(cov, cov2, rtol=1e-6, atol=1e-12)
+        assert cov[0, 0] > 0 and cov[1, 1] > 0 and cov[5, 5] > 0 and np.allclose(cov, cov.T)

@@ -52,3 +52,19 @@ def test_get_cost_false_and_capacity(oracle, hip_lib):
     exp = oracle.get_cost(so, poses, po, itr=2)
     assert rc == 0 and m.value == len(exp[1]) and np.allclose(res[:5], exp[1][:5], atol=1e-9) and np.all(res[5:] == -1.0)
     ctx.close()
+
+
+@pytest.mark.parametrize("steps,xy,yaw,cost", [(3, 0.4, 0.0043625, 1), (5, 0.4, 0.0043625, 1), (3, 1.0, 0.02, 2), (2, 0.4, 0.0043625, 0)])
+def test_cov_by_sampling_matches_oracle(oracle, steps, xy, yaw, cost):
+    """approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380): all sample poses in one launch"""
+    po, ctx, so, sg, gt = build(oracle, 4, cost=cost, loss=1, weight_opt=4, loss_limit=0.1)
+    poses = gt[:4].copy()
+    ret, P, cov_reg, S = oracle.register(so, poses, po)  # processFrame samples around the registered pose
+    itr = S.outer_iterations
+    ok_o, cov_o, costs_o = oracle.cov_by_sampling(so, P, po, S.final_cost, S.num_residuals, itr=itr, xy_range=xy, yaw_range=yaw, steps=steps)
+    ok_g, cov_g, costs_g = ctx.cov_by_sampling(sg, P, S.final_cost, S.num_residuals, itr=itr, xy_range=xy, yaw_range=yaw, steps=steps)
+    assert np.allclose(costs_g, costs_o, rtol=1e-10, atol=1e-10)
+    assert ok_g == ok_o
+    if ok_o:
+        assert np.allclose(cov_g, cov_o, rtol=1e-5, atol=1e-12)
+    ctx.close()
