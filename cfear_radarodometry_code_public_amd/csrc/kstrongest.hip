@@ -11,11 +11,13 @@
 //
 // Selection (bit-exact with the reference's bounded sorted insert): the result is the k largest
 // keys (intensity, range) among bytes >= z_min. Instead of sorting, the wave
-//   1. bounds the k-th largest intensity from below by the k-th largest per-lane maximum,
+//   1. probes the previous azimuth's threshold T (a wave walks consecutive rows); if that yields fewer than k
+//      candidates it bounds the k-th largest intensity from below by the k-th largest per-lane maximum,
 //   2. counts bytes >= T with SWAR compares (4 bytes / 5 VALU ops) and narrows T by bisection
 //      until k <= count <= 64 (usually the first probe),
-//   3. compacts the <= 64 candidates through LDS, ranks them (key includes the range, so ties go
-//      to the larger range bin exactly like std::pair<uchar,int> ordering) and
+//   3. gives every candidate a lane without a per-candidate loop (prefix sums, owner scatter + DPP max-scan,
+//      popcount split + byte table), ranks the keys with LDS broadcast reads (the key includes the range, so
+//      ties go to the larger range bin exactly like std::pair<uchar,int> ordering) and
 //   4. handles rows with > 64 ties at the threshold intensity by a backwards positional scan.
 // No block-level barrier is used: the four waves of a block are independent.
 #include <stdlib.h>
