@@ -233,7 +233,7 @@ __device__ inline int lower_bound_int(const int* a, int n, long long v) {
 
 // shifted weighted moments of the points q in [a, b) of the sorted array that lie within r2 of (cx, cy)
 struct CellAcc { int m; double s0, s1x, s1y, sxx, sxy, syy; };
-// lane `sub` of a group of GS lanes takes the batches a + 4*sub, a + 4*(sub + GS), ...
+// lane `sub` of a group of GS lanes takes the batches a + 4*sub, a + 4*(sub + GS), ... (the chunked caller uses sub = 0, GS = 1)
 __device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, int a, int b, float cx, float cy, float r2,
                                         int weight_intensity, CellAcc& A, int sub, int GS) {
   const double cxd = (double)cx, cyd = (double)cy;
@@ -411,8 +411,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   //   mean = c + S1/S0,  cov = S2/S0 - (S1/S0)(S1/S0)^T   (== sum w_i (x_i-u)(x_i-u)^T with sum w_i = 1)
   const float r2 = (float)((double)P.radius * (double)P.radius);
   const float rq = P.radius * 1.0001f;
-  // Groups of 8 lanes share one sample point (candidate counts range from 1 to ~1000 per voxel, so a
-  // thread-per-voxel mapping is badly imbalanced); fixed xor-tree reduction keeps the result deterministic.
   // Candidate counts range from 1 to ~1000 per sample point, so the work is cut into chunks of at most C
   // candidates: (1) per sample the candidate row ranges and their total, (2) a scan turns them into a chunk
   // list, (3) one lane per chunk accumulates partial moments, (4) the epilogue adds a sample's partials in
