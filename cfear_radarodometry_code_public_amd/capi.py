@@ -63,7 +63,7 @@ EXPORTS = [
     "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
-    "cfear_register", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
+    "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_time_kstrongest",
 ]
@@ -113,6 +113,7 @@ def lib():
         "cfear_scan_download_cells": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
         "cfear_scan_closest": (C.c_int, [vp, vp, f64p, C.c_int, C.c_double, i32p]),
         "cfear_register": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, f64p, C.POINTER(RegSummary)]),
+        "cfear_register_soft": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, f64p, f64p, C.POINTER(RegSummary)]),
         "cfear_get_cost": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, C.c_int, f64p, f64p, C.c_int, C.POINTER(C.c_int)]),
         "cfear_cov_by_sampling": (C.c_int, [vp, C.POINTER(vp), C.c_int, f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
                                             C.c_double, C.c_int, f64p, C.POINTER(C.c_int), f64p]),
@@ -266,6 +267,17 @@ class Context:
         cov = np.zeros(36)
         S = RegSummary()
         self._check(self._L.cfear_register(self._h, arr, n, P.ctypes.data, cov.ctypes.data, C.byref(S)), "cfear_register")
+        return bool(S.success), P, cov.reshape(6, 6), S
+
+    def register_soft(self, scans, poses, prior_cov6):
+        """Register(..., soft_constraints=true) with reg_cov.back() = prior_cov6"""
+        n = len(scans)
+        arr = (C.c_void_p * n)(*[s._h for s in scans])
+        P = np.ascontiguousarray(poses, dtype=np.float64).reshape(n, 3).copy()
+        pc = np.ascontiguousarray(prior_cov6, dtype=np.float64).reshape(36).copy()
+        cov = np.zeros(36)
+        S = RegSummary()
+        self._check(self._L.cfear_register_soft(self._h, arr, n, P.ctypes.data, pc.ctypes.data, cov.ctypes.data, C.byref(S)), "cfear_register_soft")
         return bool(S.success), P, cov.reshape(6, 6), S
 
     def get_cost(self, scans, poses, itr=2):

@@ -149,14 +149,14 @@ __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double
 }
 
 __global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
-                                                           BlockScratch B, cfear_reg_summary* out) {
+                                                           BlockScratch B, cfear_reg_summary* out, const double* prior_cov6) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
   ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
   for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];
   __syncthreads();
   const RegScratch W = make_rscratch(B, lds);
   register_block(sp, n, poses, cov6, P, W, reinterpret_cast<double*>(lds + RegLds::par),
-                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), out);
+                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), out, nullptr, prior_cov6);
 }
 
 __global__ __launch_bounds__(BLOCK_R) void get_cost_kernel(ScanDev* const* scans, int n, const double* poses, RegParams P, BlockScratch B,
@@ -663,8 +663,8 @@ int cfear_scan_closest(cfear_ctx* ctx, const cfear_scan* s, const double* qxy, i
 }
 
 // ---- registration ------------------------------------------------------------------------------
-int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
-                   cfear_reg_summary* summary) {
+static int register_impl(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, const double* prior_cov6, double* cov6_last,
+                         cfear_reg_summary* summary) {
   if (!ctx || !scans || !poses_xyt || n < 2) return cfear_fail(ctx, CFEAR_ERR_INVALID, "register: need >= 2 scans and poses");
   if (n > MAX_SCANS) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "register: more than 64 scans");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -690,13 +690,29 @@ int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* pose
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
   const RegParams P = reg_params(ctx);
-  hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum);
+  double* d_prior = nullptr;
+  if (prior_cov6) {  // staged behind the summary, in the tail of the context scratch
+    d_prior = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(d_sum) + ((sizeof(cfear_reg_summary) + 15) / 16) * 16);
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_prior, prior_cov6, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
+  }
+  hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum, d_prior);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, d_poses, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
   if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6_last, d_cov, sizeof(double) * 36, hipMemcpyDeviceToHost, ctx->stream));
   if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(summary, d_sum, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
+}
+
+int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
+                   cfear_reg_summary* summary) {
+  return register_impl(ctx, scans, n, poses_xyt, nullptr, cov6_last, summary);
+}
+
+int cfear_register_soft(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, const double* prior_cov6, double* cov6_last,
+                        cfear_reg_summary* summary) {
+  if (!prior_cov6) return cfear_fail(ctx, CFEAR_ERR_INVALID, "register_soft: null prior covariance");
+  return register_impl(ctx, scans, n, poses_xyt, prior_cov6, cov6_last, summary);
 }
 
 int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double* poses_xyt, int itr, double* score, double* residuals,

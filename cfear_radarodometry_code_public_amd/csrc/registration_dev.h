@@ -134,6 +134,8 @@ struct RegShared {
   // parameter blocks the out-of-line functions take by reference: kept here so that they are LDS reads, not reads
   // of a per-thread stack copy
   RegParams rp; RegScratch rw; RegIo rio;
+  // soft constraint (Register(..., soft_constraints = true), n_scan_normal.cpp:373-377): residual L alpha (guess - x)
+  int prior_on, pad_p; double pL[9], pguess[3], palpha;
   // ---- controller state: outer association loop (n_scan_normal.cpp:82-187)
   int success, nres, ret, pad0;
   double xcur[3], prev_par[3], tsrc_last[3], prev_score;
@@ -571,6 +573,21 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
   }
 }
 
+// mahalanobisDistanceError (n_scan_normal.h:259-290) at x: r = L (alpha (guess - x)), J = -alpha L, no loss
+__device__ __noinline__ void add_prior(const RegShared* sh, NormalEq& E, double x0, double x1, double x2) {
+  const double a = sh->palpha;
+  const double d0 = a * (sh->pguess[0] - x0), d1 = a * (sh->pguess[1] - x1), d2 = a * (sh->pguess[2] - x2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double l0 = sh->pL[3 * i], l1 = sh->pL[3 * i + 1], l2 = sh->pL[3 * i + 2];
+    const double r = l0 * d0 + l1 * d1 + l2 * d2;
+    const double j0 = -a * l0, j1 = -a * l1, j2 = -a * l2;
+    E.cost += 0.5 * (r * r);
+    E.g0 += j0 * r; E.g1 += j1 * r; E.g2 += j2 * r;
+    E.h00 += j0 * j0; E.h01 += j0 * j1; E.h02 += j0 * j2; E.h11 += j1 * j1; E.h12 += j1 * j2; E.h22 += j2 * j2;
+  }
+}
+
 // ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
 // over its callees, and it decides how many workgroups share a compute unit) ----
 __device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, const RegParams& P) {
@@ -582,12 +599,14 @@ __device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, con
     ctl_finish(sh, io, P, false, z);
     return;
   }
+  if (sh->prior_on) sh->nres += 3;  // the prior block joins after the residual-count check (:370-377)
   ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
 }
 
 __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double gradient_tolerance = 1e-10;
-  const NormalEq E = gather_partials(W);
+  NormalEq E = gather_partials(W);
+  if (sh->prior_on) add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   sh->E = E; sh->x_cost = E.cost;
   sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
@@ -602,7 +621,8 @@ __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const
 __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
-  const NormalEq C = gather_partials(W);
+  NormalEq C = gather_partials(W);
+  if (sh->prior_on) add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
   __builtin_amdgcn_sched_barrier(0);
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
@@ -636,7 +656,8 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
 }
 
 __device__ __noinline__ void ctl_after_cov(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
-  const NormalEq E = gather_partials(W);
+  NormalEq E = gather_partials(W);
+  if (sh->prior_on) add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   ctl_finish(sh, io, P, true, E);
 }
 
@@ -655,7 +676,7 @@ __device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const R
 // Wave 0 is the controller; every wave executes the published commands (two barriers per command).
 __device__ inline int register_block(ScanDev* const* scans, int n, double* poses, double* cov6, const RegParams& P_in,
                                      const RegScratch& W_in, double* par_lds, RegShared* sh, cfear_reg_summary* out,
-                                     PhaseTimer* pt = nullptr) {
+                                     PhaseTimer* pt = nullptr, const double* prior_cov6 = nullptr) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     sh->rp = P_in; sh->rw = W_in;
@@ -682,6 +703,21 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   if (master) {
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
+    sh->prior_on = 0;
+    if (prior_cov6) {  // :373-376: guess_inf_sqrt = Cov6to3(cov).inverse().llt().matrixL(), alpha = sqrt(#source cells)
+      const double* Cq = prior_cov6;
+      const double a = Cq[0], b = Cq[1], c = Cq[5], d = Cq[6], e = Cq[7], f5 = Cq[11], g6 = Cq[30], h = Cq[31], i9 = Cq[35];  // registration.cpp:123-129
+      const double A00 = e * i9 - f5 * h, A10 = f5 * g6 - d * i9, A11 = a * i9 - c * g6, A20 = d * h - e * g6, A21 = b * g6 - a * h, A22 = a * e - b * d;
+      const double det = a * A00 + b * A10 + c * A20;
+      const double i00 = A00 / det, i10 = A10 / det, i11 = A11 / det, i20 = A20 / det, i21 = A21 / det, i22 = A22 / det;  // lower triangle of the inverse
+      const double l00 = sqrt(i00), l10 = i10 / l00, l20 = i20 / l00;
+      const double l11 = sqrt(i11 - l10 * l10), l21 = (i21 - l20 * l10) / l11;
+      const double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
+      sh->pL[0] = l00; sh->pL[1] = 0; sh->pL[2] = 0; sh->pL[3] = l10; sh->pL[4] = l11; sh->pL[5] = 0; sh->pL[6] = l20; sh->pL[7] = l21; sh->pL[8] = l22;
+      sh->pguess[0] = par_lds[L]; sh->pguess[1] = par_lds[L + 1]; sh->pguess[2] = par_lds[L + 2];  // Affine3dToEigVectorXYeZ(Tsrc.back()) (:93-94)
+      sh->palpha = sqrt((double)scans[n - 1]->n_cells);
+      sh->prior_on = 1;
+    }
     sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
     sh->tsrc_last[0] = poses[L]; sh->tsrc_last[1] = poses[L + 1]; sh->tsrc_last[2] = poses[L + 2];
     sh->prev_score = 1.7976931348623157e308;
@@ -732,6 +768,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
   if ((tid >> 6) == 0) {
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
+    sh->prior_on = 0;
     ctl_publish_build(sh, sh->rio);
   }
   __syncthreads();

@@ -232,7 +232,6 @@ class n_scan_normal_reg {
   void SetParameters(unsigned int max_itr_association, unsigned int max_itr_solver) { max_itr_association_ = (int)max_itr_association; max_itr_solver_ = (int)max_itr_solver; }
   // bool Register(scans, Tsrc, reg_cov, soft_constraints = false) (n_scan_normal.cpp:82-187); only Tsrc.back() is free.
   bool Register(std::vector<MapNormalPtr>& scans, std::vector<Affine3d>& Tsrc, std::vector<Matrix6d>& reg_cov, bool soft_constraints = false) {
-    if (soft_constraints) throw std::runtime_error("soft_constraints (mahalanobisDistanceError prior) is off by default in the reference and not on the accelerated path");
     const size_t n = scans.size();
     if (Tsrc.size() != n || reg_cov.size() != n || n < 2) throw std::runtime_error("Register: scans/Tsrc/reg_cov size mismatch");  // assert at n_scan_normal.cpp:84
     cfear_params p = dev_->params();
@@ -243,7 +242,13 @@ class n_scan_normal_reg {
     std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
     for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = Tsrc[i].t[0]; poses[3 * i + 1] = Tsrc[i].t[1]; poses[3 * i + 2] = Tsrc[i].yaw(); }
     double cov[36];
-    dev_->check(cfear_register(dev_->ctx(), h.data(), (int)n, poses.data(), cov, &summary_), "cfear_register");
+    if (soft_constraints) {  // :373-377: prior from reg_cov.back() as passed in
+      double prior[36];
+      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) prior[6 * a + b] = reg_cov.back().m[a][b];
+      dev_->check(cfear_register_soft(dev_->ctx(), h.data(), (int)n, poses.data(), prior, cov, &summary_), "cfear_register_soft");
+    } else {
+      dev_->check(cfear_register(dev_->ctx(), h.data(), (int)n, poses.data(), cov, &summary_), "cfear_register");
+    }
     Tsrc.back() = Affine3d::FromXYT(poses[3 * (n - 1)], poses[3 * (n - 1) + 1], poses[3 * (n - 1) + 2]);
     if (summary_.usable) {  // :164-178: every pose passes through vectorToAffine3d(parameters), covariances get the default diagonal
       for (size_t i = 0; i + 1 < n; i++) Tsrc[i] = Affine3d::FromXYT(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);

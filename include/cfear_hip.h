@@ -164,6 +164,13 @@ typedef struct cfear_reg_summary {
 int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
                    cfear_reg_summary* summary);
 
+/* Register(..., soft_constraints = true) (n_scan_normal.cpp:373-377): adds the Mahalanobis prior
+ * mahalanobisDistanceError (n_scan_normal.h:259-290) on the last pose around its initial value, with the information
+ * matrix of prior_cov6 = reg_cov.back() as passed in (36 doubles row-major; rows/columns x, y, yaw are used,
+ * registration.cpp:123-129) and the weight sqrt(#cells of the last scan). Everything else as cfear_register. */
+int cfear_register_soft(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, const double* prior_cov6,
+                        double* cov6_last, cfear_reg_summary* summary);
+
 /* bool GetCost(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc, double& score,
  *              std::vector<double>& residuals) (n_scan_normal.cpp:188-213; called by the cost-sampling covariance,
  * odometrykeyframefuser.cpp:305): associations and residual blocks at the given poses, no solve. itr = the object's

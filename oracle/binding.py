@@ -94,6 +94,7 @@ def lib():
     L.cfo_scan_closest.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
     L.cfo_register.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, f64p, C.POINTER(Params), C.c_int,
                                C.POINTER(RegSummary)]
+    L.cfo_register_soft.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, f64p, f64p, C.POINTER(Params), C.c_int, C.POINTER(RegSummary)]
     L.cfo_get_cost.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(Params), C.c_int, C.c_int, f64p, f64p, C.c_int]
     L.cfo_cov_by_sampling.argtypes = [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(Params), C.c_int, C.c_int, C.c_double, C.c_double,
                                       C.c_int, C.c_double, C.c_double, C.c_int, f64p, f64p]
@@ -208,6 +209,19 @@ def register(scans, poses, params, brute=False):
     S = RegSummary()
     ret = lib().cfo_register(arr, n, _ptr(P, C.c_double), _ptr(cov, C.c_double), C.byref(params), int(brute),
                              C.byref(S))
+    return ret, P, cov.reshape(6, 6), S
+
+
+def register_soft(scans, poses, prior_cov6, params, brute=False):
+    """Register(..., soft_constraints=true): prior_cov6 = the 6x6 covariance passed in for the last pose."""
+    n = len(scans)
+    arr = (C.c_void_p * n)(*[s._h for s in scans])
+    P = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    pc = np.ascontiguousarray(prior_cov6, dtype=np.float64).reshape(36).copy()
+    cov = np.zeros(36, dtype=np.float64)
+    S = RegSummary()
+    ret = lib().cfo_register_soft(arr, n, _ptr(P, C.c_double), _ptr(pc, C.c_double), _ptr(cov, C.c_double), C.byref(params), int(brute),
+                                  C.byref(S))
     return ret, P, cov.reshape(6, 6), S
 
 

@@ -626,6 +626,8 @@ static void loss_eval(int loss, double a, double s, double rho[3]) {
 
 typedef struct {
   const match_t* m; int nm; int cost; int loss; double loss_limit;
+  /* soft constraint (n_scan_normal.cpp:373-377): residual L * alpha * (guess - x), no loss */
+  int prior; double pL[9], pguess[3], palpha;
 } problem_t;
 
 /* [3P] ceres ResidualBlock::Evaluate + Corrector (rho'' <= 0 for every loss here => r~ = sqrt(rho')r).
@@ -677,6 +679,21 @@ static double evaluate_res(const problem_t* P, const double x[3], double g[3], d
         const double rk = sr * r[k];
         const double j0 = sr * J[k][0], j1 = sr * J[k][1], j2 = sr * J[k][2];
         g[0] += j0 * rk; g[1] += j1 * rk; g[2] += j2 * rk;
+        H[0] += j0 * j0; H[1] += j0 * j1; H[2] += j0 * j2;
+        H[3] += j1 * j1; H[4] += j1 * j2; H[5] += j2 * j2;
+      }
+    }
+  }
+  if (P->prior) { /* mahalanobisDistanceError (n_scan_normal.h:259-290): r = L (alpha (guess - x)), J = -alpha L */
+    double d[3], r[3];
+    for (int k = 0; k < 3; k++) d[k] = P->palpha * (P->pguess[k] - x[k]);
+    for (int i = 0; i < 3; i++) r[i] = P->pL[3 * i] * d[0] + P->pL[3 * i + 1] * d[1] + P->pL[3 * i + 2] * d[2];
+    cost += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (res_out) for (int i = 0; i < 3; i++) res_out[nres_out++] = r[i];
+    if (g) {
+      for (int i = 0; i < 3; i++) {
+        const double j0 = -P->palpha * P->pL[3 * i], j1 = -P->palpha * P->pL[3 * i + 1], j2 = -P->palpha * P->pL[3 * i + 2];
+        g[0] += j0 * r[i]; g[1] += j1 * r[i]; g[2] += j2 * r[i];
         H[0] += j0 * j0; H[1] += j0 * j1; H[2] += j0 * j2;
         H[3] += j1 * j1; H[4] += j1 * j2; H[5] += j2 * j2;
       }
@@ -864,7 +881,7 @@ int cfo_get_cost(cfo_scan* const* scans, int n, const double* poses_xyt, const c
   }
   const int nsrc = scans[n - 1]->ncells;
   match_t* M = (match_t*)malloc(sizeof(match_t) * (size_t)((n - 1) * (nsrc > 0 ? nsrc : 1)));
-  problem_t P; P.m = M; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit;
+  problem_t P; P.m = M; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit; P.prior = 0;
   int nres = 0;
   P.nm = build_problem(scans, n, par, p, itr, brute, M, &nres);
   int ret = -1;
@@ -1015,8 +1032,8 @@ int cfo_cov_by_sampling(cfo_scan* const* scans, int n, const double* poses_xyt, 
   return 1;
 }
 
-int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
-                 int brute, cfo_reg_summary* out) {
+static int register_impl(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
+                         int brute, cfo_reg_summary* out, const double* prior_cov6) {
   cfo_reg_summary S;
   memset(&S, 0, sizeof(S));
   if (n < 2 || n > 1024) { if (out) *out = S; return 0; }
@@ -1031,13 +1048,33 @@ int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6,
   int success = 1;
   double prev_par[3] = {par[n - 1][0], par[n - 1][1], par[n - 1][2]};
   double prev_score = DBL_MAX;
-  problem_t P; P.m = M; P.nm = 0; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit;
+  problem_t P; P.m = M; P.nm = 0; P.cost = p->cost; P.loss = p->loss; P.loss_limit = p->loss_limit; P.prior = 0;
+  int prior_ok = 0;
+  if (prior_cov6) { /* :373-376: guess_inf_sqrt = Cov6to3(cov).inverse().llt().matrixL(); alpha = sqrt(N_src) */
+    const double* C = prior_cov6;
+    const double a = C[0], b = C[1], c = C[5], d = C[6], e = C[7], f5 = C[11], g6 = C[30], h = C[31], i9 = C[35]; /* Cov6to3 (registration.cpp:123-129) */
+    const double A00 = e * i9 - f5 * h, A01 = c * h - b * i9, A02 = b * f5 - c * e;
+    const double A10 = f5 * g6 - d * i9, A11 = a * i9 - c * g6, A12 = c * d - a * f5;
+    const double A20 = d * h - e * g6, A21 = b * g6 - a * h, A22 = a * e - b * d;
+    const double det = a * A00 + b * A10 + c * A20;
+    const double I[9] = {A00 / det, A01 / det, A02 / det, A10 / det, A11 / det, A12 / det, A20 / det, A21 / det, A22 / det};
+    /* lower Cholesky factor of the (symmetric) information matrix, reading its lower triangle like Eigen's LLT */
+    const double l00 = sqrt(I[0]), l10 = I[3] / l00, l20 = I[6] / l00;
+    const double l11 = sqrt(I[4] - l10 * l10), l21 = (I[7] - l20 * l10) / l11;
+    const double l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
+    const double L[9] = {l00, 0, 0, l10, l11, 0, l20, l21, l22};
+    memcpy(P.pL, L, sizeof(L));
+    P.pguess[0] = par[n - 1][0]; P.pguess[1] = par[n - 1][1]; P.pguess[2] = par[n - 1][2]; /* Affine3dToEigVectorXYeZ(Tsrc.back()) (:93-94) */
+    P.palpha = sqrt((double)scans[n - 1]->ncells);
+    prior_ok = 1;
+  }
   int nres = 0;
   solve_summary ss; memset(&ss, 0, sizeof(ss));
   int itr;
   for (itr = 1; itr <= p->max_itr_association && success; itr++) { /* :102 */
     P.nm = build_problem(scans, n, par, p, itr, brute, M, &nres);
     if (nres <= 1) { success = 0; break; } /* :370-371, :114-115 */
+    if (prior_ok) { P.prior = 1; nres += 3; } /* the prior block joins after the residual-count check (:370-377) */
     ss = lm_solve(&P, par[n - 1], p->max_solver_iterations);
     success = (ss.termination != 2); /* IsSolutionUsable */
     if (success) { tsrc_last[0] = par[n - 1][0]; tsrc_last[1] = par[n - 1][1]; tsrc_last[2] = par[n - 1][2]; } /* :119-121 */
@@ -1089,6 +1126,17 @@ int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6,
   if (out) *out = S;
   free(M); free(par);
   return ret;
+}
+
+int cfo_register(cfo_scan* const* scans, int n, double* poses_xyt, double* cov6, const cfo_params* p,
+                 int brute, cfo_reg_summary* out) {
+  return register_impl(scans, n, poses_xyt, cov6, p, brute, out, NULL);
+}
+
+/* Register(..., soft_constraints = true): prior_cov6 = reg_cov.back() as passed in (36 doubles, row-major) */
+int cfo_register_soft(cfo_scan* const* scans, int n, double* poses_xyt, const double* prior_cov6, double* cov6,
+                      const cfo_params* p, int brute, cfo_reg_summary* out) {
+  return register_impl(scans, n, poses_xyt, cov6, p, brute, out, prior_cov6);
 }
 
 /* ------------------------------------------------------------------------------------------

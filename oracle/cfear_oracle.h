@@ -131,6 +131,10 @@ typedef struct cfo_reg_summary {
 
 /* n_scan_normal_reg::Register (n_scan_normal.cpp:82-187). poses = n x (x,y,theta) in/out;
  * cov6 = 36 doubles (row-major 6x6) of reg_cov.back(). */
+/* Register with soft_constraints = true (n_scan_normal.cpp:373-377): a Mahalanobis prior on the last pose around its
+ * initial value with information from prior_cov6 (reg_cov.back() as passed in), weighted by sqrt(#source cells) */
+int cfo_register_soft(cfo_scan* const* scans, int n, double* poses_xyt, const double* prior_cov6, double* cov6,
+                      const cfo_params* p, int brute, cfo_reg_summary* out);
 /* n_scan_normal_reg::GetCost (n_scan_normal.cpp:188-213); itr = the object's itr_ (association radius, :222).
  * Returns the number of residuals or -1 (reference: false). */
 int cfo_get_cost(cfo_scan* const* scans, int n, const double* poses_xyt, const cfo_params* p, int itr, int brute,

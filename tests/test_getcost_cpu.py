@@ -130,3 +130,24 @@ def test_cov_by_sampling_matches_numpy(oracle, steps, xy, yaw):
     if ok:
         assert np.allclose(cov, cov2, rtol=1e-6, atol=1e-12)
         assert cov[0, 0] > 0 and cov[1, 1] > 0 and cov[5, 5] > 0 and np.allclose(cov, cov.T)
+
+
+def test_soft_constraint_prior_limits(oracle):
+    """Register(..., soft_constraints=true): a loose prior reproduces the free solution, a tight one pins the pose to its guess,
+    and the prior's three residuals are counted (n_scan_normal.cpp:370-377)."""
+    p = oracle.default_params(range_res=RR, z_min=60.0, res=3.0, cost=1, loss=1, loss_limit=0.1, weight_opt=4, weight_intensity=1)
+    scans, gt = scans_of(oracle, 3, p)
+    poses = gt[:3].copy()
+    poses[2, :2] += [0.3, -0.2]
+    ret0, P0, cov0, S0 = oracle.register(scans, poses, p)
+    retL, PL, covL, SL = oracle.register_soft(scans, poses, np.eye(6) * 1e6, p)
+    retT, PT, covT, ST = oracle.register_soft(scans, poses, np.eye(6) * 1e-10, p)
+    assert np.allclose(PL[2], P0[2], atol=1e-5)
+    assert np.allclose(PT[2], poses[2], atol=1e-4) and np.linalg.norm(P0[2, :2] - poses[2, :2]) > 0.2
+    assert SL.num_residuals == SL.num_residual_blocks + 3 and S0.num_residuals == S0.num_residual_blocks
+    # anisotropic, correlated prior: the solution moves along the loose direction only
+    C = np.eye(6)
+    C[0, 0], C[1, 1], C[5, 5], C[0, 1], C[1, 0] = 1e-8, 1e2, 1e2, 0.0, 0.0
+    retA, PA, covA, SA = oracle.register_soft(scans, poses, C, p)
+    assert abs(PA[2, 0] - poses[2, 0]) < 1e-3  # x pinned to its guess
+    assert abs(PA[2, 1] - poses[2, 1]) > 0.1 and abs(PA[2, 1] - P0[2, 1]) < 0.1  # y free to move towards the unconstrained solution

@@ -68,3 +68,24 @@ def test_cov_by_sampling_matches_oracle(oracle, steps, xy, yaw, cost):
     if ok_o:
         assert np.allclose(cov_g, cov_o, rtol=1e-5, atol=1e-12)
     ctx.close()
+
+
+@pytest.mark.parametrize("cost,sig", [(1, 1.0), (1, 0.05), (2, 0.2), (0, 1e-3)])
+def test_register_soft_matches_oracle(oracle, cost, sig):
+    """Register(..., soft_constraints=true) (n_scan_normal.cpp:373-377): poses, iteration counts and covariance"""
+    po, ctx, so, sg, gt = build(oracle, 4, cost=cost, loss=1, weight_opt=4, loss_limit=0.1, regularization=0.1)
+    poses = gt[:4].copy()
+    poses[3] += [0.25, -0.15, 0.01]
+    C = np.eye(6) * sig ** 2
+    C[0, 1] = C[1, 0] = 0.3 * sig ** 2
+    C[0, 5] = C[5, 0] = -0.1 * sig ** 2
+    ro = oracle.register_soft(so, poses, C, po)
+    rg = ctx.register_soft(sg, poses, C)
+    So, Sg = ro[3], rg[3]
+    assert Sg.outer_iterations == So.outer_iterations and list(Sg.inner_iterations[:8]) == list(So.inner_iterations[:8])
+    assert Sg.num_residuals == So.num_residuals == So.num_residual_blocks * (1 if cost == 1 else 2) + 3
+    assert np.all(np.abs(rg[1][:, :2] - ro[1][:, :2]) < 1e-4) and np.all(np.abs(rg[1][:, 2] - ro[1][:, 2]) < 1e-5)
+    assert bool(ro[0]) == rg[0]
+    assert np.allclose(rg[2], ro[2], rtol=1e-6, atol=1e-12)
+    assert abs(Sg.final_cost - So.final_cost) < 1e-9 * max(1.0, So.final_cost)
+    ctx.close()
