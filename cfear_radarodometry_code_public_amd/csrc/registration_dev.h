@@ -147,7 +147,9 @@ struct RegShared {
 };
 
 // ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
-#define CFEAR_MATCH_LDS_CAP 640
+// 636 matches x 64 B + the rest of the registration kernels' LDS = 53,568 B: three workgroups per compute unit need
+// <= 53,760 B each (LDS is handed out in 1,280-byte granules; 53,824 B already drops the kernel to two per CU and +34 % time)
+#define CFEAR_MATCH_LDS_CAP 636
 struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
 __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   MatchPtrs m;
@@ -574,7 +576,8 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
 }
 
 // mahalanobisDistanceError (n_scan_normal.h:259-290) at x: r = L (alpha (guess - x)), J = -alpha L, no loss
-__device__ __noinline__ void add_prior(const RegShared* sh, NormalEq& E, double x0, double x1, double x2) {
+// (forceinline, by value: a NormalEq handed to an out-of-line function by reference would live in per-thread scratch)
+__device__ __forceinline__ NormalEq add_prior(const RegShared* sh, NormalEq E, double x0, double x1, double x2) {
   const double a = sh->palpha;
   const double d0 = a * (sh->pguess[0] - x0), d1 = a * (sh->pguess[1] - x1), d2 = a * (sh->pguess[2] - x2);
 #pragma unroll
@@ -586,6 +589,7 @@ __device__ __noinline__ void add_prior(const RegShared* sh, NormalEq& E, double 
     E.g0 += j0 * r; E.g1 += j1 * r; E.g2 += j2 * r;
     E.h00 += j0 * j0; E.h01 += j0 * j1; E.h02 += j0 * j2; E.h11 += j1 * j1; E.h12 += j1 * j2; E.h22 += j2 * j2;
   }
+  return E;
 }
 
 // ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
@@ -606,7 +610,7 @@ __device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, con
 __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double gradient_tolerance = 1e-10;
   NormalEq E = gather_partials(W);
-  if (sh->prior_on) add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
+  if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   sh->E = E; sh->x_cost = E.cost;
   sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
@@ -622,7 +626,7 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
   NormalEq C = gather_partials(W);
-  if (sh->prior_on) add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
+  if (sh->prior_on) C = add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
   __builtin_amdgcn_sched_barrier(0);
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
@@ -657,7 +661,7 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
 
 __device__ __noinline__ void ctl_after_cov(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   NormalEq E = gather_partials(W);
-  if (sh->prior_on) add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
+  if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   ctl_finish(sh, io, P, true, E);
 }
 
