@@ -201,6 +201,32 @@ class MapPointNormal {
     dev_->check(cfear_scan_closest(dev_->ctx(), scan_, q, 1, d, &idx), "cfear_scan_closest");
     return idx >= 0 ? std::vector<int>{idx} : std::vector<int>();
   }
+  // double GetCellRelTimeStamp(index, ccw) (pointnormal.cpp:139-143) with GetRelTimeStamp (utils.h:28-32)
+  double GetCellRelTimeStamp(size_t index, bool ccw) {
+    fetch();
+    const double a = std::atan2(cells_[index].u_.y, cells_[index].u_.x);
+    const double d = (a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI);
+    return ccw ? -(d - 0.5) : (d - 0.5);
+  }
+  // std::vector<cell> TransformCells(T) (pointnormal.cpp:352-361) -> cell::TransformCopy (:515-527), arithmetic as written
+  // there: C = R * T * cov * R^T with the affine T applied to the columns of cov (so the translation enters the product)
+  std::vector<cell> TransformCells(const Affine3d& T) {
+    fetch();
+    std::vector<cell> out;
+    const double (*R)[2] = T.l;
+    for (const cell& c : cells_) {
+      cell ct = c;
+      double M[2][2], RT[2][2], rt[2];  // R*T: linear R*R, translation R*t
+      for (int i = 0; i < 2; i++) { for (int j = 0; j < 2; j++) RT[i][j] = R[i][0] * R[0][j] + R[i][1] * R[1][j]; rt[i] = R[i][0] * T.t[0] + R[i][1] * T.t[1]; }
+      for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) M[i][j] = RT[i][0] * c.cov_.m[0][j] + RT[i][1] * c.cov_.m[1][j] + rt[i];
+      for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) ct.cov_.m[i][j] = M[i][0] * R[j][0] + M[i][1] * R[j][1];
+      ct.snormal_.x = R[0][0] * c.snormal_.x + R[0][1] * c.snormal_.y; ct.snormal_.y = R[1][0] * c.snormal_.x + R[1][1] * c.snormal_.y;
+      ct.orth_normal.x = R[0][0] * c.orth_normal.x + R[0][1] * c.orth_normal.y; ct.orth_normal.y = R[1][0] * c.orth_normal.x + R[1][1] * c.orth_normal.y;
+      ct.u_.x = R[0][0] * c.u_.x + R[0][1] * c.u_.y + T.t[0]; ct.u_.y = R[1][0] * c.u_.x + R[1][1] * c.u_.y + T.t[1];
+      out.push_back(ct);
+    }
+    return out;
+  }
   cfear_scan* handle() const { return scan_; }
   static double downsample_factor;  // pointnormal.h:241 (set through cfear_params.downsample_factor)
  private:

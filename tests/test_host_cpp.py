@@ -78,3 +78,53 @@ def test_offline_odometry_with_ca_cfar_filter_matches_oracle(oracle, tmp_path):
         got = np.array([est[t, 3], est[t, 7], np.arctan2(est[t, 4], est[t, 0])])
         assert np.all(np.abs(got[:2] - exp[:2]) < 1e-4 + 5e-7), (t, got, exp)
         assert abs(got[2] - exp[2]) < 1e-5 + 2e-6
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_classes_against_oracle(oracle, tmp_path):
+    """api_check.cpp drives radarDriver (both filter types), MapPointNormal and its accessors, n_scan_normal_reg::Register with
+    and without soft constraints, GetCost and GetCovarianceScaler the way reference code would; the numbers must be the oracle's."""
+    import json
+    build_harness()
+    imgs, gt = synth.world_sequence(3, seed=61)
+    f = tmp_path / "three.u8"
+    imgs.tofile(f)
+    r = subprocess.run([os.path.join(HOST, "api_check"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    p = oracle.default_params(range_res=RR, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, cost=1, loss=1, loss_limit=0.1)
+    scans, clouds = [], []
+    for t in range(3):
+        xyi = oracle.cloud(oracle.filter_polar(imgs[t], 60, 12), p.range_res, p.min_distance)
+        clouds.append(xyi)
+        scans.append(oracle.Scan(xyi, p))
+    assert out["points"] == [len(c) for c in clouds]
+    assert out["cfar_points"] == len(oracle.cfar(imgs[0], RR, 60.0, 2.5)) and out["cfar_peaks"] == 0
+    assert out["cells"] == [s.size for s in scans]
+    c0 = scans[2].cells()[0]
+    assert np.allclose(out["cell0"], [c0["mean"][0], c0["mean"][1], c0["normal"][0], c0["normal"][1]], atol=1e-9)
+    assert out["closest_self"] == 0
+    a = np.arctan2(c0["mean"][1], c0["mean"][0])
+    assert abs(out["rel_time0"] - ((a if a > 0.00001 else 2 * np.pi + a) / (2 * np.pi) - 0.5)) < 1e-12
+    c, s = np.cos(0.3), np.sin(0.3)
+    Rm = np.array([[c, -s], [s, c]])
+    u = Rm @ c0["mean"] + [1.0, -2.0]
+    assert np.allclose(out["tcell0"][:2], u, atol=1e-9) and abs(out["tcell0"][2] - (Rm @ c0["normal"])[0]) < 1e-9
+    cov = np.array([[c0["cov"][0], c0["cov"][1]], [c0["cov"][1], c0["cov"][2]]])
+    Cq = (Rm @ Rm @ cov + (Rm @ np.array([1.0, -2.0]))[:, None]) @ Rm.T  # cell::TransformCopy as written (pointnormal.cpp:515-527)
+    assert np.allclose(out["tcell0"][3:], [Cq[0, 0], Cq[0, 1]], atol=1e-9)
+    poses = np.array([[0, 0, 0], [1.0, 0.02, 0.02], [2.2, 0.1, 0.05]])
+    ret, P, cov6, S = oracle.register(scans, poses, p)
+    assert out["register"]["ok"] == ret and out["register"]["itr"] == S.outer_iterations
+    assert np.all(np.abs(np.array(out["register"]["pose"]) - P[2]) < [1e-4, 1e-4, 1e-5])
+    assert abs(out["register"]["cov00"] - cov6[0, 0]) < 1e-6 * abs(cov6[0, 0])
+    assert out["register"]["has_scale"] == 1 and abs(out["register"]["cov_scale"] - S.final_cost / (S.num_residuals - 3)) < 1e-9
+    sc, res = oracle.get_cost(scans, P, p, itr=S.outer_iterations)
+    g = out["get_cost"]
+    assert g["ok"] == 1 and g["n"] == len(res) and abs(g["score"] - sc) < 1e-7 and abs(g["r0"] - res[0]) < 1e-7
+    assert abs(g["getScore"] - sc / len(res)) < 1e-9  # score_ = score / #residuals (n_scan_normal.cpp:211)
+    prior = np.eye(6)
+    prior[np.arange(6), np.arange(6)] = 0.05 ** 2
+    rs = oracle.register_soft(scans, poses, prior, p)
+    assert out["register_soft"]["ok"] == rs[0] and out["register_soft"]["residuals"] == rs[3].num_residuals
+    assert np.all(np.abs(np.array(out["register_soft"]["pose"]) - rs[1][2]) < [1e-4, 1e-4, 1e-5])
