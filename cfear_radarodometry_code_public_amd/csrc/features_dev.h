@@ -438,7 +438,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     if (nr > 4) R[0] = -1;  // only with leaf < radius: the chunk lanes search again (copies made below)
     int4* Rg = reinterpret_cast<int4*>(W.rng + 8 * (size_t)v);
     Rg[0] = make_int4(R[0], R[1], R[2], R[3]); Rg[1] = make_int4(R[4], R[5], R[6], R[7]);
-    T[v] = tot;
+    T[v] = tot >= 6 ? tot : 0;  // fewer than six candidates can never make a cell (pointnormal.cpp:291): no chunks, no partial sums
   }
   const bool wide = (int)(2.0f * rq * inv) + 2 > 4;  // block-uniform
   if (wide) {
