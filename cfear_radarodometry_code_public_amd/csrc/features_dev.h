@@ -423,10 +423,16 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
     int tot = 0, nr = 0;
     int R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long vid = W.vlist[v];
     for (int gy = gy0; gy <= gy1 && gx0 <= gx1; gy++) {
       // voxels gx0..gx1 of this row are contiguous in the sorted order: search the voxel list
       const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
-      const int p0 = lower_bound_int(W.vlist, nv, k0);
+      // sample v sits at position v of the voxel list (its own voxel): voxel indices are distinct integers, so the
+      // first voxel >= k0 is at most |k0 - own index| positions away from v - a short search instead of all of the list
+      int lo, hi;
+      if (k0 <= vid) { lo = v - (int)min((long long)v, vid - k0); hi = v; }
+      else { lo = v; hi = (int)min((long long)nv, (long long)v + (k0 - vid)); }
+      const int p0 = lo + lower_bound_int(W.vlist + lo, hi - lo, k0);
       int p1 = p0;
       while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
       const int a = W.vstart[p0], b = W.vstart[p1];
