@@ -506,9 +506,9 @@ __device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const R
   }
   const double current_score = sh->ss.final_cost;
   const double rel_improvement = (sh->prev_score - current_score) / sh->prev_score;
-  bool brk = false;
+  bool brk = false, reverted = false;
   if (itr > P.min_itr) {  // :134-149
-    if (sh->prev_score < current_score) { sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; brk = true; }
+    if (sh->prev_score < current_score) { sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; brk = true; reverted = true; }
     else if (rel_improvement < 0.00001) brk = true;
     else if (sh->ss.last_relative_decrease < 0.00001 || sh->ss.num_iterations == 1) brk = true;
   }
@@ -518,8 +518,11 @@ __device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const R
     sh->itr = itr + 1;  // for-loop increment (:102)
     if (sh->itr <= P.max_outer && sh->success) { ctl_publish_build(sh, io); return; }
   }
-  // loop left: covariance pass on the last built problem if the solution is usable (:164-183)
-  if (sh->success) ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV);
+  // loop left: covariance of the last built problem at the final parameters if the solution is usable (:164-183). The LM
+  // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
+  // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
+  if (sh->success && reverted) ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV);
+  else if (sh->success) { const NormalEq E = sh->E; ctl_finish(sh, io, P, true, E); }
   else { NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; ctl_finish(sh, io, P, false, z); }
 }
 
