@@ -14,27 +14,42 @@ __device__ __forceinline__ int lane_id() {
   return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// ---- wave reductions (64 lanes) via ds_bpermute shuffles ----
+// ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// DPP prefix pattern (Hillis-Steele inside the 16-lane rows, then two row broadcasts): after the six steps lane i holds
+// op over lanes 0..i, so lane 63 holds the wave result. No LDS crossbar round trips (ds_bpermute) on the way.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull(int own, int v) {  // lanes without a source lane get `own`
+  return __builtin_amdgcn_update_dpp(own, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += dpp_pull<0x111, 0xF>(0, v);  // row_shr:1
+  v += dpp_pull<0x112, 0xF>(0, v);  // row_shr:2
+  v += dpp_pull<0x114, 0xF>(0, v);  // row_shr:4
+  v += dpp_pull<0x118, 0xF>(0, v);  // row_shr:8
+  v += dpp_pull<0x142, 0xA>(0, v);  // row_bcast15 -> rows 1, 3
+  v += dpp_pull<0x143, 0xC>(0, v);  // row_bcast31 -> rows 2, 3
   return v;
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63); }
+#define CFEAR_DPP_FLOAT_REDUCE(NAME, OP)                                                          \
+  __device__ __forceinline__ float NAME(float v) {                                                \
+    int b = __float_as_int(v);                                                                    \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x111, 0xF>(b, b))));        \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x112, 0xF>(b, b))));        \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x114, 0xF>(b, b))));        \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x118, 0xF>(b, b))));        \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x142, 0xA>(b, b))));        \
+    b = __float_as_int(OP(__int_as_float(b), __int_as_float(dpp_pull<0x143, 0xC>(b, b))));        \
+    return __int_as_float(__builtin_amdgcn_readlane(b, 63));                                      \
+  }
+CFEAR_DPP_FLOAT_REDUCE(wave_min, fminf)
+CFEAR_DPP_FLOAT_REDUCE(wave_max, fmaxf)
+#undef CFEAR_DPP_FLOAT_REDUCE
 
 // scratch: >= 32 elements of T in LDS. Result broadcast to all threads.
 __device__ __forceinline__ float block_min(float v, float* scratch) {
@@ -89,12 +104,7 @@ __device__ __forceinline__ int block_sum(int v, int* scratch) {
 __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
   auto* sl = CFEAR_LDS_PTR(int, scratch);
   const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(inc, off);
-    if (lane >= off) inc += t;
-  }
+  const int inc = wave_inclusive_scan(v);
   __syncthreads();
   if (lane == 63) sl[w] = inc;
   __syncthreads();
