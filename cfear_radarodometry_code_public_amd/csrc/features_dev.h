@@ -130,7 +130,7 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
 //
 // Compensation needs atan2(y, x), sin and cos per point in f64 (utils.cpp:96-107) - hundreds of instructions each.
 // Here the points of bearing b lie on the ray theta_b up to the float rounding of (x, y), so these are expanded
-// around per-bearing values kept in LDS (tab: 3 doubles per bearing):
+// around per-bearing values kept in LDS (tab: 4 doubles per bearing: angle, sin, cos of d_b * m2, d_b):
 //   atan2(y, x) = theta_b + atan((y c_b - x s_b) / (x c_b + y s_b)),  argument ~1e-7 => atan(t) = t to f64 precision
 //   sin/cos(arg) around arg_b = d_b * m2 to second order in (arg - arg_b) ~ 1e-9
 // which agrees with evaluating the reference's expressions to within f64 rounding (the test tolerance on
@@ -154,7 +154,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
       double sb, cb;
       sincos(d * m2, &sb, &cb);
-      tab[3 * b] = a; tab[3 * b + 1] = sb; tab[3 * b + 2] = cb;
+      tab[4 * b] = a; tab[4 * b + 1] = sb; tab[4 * b + 2] = cb; tab[4 * b + 3] = d;
     }
   }
   int cnt = 0;
@@ -165,11 +165,12 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   int total;
   int o = block_exclusive_scan(cnt, red_i, &total);  // (its barriers also publish tab)
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
-  for (int i = i0; i < i1; i++) {
+  int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
+  for (int i = i0; i < i1; i++, jb++) {
+    if (jb == k) { jb = 0; b++; }
     const uint32_t s = slots[i];
     const int range = CFEAR_SLOT_RANGE(s);
     if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
-      const int b = i / k;
       const double cb = trig[2 * b], sb = trig[2 * b + 1];
       const double rad = range_res_half + range_res * range;
       float x = (float)(rad * cb);  // :329
@@ -185,12 +186,10 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
         y = (float)((s1 * px + c1 * py) + d * m1);
       } else if (compensate) {
         const double px = (double)x, py = (double)y;
-        const double ab = tab[3 * b], s_b = tab[3 * b + 1], c_b = tab[3 * b + 2];
+        const double ab = tab[4 * b], s_b = tab[4 * b + 1], c_b = tab[4 * b + 2], d_b = tab[4 * b + 3];
         const double a = ab + (py * cb - px * sb) / (px * cb + py * sb);
         const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
         const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-        const double ddb = ((ab > 0.00001 ? ab : (CFEAR_TWO_PI + ab)) / CFEAR_TWO_PI);
-        const double d_b = ccw ? -(ddb - 0.5) : (ddb - 0.5);
         const double e = d * m2 - d_b * m2;
         const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
         x = (float)((c1 * px + (-s1) * py) + d * m0);
