@@ -685,9 +685,11 @@ __device__ inline int scan_closest(const GridView& S, double px, double py, doub
   const int gw = S.gw, gh = S.gh;
   if (S.n_cells <= 0 || gw <= 0) return -1;
   const double m = d * (1.0 + 1e-6) + 1e-6;
-  const double gc = (double)S.gcell, gmx = (double)S.gminx, gmy = (double)S.gminy;
-  int gx0 = (int)floor(((double)qx - m - gmx) / gc), gx1 = (int)floor(((double)qx + m - gmx) / gc);
-  int gy0 = (int)floor(((double)qy - m - gmy) / gc), gy1 = (int)floor(((double)qy + m - gmy) / gc);
+  // one reciprocal instead of four divisions: the window is padded by m - d >= 1e-6, an ulp in the bucket coordinate
+  // cannot uncover anything within d of the query
+  const double igc = 1.0 / (double)S.gcell, gmx = (double)S.gminx, gmy = (double)S.gminy;
+  int gx0 = (int)floor(((double)qx - m - gmx) * igc), gx1 = (int)floor(((double)qx + m - gmx) * igc);
+  int gy0 = (int)floor(((double)qy - m - gmy) * igc), gy1 = (int)floor(((double)qy + m - gmy) * igc);
   // the builder clamps bucket coordinates, so clamp the query window the same way
   gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
   if (gx0 > gx1 || gy0 > gy1) return -1;
