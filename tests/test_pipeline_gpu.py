@@ -254,3 +254,48 @@ def test_baseline_config3_p2d(oracle):
     imgs, gt = synth.world_sequence(6, seed=43, ccw=True)
     got = _fuser_parity(oracle, imgs, 400, 3360, cost=2, regularization=0.1, covar_scale=1.0, radar_ccw=1, min_keyframe_dist=1.5)
     assert np.linalg.norm(got[:2] - gt[-1, :2]) < 0.5
+
+
+def test_blank_sweep_in_one_sequence_does_not_disturb_the_others(oracle):
+    """A sequence whose sweep has no returns (the reference prints 'error, cloud empty' and exits, pointnormal.cpp:72-75) coasts on
+    its constant-velocity guess (odometrykeyframefuser.cpp:164-168) and stays finite; its batch neighbours are unaffected; the
+    sequence recovers on the next real sweep."""
+    imgs, _ = synth.world_sequence(5, seed=71)
+    blank = np.zeros_like(imgs[0])
+    pg, po = mk_params(capi), mk_params(oracle)
+    ctx = capi.Context(pg, 400, 3360)
+    odo = ctx.odometry(2)
+    fu = oracle.Fuser(po)
+    for t in range(5):
+        batch = np.stack([imgs[t], blank if t == 2 else imgs[t]])
+        odo.step_host(batch)
+        got = odo.poses()
+        exp = fu.process_polar(imgs[t])
+        assert np.all(np.abs(got[0, :2] - exp[:2]) < POS_TOL) and abs(got[0, 2] - exp[2]) < ROT_TOL, t
+        assert np.all(np.isfinite(got[1]))
+        if t == 2:  # no registration possible: the pose is the prediction from the previous motion
+            assert np.linalg.norm(got[1, :2] - got[0, :2]) < 0.3 and abs(got[1, 2] - got[0, 2]) < 0.02
+    assert np.linalg.norm(got[1, :2] - got[0, :2]) < 1.0  # back on track after the gap
+    odo.release()
+    ctx.close()
+
+
+def test_reset_replays_identically_and_contexts_are_independent(oracle):
+    imgs, _ = synth.world_sequence(4, seed=72)
+    ctx_a = capi.Context(mk_params(capi), 400, 3360)
+    ctx_b = capi.Context(mk_params(capi, cost=2, res=3.5, submap_scan_size=2), 400, 3360)  # different parameters side by side
+    oa, ob = ctx_a.odometry(1), ctx_b.odometry(1)
+    first = []
+    for t in range(4):
+        oa.step_host(imgs[t][None]); ob.step_host(imgs[t][None])
+        first.append((oa.poses()[0].copy(), ob.poses()[0].copy()))
+    assert not np.allclose(first[-1][0], first[-1][1], atol=1e-6)  # P2L r=3.0 vs P2D r=3.5 differ, i.e. no shared state
+    oa.reset()
+    for t in range(4):
+        oa.step_host(imgs[t][None])
+        assert np.array_equal(oa.poses()[0], first[t][0])
+    fb = oracle.Fuser(mk_params(oracle, cost=2, res=3.5, submap_scan_size=2))
+    for t in range(4):
+        exp = fb.process_polar(imgs[t])
+    assert np.all(np.abs(first[-1][1][:2] - exp[:2]) < POS_TOL)
+    oa.release(); ob.release(); ctx_a.close(); ctx_b.close()
