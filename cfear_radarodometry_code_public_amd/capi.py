@@ -60,7 +60,7 @@ class RegSummary(C.Structure):
 EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
     "cfear_set_params", "cfear_synchronize", "cfear_kstrongest_device", "cfear_kstrongest_host",
-    "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
+    "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
@@ -98,6 +98,8 @@ def lib():
         "cfear_synchronize": (C.c_int, [vp]),
         "cfear_kstrongest_device": (C.c_int, [vp, u8p, C.c_int, u32p]),
         "cfear_kstrongest_host": (C.c_int, [vp, u8p, C.c_int, u32p]),
+        "cfear_rotate_polar": (C.c_int, [vp, u8p, C.c_int, C.c_int, u8p]),
+        "cfear_rotate_polar_device": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, u8p]),
         "cfear_filter_polar": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
         "cfear_filter_polar_device": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
         "cfear_filter_cfar": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_float, C.c_double, C.POINTER(vp)]),
@@ -216,6 +218,13 @@ class Context:
         self._check(self._L.cfear_time_kstrongest(self._h, _addr(d_polar), int(n_scans), _addr(d_slots), int(warmup),
                                                   int(iters), C.byref(t)), "cfear_time_kstrongest")
         return t.value
+
+    def rotate_polar(self, img):
+        """radarDriver::Callback (non-Oxford): rows = range -> rows = azimuth (cv::ROTATE_90_COUNTERCLOCKWISE)"""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty((img.shape[1], img.shape[0]), dtype=np.uint8)
+        self._check(self._L.cfear_rotate_polar(self._h, img.ctypes.data, img.shape[0], img.shape[1], out.ctypes.data), "cfear_rotate_polar")
+        return out
 
     # ---- stage 1 -> clouds (radarDriver::CallbackOffline) ----
     def filter_polar(self, polar, peaks=True):

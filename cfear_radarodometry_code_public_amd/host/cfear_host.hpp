@@ -158,10 +158,19 @@ class radarDriver {
     }
     cloud->stamp = cloud_peaks->stamp = img.stamp;
   }
+  // void Callback(const sensor_msgs::ImageConstPtr&) for the non-Oxford datasets (radar_driver.cpp:74-90): the image arrives with
+  // rows = range bins; cv::rotate(ROTATE_90_COUNTERCLOCKWISE) (:84) runs on the device, then Process()
+  void Callback(const PolarImage& range_major, CloudPtr& cloud, CloudPtr& cloud_peaks) {
+    if (!range_major.data) throw std::runtime_error("Radar image NULL");
+    rotated_.resize((size_t)range_major.rows * range_major.cols);
+    dev_->check(cfear_rotate_polar(dev_->ctx(), range_major.data, range_major.rows, range_major.cols, rotated_.data()), "cfear_rotate_polar");
+    PolarImage az; az.rows = range_major.cols; az.cols = range_major.rows; az.data = rotated_.data(); az.stamp = range_major.stamp;
+    CallbackOffline(az, cloud, cloud_peaks);
+  }
   DeviceCloudPtr device_cloud() const { return last_cloud_; }  // avoids a round trip when the fuser runs on the same device
   PolarImage cv_polar_image;  // latest radar image (radar_driver.h:92)
  private:
-  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_;
+  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_; std::vector<uint8_t> rotated_;
 };
 
 // ---- Compensate (utils.h:49) -------------------------------------------------------------------------

@@ -88,6 +88,13 @@ int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
  * AxialNonMaxSupress called from radarDriver::Process (radar_driver.cpp:58-60). */
 int cfear_kstrongest_host(cfear_ctx* ctx, const uint8_t* h_polar, int n_scans, uint32_t* h_slots);
 
+/* radarDriver::Callback for the non-Oxford datasets (radar_driver.cpp:74-90): the sensor image has rows = range bins and
+ * columns = azimuths; cv::rotate(ROTATE_90_COUNTERCLOCKWISE) (:84) turns it into the rows = azimuth layout of every other
+ * call here: out[i][j] = in[j][in_cols - 1 - i], out is in_cols x in_rows. The device variant takes n_images images back to
+ * back and is asynchronous on the context stream; in and out must not overlap. */
+int cfear_rotate_polar(cfear_ctx* ctx, const uint8_t* h_in, int in_rows, int in_cols, uint8_t* h_out);
+int cfear_rotate_polar_device(cfear_ctx* ctx, const uint8_t* d_in, int n_images, int in_rows, int in_cols, uint8_t* d_out);
+
 /* ---- Stage 1/1.5: point clouds -------------------------------------------------------------- */
 typedef struct cfear_cloud cfear_cloud; /* pcl::PointCloud<pcl::PointXYZI> on the device */
 
