@@ -144,6 +144,7 @@ def main():
     if world > 1:
         dist.barrier()
     t_filter, n_filter = odo.profile_read()
+    t_feat, t_reg, n_stage = odo.profile_read_stages()
     poses = odo.poses()
     S, n_cells, n_kf = odo.summary(0)
 
@@ -186,7 +187,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": ALGO_BYTES_PER_SCAN * scans_per_launch, "avg_launch_us": filt * 1e6,
                          "launches_per_step": launches_per_step},
-            "kernels": {"kstrongest_launch_us": filt * 1e6, "kstrongest_launches": n_filter},
+            # features / registration are latency-bound chains: reported as time, not as a roofline fraction
+            "kernels": {"kstrongest_launch_us": filt * 1e6, "kstrongest_launches": n_filter,
+                        "features_launch_us": 1e6 * t_feat / max(n_stage, 1), "registration_launch_us": 1e6 * t_reg / max(n_stage, 1),
+                        "sequences_per_launch": scans_per_launch,
+                        "features_us_per_scan": 1e6 * t_feat / max(n_stage, 1) / scans_per_launch,
+                        "registration_us_per_scan": 1e6 * t_reg / max(n_stage, 1) / scans_per_launch},
             "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,
                       "pose_seq0": [float(x) for x in poses[0]], "datagen_s": t_gen},
         }

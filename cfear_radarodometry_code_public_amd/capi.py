@@ -65,7 +65,7 @@ EXPORTS = [
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
-    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_time_kstrongest",
+    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_time_kstrongest",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
                                              C.POINTER(C.c_int)]),
         "cfear_odometry_profile": (C.c_int, [vp, vp, C.c_int]),
         "cfear_odometry_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "cfear_odometry_profile_read_stages": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "cfear_time_kstrongest": (C.c_int, [vp, u8p, C.c_int, u32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -426,6 +427,13 @@ class Odometry:
         self._ctx._check(self._ctx._L.cfear_odometry_profile_read(self._ctx._h, self._h, C.byref(tf), C.byref(nf)),
                          "cfear_odometry_profile_read")
         return tf.value, nf.value
+
+    def profile_read_stages(self):
+        """-> (features seconds, registration seconds, launches of each)"""
+        tf, tr, n = C.c_double(), C.c_double(), C.c_int()
+        self._ctx._check(self._ctx._L.cfear_odometry_profile_read_stages(self._ctx._h, self._h, C.byref(tf), C.byref(tr), C.byref(n)),
+                         "cfear_odometry_profile_read_stages")
+        return tf.value, tr.value, n.value
 
     def poses(self):
         out = np.zeros((self.B, 3))

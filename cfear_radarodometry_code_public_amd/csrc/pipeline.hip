@@ -448,6 +448,7 @@ struct cfear_odometry {
   hipEvent_t fork = nullptr;
   bool profile = false;        // record HIP events around the filter launches
   std::vector<hipEvent_t> filter_events;  // 2 per profiled filter launch
+  std::vector<hipEvent_t> stage_events;   // 3 per profiled sub-batch: before features, between, after registration
 };
 extern int g_cfear_odo_streams, g_cfear_odo_fork;  // kstrongest.hip (cfear_debug_set)
 // make everything the sub-batch streams have been given so far visible to the context stream
@@ -924,6 +925,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
                   o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar, o->d_phase_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : o->stage_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : o->sub_done) (void)hipEventDestroy(e);
   for (hipStream_t st : o->sub_streams) (void)hipStreamDestroy(st);
   if (o->fork) (void)hipEventDestroy(o->fork);
@@ -1036,24 +1038,30 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
     if (o->profile && (rc = timed_event(o->filter_events, st)) != CFEAR_OK) return rc;
     return CFEAR_OK;
   };
-  auto launch_odometry = [&](int seq0, int count, hipStream_t st) {
+  auto launch_odometry = [&](int seq0, int count, hipStream_t st) -> int {
     OdoParams P = OP; P.seq0 = seq0;
-    if (o->d_phase_times) {
+    int rc = CFEAR_OK;
+    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
+    if (o->d_phase_times)
       hipLaunchKernelGGL(features_step_kernel<true>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
                          o->d_scan_ptrs, o->d_scratch_hdr);
-      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-    } else {
+    else
       hipLaunchKernelGGL(features_step_kernel<false>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
                          o->d_scan_ptrs, o->d_scratch_hdr);
+    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
+    if (o->d_phase_times)
+      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    else
       hipLaunchKernelGGL(register_step_kernel<false>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
                          o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-    }
+    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
+    return CFEAR_OK;
   };
   int rc = CFEAR_OK;
   if (o->nsub <= 1) {
     if ((rc = launch_filter(0, o->B, ctx->stream)) != CFEAR_OK) return rc;
-    launch_odometry(0, o->B, ctx->stream);
+    if ((rc = launch_odometry(0, o->B, ctx->stream)) != CFEAR_OK) return rc;
   } else {
     if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipEventRecord(o->fork, ctx->stream));  // the sweeps are ready at this point of the context stream
     const int per = (o->B + o->nsub - 1) / o->nsub;
@@ -1063,7 +1071,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
       hipStream_t st = o->sub_streams[i];
       if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(st, o->fork, 0));
       if ((rc = launch_filter(seq0, count, st)) != CFEAR_OK) return rc;
-      launch_odometry(seq0, count, st);
+      if ((rc = launch_odometry(seq0, count, st)) != CFEAR_OK) return rc;
     }
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
@@ -1092,6 +1100,8 @@ int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* o, int enable) {
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
   o->filter_events.clear();
+  for (hipEvent_t e : o->stage_events) (void)hipEventDestroy(e);
+  o->stage_events.clear();
   o->profile = enable != 0;
   return CFEAR_OK;
 }
@@ -1109,6 +1119,24 @@ int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filte
   }
   if (filter_seconds) *filter_seconds = tf;
   if (filter_launches) *filter_launches = nf;
+  return CFEAR_OK;
+}
+
+int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* o, double* features_seconds, double* registration_seconds, int* launches) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile_read_stages: bad argument");
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tf = 0, tr = 0;
+  const int n = (int)(o->stage_events.size() / 3);
+  for (int i = 0; i < n; i++) {
+    float a = 0.f, b = 0.f;
+    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&a, o->stage_events[3 * i], o->stage_events[3 * i + 1]));
+    CFEAR_HIP_CHECK(ctx, hipEventElapsedTime(&b, o->stage_events[3 * i + 1], o->stage_events[3 * i + 2]));
+    tf += a * 1e-3; tr += b * 1e-3;
+  }
+  if (features_seconds) *features_seconds = tf;
+  if (registration_seconds) *registration_seconds = tr;
+  if (launches) *launches = n;
   return CFEAR_OK;
 }
 

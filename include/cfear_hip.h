@@ -223,6 +223,10 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cf
  * per sub-batch of sequences). */
 int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* odo, int enable);
 int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* odo, double* filter_seconds, int* filter_launches);
+/* The same for the two kernels behind the filter (stages 1.5-2: cloud + compensation + oriented surface points;
+ * stage 3 + caller: registration and keyframe logic), summed over the profiled launches. */
+int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* odo, double* features_seconds, double* registration_seconds,
+                                       int* launches);
 
 /* Timing hook used by bench.py: seconds of the filter kernel measured with HIP events on the
  * context stream over `iters` launches (after `warmup`). */
