@@ -349,7 +349,7 @@ ScanLayout scan_layout(int cap_points) {
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
-  L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
+  L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 4), 256);
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);
@@ -387,7 +387,7 @@ ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   L.order = o; o = align_up(o + sizeof(int) * cp, 256);
   L.vstart = o; o = align_up(o + sizeof(int) * (cp + 2), 256);
   L.vlist = o; o = align_up(o + sizeof(int) * cp, 256);
-  L.vcur = o; o = align_up(o + sizeof(int) * (GRID_CAP + 2), 256);
+  L.vcur = o; o = align_up(o + sizeof(int) * (GRID_CAP + 4), 256);
   L.rng = o; o = align_up(o + sizeof(int) * 8 * (size_t)cap_points, 256);
   L.part = o; o = align_up(o + sizeof(double) * 7 * (size_t)cap_points, 256);
   L.tmpi = o; o = align_up(o + sizeof(int) * (2 * (size_t)cap_points + 16), 256);

@@ -366,14 +366,157 @@ __device__ __noinline__ int associate_pair(const ScanDev* src, const RegShared* 
   }
   return ti;
 }
-__device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, const RegParams& P,
-                                        const RegScratch& W, int nsrc, int p, int ti, int o, bool use_lds) {
+__device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, int nsrc, int p, int ti, int o, bool use_lds) {
+  const RegParams& P = sh->rp;
+  const RegScratch& W = sh->rw;
   const int i = p / nsrc, j = p - i * nsrc;
   const RCell cs = rcell_src(src, j);
-  const RCell ct = rcell_tar(scans[i], ti);
-  const cfear_cell* ctf = &scans[i]->cells[ti];
+  RCell ct;
+  {
+    const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti);  // the LDS view: no pointer chase
+    const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+    ct.mx = r0.x; ct.my = r0.y; ct.nx = r1.x; ct.ny = r1.y; ct.ns = r2.x; ct.scale = r2.y;
+  }
+  const cfear_cell* ctf = (P.cost == CFEAR_COST_P2D) ? &scans[i]->cells[ti] : nullptr;
   if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
   else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
+}
+
+// ---- association of one source cell against up to four keyframes at once ------------------------------------
+// A pair's search is a chain of dependent memory round trips (source cell -> bucket bounds -> candidates -> target
+// normal), about 1 us each from L2; pair after pair that chain was the whole cost of the association. Here the four
+// chains of a source cell advance together: all bucket bounds in one round trip, candidates two per keyframe per
+// round trip, the four gate normals in one. Same results as scan_closest + the gate of associate_pair.
+struct Assoc4 { int t0, t1, t2, t3; };
+__device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0 ? a.t0 : (i == 1 ? a.t1 : (i == 2 ? a.t2 : a.t3)); }
+__device__ __noinline__ int scan_closest_wide(const GridView* S, float qx, float qy, double d) { return scan_closest(*S, (double)qx, (double)qy, d); }
+
+// keyframes i0 .. i0 + NI - 1 (those below nk) of source cell j; NC candidates per keyframe per round trip.
+// ti[u] = matched target cell of keyframe i0 + u or -1.
+template <int NI, int NC>
+__device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegShared* sh, int nk, int i0, int j, double curr_radius, int* ti) {
+  const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
+  const size_t cc = (size_t)src->cap_cells;
+  const double* rs = src->rsrc + j;
+  const double mx = rs[0], my = rs[cc];
+  const double m = curr_radius * (1.0 + 1e-6) + 1e-6;  // window padding of scan_closest
+  float qx[NI], qy[NI];
+  int nrows[NI], wide = 0;
+  int lo[NI][3], hi[NI][3];
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int i = i0 + u;
+    qx[u] = 0.f; qy[u] = 0.f; nrows[u] = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { lo[u][r] = 0; hi[u][r] = 0; }
+    if (i < nk) {
+      const double* T = sh->Trel[i];
+      qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
+      qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
+      const int gw = sh->kf[i].gw, gh = sh->kf[i].gh;
+      int gx0 = 0, gy0 = 0, gxe = 0;
+      if (sh->kf[i].n_cells > 0 && gw > 0) {
+        const double igc = 1.0 / (double)sh->kf[i].gcell, gmx = (double)sh->kf[i].gminx, gmy = (double)sh->kf[i].gminy;
+        int ax0 = (int)floor(((double)qx[u] - m - gmx) * igc), ax1 = (int)floor(((double)qx[u] + m - gmx) * igc);
+        int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
+        ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
+        if (ax0 <= ax1 && ay0 <= ay1) {
+          if (ay1 - ay0 > 2) wide |= 1 << u;  // more than three rows of buckets (a query within rounding of a bucket edge)
+          else { gx0 = ax0; gy0 = ay0; gxe = ax1 + 1; nrows[u] = ay1 - ay0 + 1; }
+        }
+      }
+      const int* gs = sh->kf[i].gs;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {  // rows past the window repeat the last one
+        const int row = gy0 + min(r, max(nrows[u] - 1, 0));
+        lo[u][r] = gs[row * gw + gx0]; hi[u][r] = gs[row * gw + gxe];
+      }
+    }
+  }
+  int cnt[NI][2], tot[NI], kmax = 0;  // candidates of rows 0, 0..1 and of the whole window
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int c0 = (0 < nrows[u]) ? hi[u][0] - lo[u][0] : 0;
+    const int c1 = (1 < nrows[u]) ? hi[u][1] - lo[u][1] : 0;
+    const int c2 = (2 < nrows[u]) ? hi[u][2] - lo[u][2] : 0;
+    cnt[u][0] = c0; cnt[u][1] = c0 + c1; tot[u] = c0 + c1 + c2;
+    lo[u][1] -= c0; lo[u][2] -= c0 + c1;  // candidate kk of row r sits at lo[r] + kk
+    kmax = max(kmax, tot[u]);
+  }
+  int best[NI];
+  float bd[NI];
+#pragma unroll
+  for (int u = 0; u < NI; u++) { best[u] = -1; bd[u] = 3.4e38f; }
+  for (int k = 0; k < kmax; k += NC) {
+    float4 c[NI][NC];
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const float4* gp = sh->kf[min(i0 + u, nk - 1)].gp;
+#pragma unroll
+      for (int v = 0; v < NC; v++) {
+        const int kk = max(min(k + v, tot[u] - 1), 0);  // candidate kk of the window, rows in ascending order
+        const int idx = kk + (kk < cnt[u][0] ? lo[u][0] : (kk < cnt[u][1] ? lo[u][1] : lo[u][2]));
+        c[u][v] = gp[tot[u] > 0 ? idx : 0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+#pragma unroll
+      for (int v = 0; v < NC; v++) {
+        const float dx = qx[u] - c[u][v].x, dy = qy[u] - c[u][v].y;
+        float d2 = dx * dx; d2 += dy * dy;
+        const int ci = __float_as_int(c[u][v].z);
+        if (k + v < tot[u] && (d2 < bd[u] || (d2 == bd[u] && ci < best[u]))) { bd[u] = d2; best[u] = ci; }
+      }
+    }
+  }
+  const double snx = rs[2 * cc], sny = rs[3 * cc];
+  double2 tn[NI];
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int i = i0 + u;
+    ti[u] = (best[u] >= 0 && (double)bd[u] < curr_radius * curr_radius) ? best[u] : -1;
+    if (wide & (1 << u)) ti[u] = scan_closest_wide(&sh->kf[i], qx[u], qy[u], curr_radius);
+    if (i >= nk) ti[u] = -1;
+    tn[u] = make_double2(0.0, 0.0);
+    if (ti[u] >= 0) tn[u] = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti[u])[1];
+  }
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    if (ti[u] >= 0) {
+      const double* T = sh->Trel[i0 + u];
+      const double nx = T[0] * snx + T[1] * sny;
+      const double ny = T[2] * snx + T[3] * sny;
+      const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
+      if (!(sim > angle_outlier)) ti[u] = -1;  // :247
+    }
+  }
+}
+// two keyframes per call (register budget of the registration kernels): (ti of i0) | (ti of i0 + 1) << 32
+__device__ __noinline__ unsigned long long associate_cell2(const ScanDev* src, const RegShared* sh, int nk, int i0, int j, double curr_radius) {
+  int ti[2];
+  associate_cell_t<2, 4>(src, sh, nk, i0, j, curr_radius, ti);
+  return (unsigned long long)(unsigned)ti[0] | ((unsigned long long)(unsigned)ti[1] << 32);
+}
+__device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const RegShared* sh, int nk, int j, double curr_radius) {
+  Assoc4 a = {-1, -1, -1, -1};
+  const unsigned long long p = associate_cell2(src, sh, nk, 0, j, curr_radius);
+  a.t0 = (int)(unsigned)p; a.t1 = (int)(unsigned)(p >> 32);
+  if (nk > 2) {
+    const unsigned long long q = associate_cell2(src, sh, nk, 2, j, curr_radius);
+    a.t2 = (int)(unsigned)q; a.t3 = (int)(unsigned)(q >> 32);
+  }
+  return a;
+}
+
+// residual blocks of one source cell (up to four keyframes); pos = four 16-bit positions in the match arrays
+__device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const RegShared* sh,
+                                          int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
+#pragma unroll 1
+  for (int i = 0; i < nk; i++) {
+    const int ti = assoc_get(a, i);
+    if (ti >= 0) emit_match(scans, src, sh, nsrc, i * nsrc + j, ti, (int)((pos >> (16 * i)) & 0xFFFF), use_lds);
+  }
 }
 
 // AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
@@ -381,35 +524,69 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
 // number of matches, compacted in reference residual-block order (pair index ascending) into the LDS match array
 // if they fit, else into W's global arrays. Pairs are dealt round-robin (pair p -> thread p mod blockDim), so
 // the source-cell reads of a wave are contiguous; one packed scan of four 16-bit counters orders the matches.
-__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, const RegParams& P, int itr,
-                                                const RegScratch& W) {
-  const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
+// The fast path works on blocks of blockDim source cells: thread <-> source cell, its keyframes searched together; one
+// packed scan of four 16-bit counters per block orders the matches as the reference does (pair index i * nsrc + j
+// ascending). The per-block steps are straight-line functions of their own: a value that lives across a call sits in a
+// register the callee does not touch, above the callee's own, so every such value raises the kernel's register count.
+struct AssocBlock { unsigned long long e, tb; Assoc4 a; };  // exclusive positions / totals per keyframe (16-bit fields), matches
+__device__ __forceinline__ unsigned long long assoc_counts(const Assoc4& a) {
+  return (unsigned long long)(a.t0 >= 0) | ((unsigned long long)(a.t1 >= 0) << 16) | ((unsigned long long)(a.t2 >= 0) << 32) |
+         ((unsigned long long)(a.t3 >= 0) << 48);
+}
+__device__ __noinline__ AssocBlock assoc_block(const ScanDev* src, const RegShared* sh, int nk, int nsrc, int itr, int b) {
+  AssocBlock R;
+  R.a.t0 = R.a.t1 = R.a.t2 = R.a.t3 = -1;
+  const int j = b * blockDim.x + threadIdx.x;
+  if (j < nsrc) {
+    const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
+    R.a = associate_cell(src, sh, nk, j, curr_radius);
+  }
+  R.e = block_exclusive_scan64(assoc_counts(R.a), reinterpret_cast<unsigned long long*>(sh->rw.red), &R.tb);
+  // more source cells than threads: the matches wait in W.assoc for the totals of all blocks
+  if (nsrc > (int)blockDim.x && j < nsrc) reinterpret_cast<int4*>(sh->rw.assoc)[j] = make_int4(R.a.t0, R.a.t1, R.a.t2, R.a.t3);
+  return R;
+}
+// residual blocks of block b of the source cells; before = matches in front of this block, per keyframe. Returns the
+// matches of the block per keyframe (0 when the block is the only one: nothing follows it).
+__device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, int nk, int nsrc, int b,
+                                                      Assoc4 a, unsigned long long e, unsigned long long before, bool use_lds) {
+  const int j = b * blockDim.x + threadIdx.x;
+  unsigned long long tb = 0;
+  if (nsrc > (int)blockDim.x) {  // positions inside the block: the same scan again (cheaper than keeping them)
+    a.t0 = a.t1 = a.t2 = a.t3 = -1;
+    if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
+    e = block_exclusive_scan64(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
+  }
+  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell(scans, src, sh, nsrc, nk, j, a, before + e, use_lds);
+  return tb;
+}
+
+__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, int itr) {
+  const RegParams& P = sh->rp;  // in LDS: addresses derived from sh, nothing to keep alive across the calls below
+  const RegScratch& W = sh->rw;
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
   const int nt = blockDim.x, tid = threadIdx.x;
   int M;
   bool use_lds;
-  if (pairs <= 4 * nt) {
-    int ti[4];
-    unsigned long long c = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int p = r * nt + tid;
-      ti[r] = (p < pairs) ? associate_pair(src, sh, nsrc, p, curr_radius) : -1;
-      c |= (unsigned long long)(ti[r] >= 0 ? 1 : 0) << (16 * r);
+  const int nk = n - 1;
+  const bool can_park = 4 * (long long)nsrc <= (long long)W.cap && (reinterpret_cast<uintptr_t>(W.assoc) & 15) == 0;
+  if (nk <= 4 && (nsrc <= nt || (nsrc <= 4 * nt && can_park))) {
+    unsigned long long T = 0, e0 = 0;
+    Assoc4 a0 = {-1, -1, -1, -1};
+    for (int b = 0; b * nt < nsrc; b++) {
+      const AssocBlock R = assoc_block(src, sh, nk, nsrc, itr, b);
+      T += R.tb;  // per keyframe, every field <= nsrc <= 4 * blockDim
+      a0 = R.a; e0 = R.e;  // used when there is one block only
     }
-    unsigned long long tot;
-    const unsigned long long ex = block_exclusive_scan64(c, reinterpret_cast<unsigned long long*>(W.red), &tot);
-    M = (int)((tot & 0xFFFF) + ((tot >> 16) & 0xFFFF) + ((tot >> 32) & 0xFFFF) + ((tot >> 48) & 0xFFFF));
+    const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+    M = (int)(t0 + t1 + t2 + t3);
     use_lds = M <= CFEAR_MATCH_LDS_CAP;
-    int base = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (ti[r] >= 0) emit_match(scans, src, sh, P, W, nsrc, r * nt + tid, ti[r], base + (int)((ex >> (16 * r)) & 0xFFFF), use_lds);
-      base += (int)((tot >> (16 * r)) & 0xFFFF);
-    }
+    unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
+    for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, a0, e0, before, use_lds);
   } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
+    const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
     const int ipt = (pairs + nt - 1) / nt;
     const int p0 = tid * ipt, p1 = min(pairs, p0 + ipt);
     int cnt = 0;
@@ -422,7 +599,7 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, Re
     use_lds = M <= CFEAR_MATCH_LDS_CAP;
     for (int p = p0; p < p1; p++) {
       const int ti = W.assoc[p];
-      if (ti >= 0) emit_match(scans, src, sh, P, W, nsrc, p, ti, o++, use_lds);
+      if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, use_lds);
     }
   }
   if (tid == 0) sh->lds_match = use_lds ? 1 : 0;
@@ -738,7 +915,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     if (cmd == REG_CMD_DONE) break;
     if (cmd == REG_CMD_BUILD) {
       if (pt) pt->mark();
-      const int M = build_problem_block(scans, n, sh, P, sh->itr, W);
+      const int M = build_problem_block(scans, n, sh, sh->itr);
       if (tid == 0) sh->M = M;
       if (pt) pt->mark();
     } else {
@@ -779,7 +956,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
     ctl_publish_build(sh, sh->rio);
   }
   __syncthreads();
-  const int M = build_problem_block(scans, n, sh, P, itr, W);
+  const int M = build_problem_block(scans, n, sh, itr);
   const int nres = M * ((P.cost == CFEAR_COST_P2L) ? 1 : 2);
   if (nres <= 1) {  // :205-208
     if (tid == 0) { *n_res = -1; *score = 0.0; }
