@@ -23,13 +23,16 @@ struct ScanDev {
   float* xyi;         // [cap_points][3]
   cfear_cell* cells;  // [cap_cells]
   float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
-  int* gstart;        // [cap_grid + 1]
+  int* gstart;        // [cap_grid + 4], followed by the three-row records uint2[cap_grid + 4] (grid_rows3)
   float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
   // registration views of the cells (the association is bound by the number of scattered load instructions,
   // so the fields it needs are packed): mean x, mean y, normal x, normal y, nsamples, scale
   double* rsrc;       // [6][cap_cells] SoA: read with consecutive cell indices when the scan is the source
   double* rtar;       // [cap_cells][8] 64-byte records: read at random cell indices when the scan is a target
 };
+#define CFEAR_GRID_CAP (128 * 128)  // buckets per scan (ScanDev::cap_grid)
+__device__ __forceinline__ uint2* grid_rows3(int* gstart) { return reinterpret_cast<uint2*>(gstart + CFEAR_GRID_CAP + 4); }
+__device__ __forceinline__ const uint2* grid_rows3(const int* gstart) { return reinterpret_cast<const uint2*>(gstart + CFEAR_GRID_CAP + 4); }
 
 struct FeatureParams {
   float range_res, min_distance;
@@ -660,6 +663,14 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
     S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
   }
+  }
+  {  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets): the association reads the bounds of
+     // its whole window with two loads. The offsets were final at the barrier before the scatter.
+    uint2* g3 = grid_rows3(S->gstart);
+    for (int g = tid; g <= G; g += nt) {
+      const unsigned a = (unsigned)S->gstart[g], b = (unsigned)S->gstart[min(g + gw, G)], c = (unsigned)S->gstart[min(g + 2 * gw, G)];
+      g3[g] = make_uint2((a & 0xFFFFu) | (b << 16), c & 0xFFFFu);
+    }
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
   __syncthreads();

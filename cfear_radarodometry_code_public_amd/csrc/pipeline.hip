@@ -340,7 +340,7 @@ RegParams reg_params(const cfear_ctx* ctx) {
   return P;
 }
 
-constexpr int GRID_CAP = 128 * 128;
+constexpr int GRID_CAP = CFEAR_GRID_CAP;
 
 struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, total; };
 ScanLayout scan_layout(int cap_points) {
@@ -349,7 +349,7 @@ ScanLayout scan_layout(int cap_points) {
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
-  L.gstart = o; o = align_up(o + sizeof(int) * (GRID_CAP + 4), 256);
+  L.gstart = o; o = align_up(o + (sizeof(int) + sizeof(uint2)) * (GRID_CAP + 4), 256);  // offsets + three-row records (grid_rows3)
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);

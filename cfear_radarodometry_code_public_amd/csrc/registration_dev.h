@@ -421,15 +421,15 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
         int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
         ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
         if (ax0 <= ax1 && ay0 <= ay1) {
-          if (ay1 - ay0 > 2) wide |= 1 << u;  // more than three rows of buckets (a query within rounding of a bucket edge)
+          if (ay1 - ay0 > 2 || sh->kf[i].n_cells > 0xFFFF) wide |= 1 << u;  // more than three rows of buckets (a query within rounding of a bucket edge), or offsets beyond 16 bits
           else { gx0 = ax0; gy0 = ay0; gxe = ax1 + 1; nrows[u] = ay1 - ay0 + 1; }
         }
       }
-      const int* gs = sh->kf[i].gs;
-#pragma unroll
-      for (int r = 0; r < 3; r++) {  // rows past the window repeat the last one
-        const int row = gy0 + min(r, max(nrows[u] - 1, 0));
-        lo[u][r] = gs[row * gw + gx0]; hi[u][r] = gs[row * gw + gxe];
+      if (nrows[u] > 0) {  // bucket bounds of the window's rows: two 8-byte records (features_dev.h, grid_rows3)
+        const uint2* g3 = grid_rows3(sh->kf[i].gs);
+        const uint2 L = g3[gy0 * gw + gx0], H = g3[gy0 * gw + gxe];
+        lo[u][0] = (int)(L.x & 0xFFFFu); lo[u][1] = (int)(L.x >> 16); lo[u][2] = (int)L.y;
+        hi[u][0] = (int)(H.x & 0xFFFFu); hi[u][1] = (int)(H.x >> 16); hi[u][2] = (int)H.y;
       }
     }
   }
@@ -454,9 +454,10 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
       const float4* gp = sh->kf[min(i0 + u, nk - 1)].gp;
 #pragma unroll
       for (int v = 0; v < NC; v++) {
-        const int kk = max(min(k + v, tot[u] - 1), 0);  // candidate kk of the window, rows in ascending order
+        const int kk = k + v;  // candidate kk of the window, rows in ascending order
         const int idx = kk + (kk < cnt[u][0] ? lo[u][0] : (kk < cnt[u][1] ? lo[u][1] : lo[u][2]));
-        c[u][v] = gp[tot[u] > 0 ? idx : 0];
+        c[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < tot[u]) c[u][v] = gp[idx];
       }
     }
 #pragma unroll
@@ -509,21 +510,60 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const RegSh
   return a;
 }
 
-// residual blocks of one source cell (up to four keyframes); pos = four 16-bit positions in the match arrays
+// residual blocks of one source cell (up to four keyframes); pos = four 16-bit positions in the match arrays.
+// The source cell is read once; matches that fit the LDS array are stored through an LDS-typed pointer (ds_write, not
+// flat stores through the address unit). Same arithmetic as write_match.
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const RegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
+  const RegParams& P = sh->rp;
+  const RCell cs = rcell_src(src, j);
+  typedef __attribute__((address_space(3))) double lds_double;
 #pragma unroll 1
   for (int i = 0; i < nk; i++) {
     const int ti = assoc_get(a, i);
-    if (ti >= 0) emit_match(scans, src, sh, nsrc, i * nsrc + j, ti, (int)((pos >> (16 * i)) & 0xFFFF), use_lds);
+    if (ti < 0) continue;
+    const int o = (int)((pos >> (16 * i)) & 0xFFFF);
+    lds_double* lm = (lds_double*)lds_match_base() + o;
+    double* gm = sh->rw.tmx + o;
+    const size_t gcap = (size_t)sh->rw.cap;
+    // array q of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
+    auto put = [&](int q, double val) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; };
+    const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti);
+    const double2 r0 = r[0], r1 = r[1], r2 = r[2];  // mean, normal, (samples, scale)
+    const double* T = sh->Trel[i];
+    const double* Tt = sh->Ttar[i];
+    put(5, cs.mx); put(6, cs.my);
+    put(0, (Tt[0] * r0.x + Tt[1] * r0.y) + Tt[4]);
+    put(1, (Tt[2] * r0.x + Tt[3] * r0.y) + Tt[5]);
+    {
+      const double nx = T[0] * cs.nx + T[1] * cs.ny;
+      const double ny = T[2] * cs.nx + T[3] * cs.ny;
+      const double sim = fmax(nx * r1.x + ny * r1.y, 0.0);
+      put(7, get_weight(P.weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y));
+    }
+    if (P.cost == CFEAR_COST_P2D) {  // :290-299
+      const cfear_cell* ctf = &scans[i]->cells[ti];
+      const double ca = ctf->cov[0], cb = ctf->cov[1], cc = ctf->cov[2];
+      const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
+      const double m00 = r00 * ca + r01 * cb, m01 = r00 * cb + r01 * cc;
+      const double m10 = r10 * ca + r11 * cb, m11 = r10 * cb + r11 * cc;
+      const double c00 = (P.regularization + (m00 * r00 + m01 * r01)) * P.covar_scale;
+      const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * P.covar_scale;
+      const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * P.covar_scale;
+      const double c11 = (P.regularization + (m10 * r10 + m11 * r11)) * P.covar_scale;
+      const double det = c00 * c11 - c01 * c10, id = 1.0 / det;
+      const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
+      const double l00 = sqrt(i00), l10 = i10 / l00;
+      const double l11 = sqrt(i11 - l10 * l10);
+      put(2, l00); put(3, l10); put(4, l11);
+    } else {
+      put(2, Tt[0] * r1.x + Tt[1] * r1.y);
+      put(3, Tt[2] * r1.x + Tt[3] * r1.y);
+      put(4, 0.0);
+    }
   }
 }
 
-// AddScanPairCost for every (keyframe i -> current) pair (n_scan_normal.cpp:215-326, :359-367).
-// Transforms and 1-NN grid views come from the controller (sh->Ttar, sh->Trel, sh->kf). All threads; returns the
-// number of matches, compacted in reference residual-block order (pair index ascending) into the LDS match array
-// if they fit, else into W's global arrays. Pairs are dealt round-robin (pair p -> thread p mod blockDim), so
-// the source-cell reads of a wave are contiguous; one packed scan of four 16-bit counters orders the matches.
 // The fast path works on blocks of blockDim source cells: thread <-> source cell, its keyframes searched together; one
 // packed scan of four 16-bit counters per block orders the matches as the reference does (pair index i * nsrc + j
 // ascending). The per-block steps are straight-line functions of their own: a value that lives across a call sits in a
@@ -573,18 +613,23 @@ __device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, Re
   const int nk = n - 1;
   const bool can_park = 4 * (long long)nsrc <= (long long)W.cap && (reinterpret_cast<uintptr_t>(W.assoc) & 15) == 0;
   if (nk <= 4 && (nsrc <= nt || (nsrc <= 4 * nt && can_park))) {
-    unsigned long long T = 0, e0 = 0;
-    Assoc4 a0 = {-1, -1, -1, -1};
-    for (int b = 0; b * nt < nsrc; b++) {
-      const AssocBlock R = assoc_block(src, sh, nk, nsrc, itr, b);
-      T += R.tb;  // per keyframe, every field <= nsrc <= 4 * blockDim
-      a0 = R.a; e0 = R.e;  // used when there is one block only
+    const Assoc4 none = {-1, -1, -1, -1};
+    if (nsrc <= nt) {  // one block of cells: its matches stay in registers
+      const AssocBlock R = assoc_block(src, sh, nk, nsrc, itr, 0);
+      const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
+      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+      M = (int)(t0 + t1 + t2 + t3);
+      use_lds = M <= CFEAR_MATCH_LDS_CAP;
+      (void)emit_block(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), use_lds);
+    } else {
+      unsigned long long T = 0;
+      for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, nk, nsrc, itr, b).tb;  // every field <= nsrc <= 4 * blockDim
+      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+      M = (int)(t0 + t1 + t2 + t3);
+      use_lds = M <= CFEAR_MATCH_LDS_CAP;
+      unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
+      for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
     }
-    const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
-    M = (int)(t0 + t1 + t2 + t3);
-    use_lds = M <= CFEAR_MATCH_LDS_CAP;
-    unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
-    for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, a0, e0, before, use_lds);
   } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
     const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
     const int ipt = (pairs + nt - 1) / nt;
