@@ -607,6 +607,9 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     gcell *= 2.f;
   }
   const int G = gw * gh;
+  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets, grid_rows3): the association reads
+  // the bounds of its whole window with two loads
+  bool rows3_done = false;
   if (W.lds && G + 1 <= W.tab_voxels / 2) {
     // bucket counters / cursors in LDS (the key region: the staged points are not needed any more)
     int* gc = reinterpret_cast<int*>(W.keys);
@@ -625,9 +628,22 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       for (int g = i0; g < i1; g++) cnt += gc[g + 1];
       int tot;
       int o = block_exclusive_scan(cnt, W.red_i, &tot);
-      for (int g = i0; g < i1; g++) { const int c = gc[g + 1]; gc[g + 1] = o; S->gstart[g + 1] = o + c; o += c; }  // cursor / end offset
-      if (tid == 0) S->gstart[0] = 0;
+      // a copy of the offsets stays in LDS for the three-row records below when the key region has room for it
+      int* gl = gc + (G + 1);
+      rows3_done = 2 * (G + 1) <= W.tab_voxels / 2;
+      for (int g = i0; g < i1; g++) {  // cursor / end offset
+        const int c = gc[g + 1]; gc[g + 1] = o; S->gstart[g + 1] = o + c; o += c;
+        if (rows3_done) gl[g + 1] = o;
+      }
+      if (tid == 0) { S->gstart[0] = 0; if (rows3_done) gl[0] = 0; }
       __syncthreads();
+      if (rows3_done) {
+        uint2* g3 = grid_rows3(S->gstart);
+        for (int g = tid; g <= G; g += nt) {
+          const unsigned a = (unsigned)gl[g], b = (unsigned)gl[min(g + gw, G)], c = (unsigned)gl[min(g + 2 * gw, G)];
+          g3[g] = make_uint2((a & 0xFFFFu) | (b << 16), c & 0xFFFFu);
+        }
+      }
     }
     for (int i = tid; i < nc; i += nt) {
       const float mx = S->mean_f[2 * i], my = S->mean_f[2 * i + 1];
@@ -664,8 +680,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
   }
   }
-  {  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets): the association reads the bounds of
-     // its whole window with two loads. The offsets were final at the barrier before the scatter.
+  if (!rows3_done) {  // from the offsets in global memory (final at the barrier before the scatter)
     uint2* g3 = grid_rows3(S->gstart);
     for (int g = tid; g <= G; g += nt) {
       const unsigned a = (unsigned)S->gstart[g], b = (unsigned)S->gstart[min(g + gw, G)], c = (unsigned)S->gstart[min(g + 2 * gw, G)];
