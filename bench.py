@@ -30,12 +30,14 @@ ALGO_BYTES_PER_SCAN = A * R + A * K_STRONGEST * 4  # 1,363,200 B
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+PARAMS = dict(z_min=60.0, min_distance=2.5, k_strongest=K_STRONGEST, res=3.0, weight_intensity=1, weight_opt=4, cost=1, loss=1,
+              loss_limit=0.1, submap_scan_size=4, min_keyframe_dist=1.5, compensate=1, radar_ccw=1)
+
+
 def params(mod):
     # BASELINE.json configs[1]: k=12, CFEAR-3 features (r=3.0, weight_intensity, weight_option 4),
     # P2L + Huber(0.1), 4 keyframes, compensation on (SURVEY.md 8d "Config 2")
-    return mod.default_params(range_res=RANGE_RES, z_min=60.0, min_distance=2.5, k_strongest=K_STRONGEST, res=3.0,
-                              weight_intensity=1, weight_opt=4, cost=1, loss=1, loss_limit=0.1, submap_scan_size=4,
-                              min_keyframe_dist=1.5, compensate=1, radar_ccw=1)
+    return mod.default_params(range_res=RANGE_RES, **PARAMS)
 
 
 def make_streams(n_unique, frames, seed0):
@@ -48,23 +50,12 @@ def make_streams(n_unique, frames, seed0):
     return np.stack(out)  # [U, T, A, R]
 
 
-def cpu_baseline(streams, budget_s=12.0):
-    """Oracle (single thread, kind=port) on the same sweeps; bounded to ~budget_s of CPU work."""
-    from oracle import binding as ob
-    p = params(ob)
-    U, T = streams.shape[:2]
-    done, t0 = 0, time.perf_counter()
-    while True:
-        for u in range(U):
-            f = ob.Fuser(p)
-            for t in range(T):
-                f.process_polar(streams[u, t])
-            done += T
-            if time.perf_counter() - t0 > budget_s:
-                dt = time.perf_counter() - t0
-                return {"value": done / dt, "unit": "scans/s", "cores": 1, "kind": "port",
-                        "sample": "%d synthetic 400x3360 sweeps (%d sequences x %d frames, repeated) in %.1f s, oracle/cfear_oracle.c single thread"
-                                  % (done, U, T, dt)}
+def cpu_baseline(budget_s=12.0, max_procs=256):
+    """Oracle (kind=port, single-threaded C) as one process per host core on the same kind of sweeps, ~budget_s of wall
+    time; the workers are fresh interpreters (oracle/cpu_bench.py), the reference's own multi-core mode (NR_WORKERS)."""
+    from oracle import cpu_bench
+    procs = max(1, min(len(os.sched_getaffinity(0)), max_procs))
+    return cpu_bench.run(procs, budget_s, 12, dict(PARAMS, A=A, R=R, range_res=float(RANGE_RES)))
 
 
 def main():
@@ -211,7 +202,7 @@ def main():
                                   "note": "host -> device copy of every sweep inside the timed region (pinned memory, cfear_odometry_step_host)",
                                   "h2d_GBps": B * A * R * args.stream_steps / dt / 1e9}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(streams)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     odo.release()
     ctx.close()
