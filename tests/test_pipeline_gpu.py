@@ -299,3 +299,66 @@ def test_reset_replays_identically_and_contexts_are_independent(oracle):
         exp = fb.process_polar(imgs[t])
     assert np.all(np.abs(first[-1][1][:2] - exp[:2]) < POS_TOL)
     oa.release(); ob.release(); ctx_a.close(); ctx_b.close()
+
+
+def dense_clouds(n_frames, n_points=4800, seed=5):
+    """Clouds with many surface points: a lattice of wall segments seen from poses on a slow arc (float32 [N, 3] each)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    segs = []
+    for i in range(-6, 7):  # walls every 10 m, both directions, with gaps
+        for j in range(-6, 6):
+            if rng.uniform() < 0.7:
+                segs.append(((10.0 * i, 10.0 * j + 1.0), (10.0 * i, 10.0 * j + 8.0)))
+            if rng.uniform() < 0.7:
+                segs.append(((10.0 * j + 1.0, 10.0 * i), (10.0 * j + 8.0, 10.0 * i)))
+    segs = np.asarray(segs)
+    t = rng.uniform(size=(40000, 1))
+    s = segs[rng.integers(0, len(segs), size=40000)]
+    world = s[:, 0] * (1 - t) + s[:, 1] * t
+    poses, clouds = [], []
+    for f in range(n_frames):
+        x, y, th = 0.8 * f, 0.1 * f, 0.015 * f
+        c, sn = np.cos(th), np.sin(th)
+        d = world - np.array([x, y])
+        loc = np.stack([c * d[:, 0] + sn * d[:, 1], -sn * d[:, 0] + c * d[:, 1]], axis=1)
+        loc = loc + rng.normal(scale=0.03, size=loc.shape)
+        r = np.hypot(loc[:, 0], loc[:, 1])
+        loc = loc[(r > 3.0) & (r < 70.0)]
+        pick = rng.permutation(len(loc))[:n_points]
+        inten = rng.integers(70, 200, size=len(pick)).astype(np.float32)
+        clouds.append(np.concatenate([loc[pick], inten[:, None]], axis=1).astype(np.float32))
+        poses.append([x, y, th])
+    return clouds, np.asarray(poses)
+
+
+@pytest.mark.parametrize("cost,res,rev", [(1, 1.5, False), (2, 1.5, False), (1, 1.0, False), (1, 1.5, True)])
+def test_register_many_cells(oracle, cost, res, rev):
+    """Scans with more surface points than the registration workgroup has threads (blocks of source cells, matches parked
+    between the two passes) and more residual blocks than the LDS match array holds (global match arrays); reversed, the
+    source scan has more than four blocks of cells (contiguous pair ranges per thread)."""
+    clouds, gt = dense_clouds(5)
+    if rev:
+        clouds, gt = clouds[::-1], gt[::-1].copy()
+        assert len(oracle.Scan(clouds[-1], mk_params(oracle, res=res)).cells()) > 1024
+    kw = dict(cost=cost, res=res, regularization=0.1, covar_scale=1.0)
+    po, pg = mk_params(oracle, **kw), mk_params(capi, **kw)
+    ctx = capi.Context(pg, 400, 3360)
+    so = [oracle.Scan(c, po) for c in clouds]
+    sg = [ctx.scan_create(ctx.cloud_upload(c)) for c in clouds]
+    assert len(so[-1].cells()) > 256, len(so[-1].cells())
+    poses = gt.copy()
+    poses[-1] += np.array([0.25, -0.15, 0.008])
+    for n in (2, 5):
+        reto, Po, covo, So = oracle.register(so[-n:], poses[-n:], po)
+        retg, Pg, covg, Sg = ctx.register(sg[-n:], poses[-n:])
+        assert So.num_residual_blocks == Sg.num_residual_blocks and So.num_residuals == Sg.num_residuals
+        if n == 5:
+            assert Sg.num_residual_blocks > 636  # beyond the LDS match array
+        assert So.outer_iterations == Sg.outer_iterations
+        assert list(So.inner_iterations[:8]) == list(Sg.inner_iterations[:8])
+        assert bool(reto) == retg
+        assert np.all(np.abs(Pg[:, :2] - Po[:, :2]) < POS_TOL)
+        assert np.all(np.abs(Pg[:, 2] - Po[:, 2]) < ROT_TOL)
+        assert np.allclose(Sg.final_cost, So.final_cost, rtol=1e-9)
+        assert np.linalg.norm(Pg[-1, :2] - gt[-1, :2]) < 0.1  # known answer
+    ctx.close()
