@@ -105,7 +105,12 @@ def main():
 
     # resident input: frame-major [T][B][A][R] so that one step reads B contiguous sweeps
     d_unique = torch.from_numpy(streams).to(dev)  # [U, T, A, R]
-    idx = torch.arange(B, device=dev) % args.unique
+    # which of the generated sequences each resident sequence replays: a seeded shuffle (i % unique would alias with the
+    # round-robin of workgroups over the 8 XCDs and hand every XCD a single kind of sequence)
+    idx = (torch.randperm(B, generator=torch.Generator().manual_seed(1234 + rank)) % args.unique).to(dev)
+    if os.environ.get("CFEAR_BENCH_GROUP"):  # tools only: sequences of one kind next to each other, kinds in the given order ("2031")
+        perm = [int(c) for c in os.environ["CFEAR_BENCH_GROUP"]]
+        idx = torch.tensor(perm, device=dev)[(torch.arange(B, device=dev) * len(perm)) // B]
     d_polar = torch.empty((frames, B, A, R), dtype=torch.uint8, device=dev)
     for t in range(frames):
         d_polar[t] = d_unique[idx, t]
@@ -113,6 +118,10 @@ def main():
     torch.cuda.synchronize()
 
     p = params(capi)
+    if os.environ.get("CFEAR_BENCH_DEBUG"):  # tools only: "key=value,..." for cfear_debug_set (e.g. 3=2: two sub-batch streams)
+        import ctypes
+        for kv in os.environ["CFEAR_BENCH_DEBUG"].split(","):
+            capi.lib().cfear_debug_set(ctypes.c_int(int(kv.split("=")[0])), ctypes.c_int(int(kv.split("=")[1])))
     stream = torch.cuda.current_stream(dev).cuda_stream
     ctx = capi.Context(p, A, R, device=local_rank, stream=stream)
     odo = ctx.odometry(B)
