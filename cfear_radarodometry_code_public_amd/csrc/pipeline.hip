@@ -229,7 +229,7 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
 }
 
 template <bool TIMED>
-__global__ __launch_bounds__(BLOCK_R, 4) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+__global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
@@ -820,14 +820,13 @@ void lstsq10(int m, const double* A, const double* b, double c[10]) {
     c[k] = q * scale[k];
   }
 }
-std::vector<double> linspace(double start, double end, int num) {  // odometrykeyframefuser.cpp:497-524
-  std::vector<double> v;
-  if (num <= 0) return v;
-  if (num == 1) { v.push_back(start); return v; }
+static void linspace(double start, double end, int num, std::vector<double>& v) {  // odometrykeyframefuser.cpp:497-524
+  v.clear();
+  if (num <= 0) return;
+  if (num == 1) { v.push_back(start); return; }
   const double delta = (end - start) / ((double)num - 1);
   for (int i = 0; i < num - 1; i++) v.push_back(start + delta * i);
   v.push_back(end);
-  return v;
 }
 }  // namespace
 
@@ -845,7 +844,9 @@ int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const
   if (rc != CFEAR_OK) return rc;
   const int steps = samples_per_axis, m = steps * steps * steps, L = 3 * (n - 1);
   const int cap = (n - 1) * (nsrc > 0 ? nsrc : 1);
-  const std::vector<double> xs = linspace(-xy_range * 0.5, xy_range * 0.5, steps), ths = linspace(-yaw_range * 0.5, yaw_range * 0.5, steps);  // :277-290
+  std::vector<double> xs, ths;  // :277-290
+  linspace(-xy_range * 0.5, xy_range * 0.5, steps, xs);
+  linspace(-yaw_range * 0.5, yaw_range * 0.5, steps, ths);
   std::vector<double> samples(3 * (size_t)m), A(10 * (size_t)m), costs((size_t)m);
   std::vector<int> nres((size_t)m);
   int k = 0;

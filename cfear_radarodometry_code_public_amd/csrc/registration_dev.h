@@ -142,6 +142,8 @@ struct RegShared {
   SolveSummary ss;
   // ---- controller state: Levenberg-Marquardt (ceres::Solve restatement)
   NormalEq E;
+  NormalEq G;  // sums of the evaluation just done (gather_partials): an 80-byte struct returned by value from an out-of-line
+               // function travels through per-thread scratch, a round trip to memory on the controller's serial chain
   double x_cost, x_norm, sc0, sc1, sc2, radius, decrease_factor, dg0, dg1, dg2, xc[3], model_cost_change;
   int reuse_diagonal, num_invalid, iteration, pad1;
 };
@@ -254,7 +256,7 @@ __device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
 // generic pointer every partial sum was a flat load the running sum had to wait for (2.8 us per evaluation).
-__device__ __noinline__ NormalEq gather_partials(const RegScratch& W) {
+__device__ __noinline__ void gather_partials(const RegScratch& W, NormalEq* out /* in LDS */) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   lds_cdouble* red = (lds_cdouble*)W.red;
   const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
@@ -275,9 +277,10 @@ __device__ __noinline__ NormalEq gather_partials(const RegScratch& W) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  NormalEq o;
-  o.cost = r[0]; o.g0 = r[1]; o.g1 = r[2]; o.g2 = r[3]; o.h00 = r[4]; o.h01 = r[5]; o.h02 = r[6]; o.h11 = r[7]; o.h12 = r[8]; o.h22 = r[9];
-  return o;
+  typedef __attribute__((address_space(3))) double lds_double;
+  lds_double* o = (lds_double*)reinterpret_cast<double*>(out);  // field order of NormalEq: cost g0 g1 g2 h00 h01 h02 h11 h12 h22
+#pragma unroll
+  for (int i = 0; i < 10; i++) o[i] = r[i];  // every lane of the controller wave stores the same values
 }
 
 // 3x3 Cholesky solve. The triangular solves multiply by reciprocal square roots of the pivots instead of dividing
@@ -679,7 +682,8 @@ __device__ __noinline__ void ctl_publish_build(RegShared* sh, const RegIo& io) {
   sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
 }
 
-__device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq& E) {
+__device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
+  const NormalEq& E = *Ep;
   const int n = io.n, L = 3 * (n - 1);
   int ret = 0;
   if (lane_id() == 0) {
@@ -744,8 +748,8 @@ __device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const R
   // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
   // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
   if (sh->success && reverted) ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV);
-  else if (sh->success) { const NormalEq E = sh->E; ctl_finish(sh, io, P, true, E); }
-  else { NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; ctl_finish(sh, io, P, false, z); }
+  else if (sh->success) ctl_finish(sh, io, P, true, &sh->E);
+  else ctl_finish(sh, io, P, false, &sh->E);
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
@@ -824,8 +828,7 @@ __device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, con
   sh->nres = sh->M * rpb;
   if (sh->nres <= 1) {  // :370-371 -> :114-115
     sh->success = 0;
-    NormalEq z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    ctl_finish(sh, io, P, false, z);
+    ctl_finish(sh, io, P, false, &sh->E);
     return;
   }
   if (sh->prior_on) sh->nres += 3;  // the prior block joins after the residual-count check (:370-377)
@@ -834,7 +837,8 @@ __device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, con
 
 __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double gradient_tolerance = 1e-10;
-  NormalEq E = gather_partials(W);
+  gather_partials(W, &sh->G);
+  NormalEq E = sh->G;
   if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   sh->E = E; sh->x_cost = E.cost;
   sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
@@ -850,7 +854,8 @@ __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const
 __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
-  NormalEq C = gather_partials(W);
+  gather_partials(W, &sh->G);
+  NormalEq C = sh->G;
   if (sh->prior_on) C = add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
   __builtin_amdgcn_sched_barrier(0);
   const double cand_cost = C.cost;
@@ -885,9 +890,9 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
 }
 
 __device__ __noinline__ void ctl_after_cov(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
-  NormalEq E = gather_partials(W);
-  if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
-  ctl_finish(sh, io, P, true, E);
+  gather_partials(W, &sh->G);
+  if (sh->prior_on) sh->G = add_prior(sh, sh->G, sh->x[0], sh->x[1], sh->x[2]);
+  ctl_finish(sh, io, P, true, &sh->G);
 }
 
 // consumes the result of the command just executed and publishes the next one
@@ -1012,8 +1017,8 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
   evaluate_partial(W, M, sh->lds_match, P, sh->xcur[0], sh->xcur[1], cs, sn, residuals, cap);
   __syncthreads();
   if (tid == 0) {
-    const NormalEq E = gather_partials(W);
-    *score = E.cost; *n_res = nres;
+    gather_partials(W, &sh->G);
+    *score = sh->G.cost; *n_res = nres;
   }
 }
 
