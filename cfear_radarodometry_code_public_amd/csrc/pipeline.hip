@@ -151,7 +151,7 @@ __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double
   if (i < nq) idx[i] = scan_closest(grid_view(S), q[2 * i], q[2 * i + 1], d);
 }
 
-__global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
+__global__ __launch_bounds__(BLOCK_R, 3) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
                                                            BlockScratch B, cfear_reg_summary* out, const double* prior_cov6) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
   ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(BLOCK_R) void register_kernel(ScanDev* const* scans
                  reinterpret_cast<RegShared*>(lds + RegLds::regsh), out, nullptr, prior_cov6);
 }
 
-__global__ __launch_bounds__(BLOCK_R) void get_cost_kernel(ScanDev* const* scans, int n, const double* poses, RegParams P, BlockScratch B,
+__global__ __launch_bounds__(BLOCK_R, 3) void get_cost_kernel(ScanDev* const* scans, int n, const double* poses, RegParams P, BlockScratch B,
                                                            int itr, double* score, double* residuals, int cap, int* n_res) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
   ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
@@ -175,11 +175,12 @@ __global__ __launch_bounds__(BLOCK_R) void get_cost_kernel(ScanDev* const* scans
 
 // GetCost of many candidate poses of the last scan at once (cost-sampling covariance, odometrykeyframefuser.cpp:291-321):
 // one workgroup per sample pose; match arrays of workgroup b at match_base + b * 8 * cap (used when they do not fit in LDS)
-__global__ __launch_bounds__(BLOCK_R) void get_cost_samples_kernel(ScanDev* const* scans, int n, const double* poses, const double* samples,
+__global__ __launch_bounds__(BLOCK_R, 3) void get_cost_samples_kernel(ScanDev* const* scans, int n, const double* poses, const double* samples,
                                                                    RegParams P, double* match_base, int* assoc_base, int cap, int itr,
                                                                    double* costs, int* n_res) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  __shared__ double my_poses[3 * MAX_SCANS];
+  // the sample's poses are written where get_cost_block keeps its parameter vectors: thread i converts pose i in place
+  double* my_poses = reinterpret_cast<double*>(lds + RegLds::par);
   const int b = blockIdx.x;
   ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
   for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = scans[i];

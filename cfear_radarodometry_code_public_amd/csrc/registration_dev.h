@@ -168,7 +168,7 @@ __device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared
 // with (c, s) = (cos, sin)(theta). Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P);
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
-template <bool LDS, int COST>
+template <bool LDS, int COST, bool HUBER>
 __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s,
                                                    double* res_out, int res_cap) {
   const int wave = threadIdx.x >> 6;
@@ -212,7 +212,8 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     double sq = r[0] * r[0];
     if (nr == 2) sq += r[1] * r[1];
     Rho rho;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
-    if (P.loss == CFEAR_LOSS_HUBER) {  // the default loss inline (an out-of-line call pays a scratch save/restore), the others out of line
+    if (HUBER) {  // the default loss inline: a function with a call inside saves and restores a register through scratch, a
+                  // round trip to memory at its exit, whichever path is taken (the other losses are out of line)
       const double la = P.loss_limit, lb = la * la;
       if (sq > lb) { const double r = sqrt(sq); rho.v = 2.0 * la * r - lb; rho.d1 = fmax(CFEAR_DBL_MIN, la / r); }
       else { rho.v = sq; rho.d1 = 1.0; }
@@ -241,22 +242,28 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     for (int i = 0; i < 10; i++) W.red[i * CFEAR_RED_STRIDE + wave] = v[i];
   }
 }
-template <int COST>
+template <int COST, bool HUBER>
 __device__ __noinline__ void evaluate_partial_c(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
                                                 double* res_out, int res_cap) {
-  if (lds_match) evaluate_partial_t<true, COST>(W, M, P, x0, x1, c, s, res_out, res_cap);
-  else evaluate_partial_t<false, COST>(W, M, P, x0, x1, c, s, res_out, res_cap);
+  if (lds_match) evaluate_partial_t<true, COST, HUBER>(W, M, P, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_t<false, COST, HUBER>(W, M, P, x0, x1, c, s, res_out, res_cap);
 }
 __device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
                                                  double* res_out = nullptr, int res_cap = 0) {
-  if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-  else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-  else evaluate_partial_c<CFEAR_COST_P2P>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  if (P.loss == CFEAR_LOSS_HUBER) {
+    if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+    else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+    else evaluate_partial_c<CFEAR_COST_P2P, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  } else {
+    if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+    else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+    else evaluate_partial_c<CFEAR_COST_P2P, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  }
 }
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
 // generic pointer every partial sum was a flat load the running sum had to wait for (2.8 us per evaluation).
-__device__ __noinline__ void gather_partials(const RegScratch& W, NormalEq* out /* in LDS */) {
+__device__ __forceinline__ void gather_partials(const RegScratch& W, NormalEq* out /* in LDS */) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   lds_cdouble* red = (lds_cdouble*)W.red;
   const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
@@ -286,7 +293,7 @@ __device__ __noinline__ void gather_partials(const RegScratch& W, NormalEq* out 
 // 3x3 Cholesky solve. The triangular solves multiply by reciprocal square roots of the pivots instead of dividing
 // (three rsqrt instead of three sqrt + nine divisions on the controller's serial chain; differs from the oracle's
 // division form by a few ulp).
-__device__ inline bool chol3_solve(const double A[6], const double b[3], double y[3]) {
+__device__ __forceinline__ bool chol3_solve(const double A[6], const double b[3], double y[3]) {
   const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
   if (!(a00 > 0)) return false;
   const double r0 = rsqrt(a00), l10 = a01 * r0, l20 = a02 * r0;
@@ -720,8 +727,13 @@ __device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const Re
   sh->cmd = REG_CMD_DONE;
 }
 
+// The state functions are leaves (no call inside: a function that calls another one saves and restores a register through
+// scratch, a round trip to memory on the controller's serial chain at every exit) and return what has to happen next;
+// ctl_step, inlined into the kernel, chains them.
+enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE };
+
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
-__device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
   const int itr = sh->itr;
   sh->success = (sh->ss.termination != 2);
   if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
@@ -742,22 +754,21 @@ __device__ __noinline__ void ctl_lm_done(RegShared* sh, const RegIo& io, const R
     sh->prev_score = current_score;
     sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
     sh->itr = itr + 1;  // for-loop increment (:102)
-    if (sh->itr <= P.max_outer && sh->success) { ctl_publish_build(sh, io); return; }
+    if (sh->itr <= P.max_outer && sh->success) return CTL_BUILD;
   }
   // loop left: covariance of the last built problem at the final parameters if the solution is usable (:164-183). The LM
   // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
   // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
-  if (sh->success && reverted) ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV);
-  else if (sh->success) ctl_finish(sh, io, P, true, &sh->E);
-  else ctl_finish(sh, io, P, false, &sh->E);
+  if (sh->success && reverted) { ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV); return CTL_WAIT; }
+  return sh->success ? CTL_FINISH_E : CTL_FINISH_NONE;
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
-__device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
   const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
   for (;;) {
-    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
-    if (sh->radius < min_radius) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; return CTL_LM_DONE; }
+    if (sh->radius < min_radius) { sh->ss.termination = 0; return CTL_LM_DONE; }
     sh->iteration++;
     __builtin_amdgcn_sched_barrier(0);  // keeps the (scalar) controller from holding all its LDS state in registers at once
     const NormalEq E = sh->E;
@@ -789,7 +800,7 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
       if (!(mcc > 0.0)) valid = false;
     }
     if (!valid) {  // HandleInvalidStep
-      if (++sh->num_invalid >= 5) { sh->ss.termination = 2; ctl_lm_done(sh, io, P); return; }
+      if (++sh->num_invalid >= 5) { sh->ss.termination = 2; return CTL_LM_DONE; }
       sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
       sh->ss.num_iterations++; sh->ss.last_relative_decrease = 0.0;
       if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
@@ -800,7 +811,7 @@ __device__ __noinline__ void ctl_lm_next(RegShared* sh, const RegIo& io, const R
     sh->model_cost_change = mcc;
     sh->xc[0] = sh->xcur[0] + y[0] * sc0; sh->xc[1] = sh->xcur[1] + y[1] * sc1; sh->xc[2] = sh->xcur[2] + y[2] * sc2;
     ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND);
-    return;
+    return CTL_WAIT;
   }
 }
 
@@ -823,19 +834,19 @@ __device__ __forceinline__ NormalEq add_prior(const RegShared* sh, NormalEq E, d
 
 // ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
 // over its callees, and it decides how many workgroups share a compute unit) ----
-__device__ __noinline__ void ctl_after_build(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ int ctl_after_build(RegShared* sh, const RegParams& P) {
   const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
   sh->nres = sh->M * rpb;
   if (sh->nres <= 1) {  // :370-371 -> :114-115
     sh->success = 0;
-    ctl_finish(sh, io, P, false, &sh->E);
-    return;
+    return CTL_FINISH_NONE;
   }
   if (sh->prior_on) sh->nres += 3;  // the prior block joins after the residual-count check (:370-377)
   ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
+  return CTL_WAIT;
 }
 
-__device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_it0(RegShared* sh, const RegScratch& W) {
   const double gradient_tolerance = 1e-10;
   gather_partials(W, &sh->G);
   NormalEq E = sh->G;
@@ -844,14 +855,14 @@ __device__ __noinline__ void ctl_after_it0(RegShared* sh, const RegIo& io, const
   sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
   const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
-  if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  if (gmax <= gradient_tolerance) { sh->ss.termination = 0; return CTL_LM_DONE; }
   sh->sc0 = 1.0 / (1.0 + sqrt(E.h00)); sh->sc1 = 1.0 / (1.0 + sqrt(E.h11)); sh->sc2 = 1.0 / (1.0 + sqrt(E.h22));
   sh->radius = 1e4; sh->decrease_factor = 2.0; sh->reuse_diagonal = 0; sh->num_invalid = 0; sh->iteration = 0;
   sh->dg0 = sh->dg1 = sh->dg2 = 0;
-  ctl_lm_next(sh, io, P);
+  return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_candidate(RegShared* sh, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
   gather_partials(W, &sh->G);
@@ -861,9 +872,9 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
   const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-  if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; return CTL_LM_DONE; }
   const double cost_change = sh->x_cost - cand_cost;
-  if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+  if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; return CTL_LM_DONE; }
   __builtin_amdgcn_sched_barrier(0);
   const double relative_decrease = cost_change / sh->model_cost_change;
   sh->ss.num_iterations++;
@@ -879,29 +890,40 @@ __device__ __noinline__ void ctl_after_candidate(RegShared* sh, const RegIo& io,
     sh->decrease_factor = 2.0; sh->reuse_diagonal = 0;
     if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
     const double gmax = fmax(fabs(C.g0), fmax(fabs(C.g1), fabs(C.g2)));
-    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; ctl_lm_done(sh, io, P); return; }
-    if (gmax <= gradient_tolerance) { sh->ss.termination = 0; ctl_lm_done(sh, io, P); return; }
+    if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; return CTL_LM_DONE; }
+    if (gmax <= gradient_tolerance) { sh->ss.termination = 0; return CTL_LM_DONE; }
   } else {  // HandleUnsuccessfulStep
     sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
     if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
   }
   __builtin_amdgcn_sched_barrier(0);
-  ctl_lm_next(sh, io, P);
+  return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ void ctl_after_cov(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_cov(RegShared* sh, const RegScratch& W) {
   gather_partials(W, &sh->G);
   if (sh->prior_on) sh->G = add_prior(sh, sh->G, sh->x[0], sh->x[1], sh->x[2]);
-  ctl_finish(sh, io, P, true, &sh->G);
+  return CTL_FINISH_G;
 }
 
 // consumes the result of the command just executed and publishes the next one
 __device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+  int nx;
   switch (sh->state) {
-    case REG_ST_BUILD: ctl_after_build(sh, io, P); return;
-    case REG_ST_LM_IT0: ctl_after_it0(sh, io, P, W); return;
-    case REG_ST_LM_CAND: ctl_after_candidate(sh, io, P, W); return;
-    default: ctl_after_cov(sh, io, P, W); return;
+    case REG_ST_BUILD: nx = ctl_after_build(sh, P); break;
+    case REG_ST_LM_IT0: nx = ctl_after_it0(sh, W); break;
+    case REG_ST_LM_CAND: nx = ctl_after_candidate(sh, P, W); break;
+    default: nx = ctl_after_cov(sh, W); break;
+  }
+  while (nx != CTL_WAIT) {
+    switch (nx) {
+      case CTL_LM_NEXT: nx = ctl_lm_next(sh, P); break;
+      case CTL_LM_DONE: nx = ctl_lm_done(sh, io, P); break;
+      case CTL_BUILD: ctl_publish_build(sh, io); nx = CTL_WAIT; break;
+      case CTL_FINISH_E: ctl_finish(sh, io, P, true, &sh->E); nx = CTL_WAIT; break;
+      case CTL_FINISH_G: ctl_finish(sh, io, P, true, &sh->G); nx = CTL_WAIT; break;
+      default: ctl_finish(sh, io, P, false, &sh->E); nx = CTL_WAIT; break;
+    }
   }
 }
 
