@@ -399,7 +399,6 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
 // round trip, the four gate normals in one. Same results as scan_closest + the gate of associate_pair.
 struct Assoc4 { int t0, t1, t2, t3; };
 __device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0 ? a.t0 : (i == 1 ? a.t1 : (i == 2 ? a.t2 : a.t3)); }
-__device__ __noinline__ int scan_closest_wide(const GridView* S, float qx, float qy, double d) { return scan_closest(*S, (double)qx, (double)qy, d); }
 
 // keyframes i0 .. i0 + NI - 1 (those below nk) of source cell j; NC candidates per keyframe per round trip.
 // ti[u] = matched target cell of keyframe i0 + u or -1.
@@ -487,7 +486,6 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
   for (int u = 0; u < NI; u++) {
     const int i = i0 + u;
     ti[u] = (best[u] >= 0 && (double)bd[u] < curr_radius * curr_radius) ? best[u] : -1;
-    if (wide & (1 << u)) ti[u] = scan_closest_wide(&sh->kf[i], qx[u], qy[u], curr_radius);
     if (i >= nk) ti[u] = -1;
     tn[u] = make_double2(0.0, 0.0);
     if (ti[u] >= 0) tn[u] = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti[u])[1];
@@ -501,6 +499,9 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
       const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
       if (!(sim > angle_outlier)) ti[u] = -1;  // :247
     }
+    // a window of more than three bucket rows is left to the caller (-2): a call in here would make this function save and
+    // restore a register through scratch at every exit
+    if ((wide & (1 << u)) && i0 + u < nk) ti[u] = -2;
   }
 }
 // two keyframes per call (register budget of the registration kernels): (ti of i0) | (ti of i0 + 1) << 32
@@ -516,6 +517,13 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const RegSh
   if (nk > 2) {
     const unsigned long long q = associate_cell2(src, sh, nk, 2, j, curr_radius);
     a.t2 = (int)(unsigned)q; a.t3 = (int)(unsigned)(q >> 32);
+  }
+  if (a.t0 == -2 || a.t1 == -2 || a.t2 == -2 || a.t3 == -2) {  // rare: the general search for those pairs
+    const int nsrc = src->n_cells;
+    if (a.t0 == -2) a.t0 = associate_pair(src, sh, nsrc, 0 * nsrc + j, curr_radius);
+    if (a.t1 == -2) a.t1 = associate_pair(src, sh, nsrc, 1 * nsrc + j, curr_radius);
+    if (a.t2 == -2) a.t2 = associate_pair(src, sh, nsrc, 2 * nsrc + j, curr_radius);
+    if (a.t3 == -2) a.t3 = associate_pair(src, sh, nsrc, 3 * nsrc + j, curr_radius);
   }
   return a;
 }
