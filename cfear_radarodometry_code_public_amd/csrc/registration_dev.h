@@ -591,7 +591,7 @@ __device__ __forceinline__ unsigned long long assoc_counts(const Assoc4& a) {
   return (unsigned long long)(a.t0 >= 0) | ((unsigned long long)(a.t1 >= 0) << 16) | ((unsigned long long)(a.t2 >= 0) << 32) |
          ((unsigned long long)(a.t3 >= 0) << 48);
 }
-__device__ __noinline__ AssocBlock assoc_block(const ScanDev* src, const RegShared* sh, int nk, int nsrc, int itr, int b) {
+__device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const RegShared* sh, int nk, int nsrc, int itr, int b) {
   AssocBlock R;
   R.a.t0 = R.a.t1 = R.a.t2 = R.a.t3 = -1;
   const int j = b * blockDim.x + threadIdx.x;
@@ -619,7 +619,7 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
   return tb;
 }
 
-__device__ __noinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, int itr) {
+__device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, int itr) {
   const RegParams& P = sh->rp;  // in LDS: addresses derived from sh, nothing to keep alive across the calls below
   const RegScratch& W = sh->rw;
   const ScanDev* src = scans[n - 1];
