@@ -681,6 +681,8 @@ __device__ __forceinline__ void ctl_publish_eval(RegShared* sh, double x0, doubl
   sh->cmd = REG_CMD_EVAL; sh->state = state;
 }
 
+__device__ __noinline__ void ctl_publish_candidate(RegShared* sh) { ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND); }
+
 // transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
 __device__ __noinline__ void ctl_publish_build(RegShared* sh, const RegIo& io) {
   const int n = io.n, L = 3 * (n - 1);
@@ -738,7 +740,7 @@ __device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const Re
 // The state functions are leaves (no call inside: a function that calls another one saves and restores a register through
 // scratch, a round trip to memory on the controller's serial chain at every exit) and return what has to happen next;
 // ctl_step, inlined into the kernel, chains them.
-enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE };
+enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND };
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
 __device__ __noinline__ int ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
@@ -818,8 +820,8 @@ __device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
     sh->num_invalid = 0;
     sh->model_cost_change = mcc;
     sh->xc[0] = sh->xcur[0] + y[0] * sc0; sh->xc[1] = sh->xcur[1] + y[1] * sc1; sh->xc[2] = sh->xcur[2] + y[2] * sc2;
-    ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND);
-    return CTL_WAIT;
+    return CTL_EVAL_CAND;  // the candidate is published by a function of its own: sincos on top of this one's registers reaches the
+                           // callee-saved ones, and saving those is a round trip through scratch at the exit
   }
 }
 
@@ -928,6 +930,7 @@ __device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const R
       case CTL_LM_NEXT: nx = ctl_lm_next(sh, P); break;
       case CTL_LM_DONE: nx = ctl_lm_done(sh, io, P); break;
       case CTL_BUILD: ctl_publish_build(sh, io); nx = CTL_WAIT; break;
+      case CTL_EVAL_CAND: ctl_publish_candidate(sh); nx = CTL_WAIT; break;
       case CTL_FINISH_E: ctl_finish(sh, io, P, true, &sh->E); nx = CTL_WAIT; break;
       case CTL_FINISH_G: ctl_finish(sh, io, P, true, &sh->G); nx = CTL_WAIT; break;
       default: ctl_finish(sh, io, P, false, &sh->E); nx = CTL_WAIT; break;
