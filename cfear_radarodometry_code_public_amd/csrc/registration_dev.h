@@ -148,6 +148,23 @@ struct RegShared {
   int reuse_diagonal, num_invalid, iteration, pad1;
 };
 
+// RegShared lives in LDS. Through a generic pointer every field access converts the address (64-bit add, compare with
+// null, select: three extra instructions each, a third of the controller's instruction stream); the functions below take
+// it through an LDS-typed pointer instead. Structs are copied field by field (no copy constructors across address spaces).
+typedef __attribute__((address_space(3))) RegShared LRegShared;
+typedef __attribute__((address_space(3))) NormalEq LNormalEq;
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ NormalEq neq_load(const LNormalEq* p) {
+  NormalEq e; e.cost = p->cost; e.g0 = p->g0; e.g1 = p->g1; e.g2 = p->g2; e.h00 = p->h00; e.h01 = p->h01; e.h02 = p->h02;
+  e.h11 = p->h11; e.h12 = p->h12; e.h22 = p->h22;
+  return e;
+}
+__device__ __forceinline__ void neq_store(LNormalEq* p, const NormalEq& e) {
+  p->cost = e.cost; p->g0 = e.g0; p->g1 = e.g1; p->g2 = e.g2; p->h00 = e.h00; p->h01 = e.h01; p->h02 = e.h02;
+  p->h11 = e.h11; p->h12 = e.h12; p->h22 = e.h22;
+}
+#define CFEAR_GENERIC(T, lvalue) (*(T*)&(lvalue))  // generic-address-space view of an LDS object (for by-reference parameters)
+
 // ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
 // 636 matches x 64 B + the rest of the registration kernels' LDS = 53,568 B: three workgroups per compute unit need
 // <= 53,760 B each (LDS is handed out in 1,280-byte granules; 53,824 B already drops the kernel to two per CU and +34 % time)
@@ -263,7 +280,7 @@ __device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
 // generic pointer every partial sum was a flat load the running sum had to wait for (2.8 us per evaluation).
-__device__ __forceinline__ void gather_partials(const RegScratch& W, NormalEq* out /* in LDS */) {
+__device__ __forceinline__ void gather_partials(const RegScratch& W, LNormalEq* out) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   lds_cdouble* red = (lds_cdouble*)W.red;
   const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
@@ -285,7 +302,7 @@ __device__ __forceinline__ void gather_partials(const RegScratch& W, NormalEq* o
     __builtin_amdgcn_sched_barrier(0);
   }
   typedef __attribute__((address_space(3))) double lds_double;
-  lds_double* o = (lds_double*)reinterpret_cast<double*>(out);  // field order of NormalEq: cost g0 g1 g2 h00 h01 h02 h11 h12 h22
+  lds_double* o = (lds_double*)out;  // field order of NormalEq: cost g0 g1 g2 h00 h01 h02 h11 h12 h22
 #pragma unroll
   for (int i = 0; i < 10; i++) o[i] = r[i];  // every lane of the controller wave stores the same values
 }
@@ -356,17 +373,17 @@ __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const Reg
 
 // association of one (keyframe i, source cell j) pair (n_scan_normal.cpp:228-247): index of the matched target
 // cell or -1. Out of line: the kernel's register budget is the maximum over its callees.
-__device__ __noinline__ int associate_pair(const ScanDev* src, const RegShared* sh, int nsrc, int p, double curr_radius) {
+__device__ __noinline__ int associate_pair(const ScanDev* src, const LRegShared* sh, int nsrc, int p, double curr_radius) {
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const int i = p / nsrc, j = p - i * nsrc;
-  const double* T = sh->Trel[i];
+  const auto* T = sh->Trel[i];
   const size_t cc = (size_t)src->cap_cells;
   const double* rs = src->rsrc + j;
   const double mx = rs[0], my = rs[cc];
   const double snx = rs[2 * cc], sny = rs[3 * cc];
   const double qx = (T[0] * mx + T[1] * my) + T[4];
   const double qy = (T[2] * mx + T[3] * my) + T[5];
-  int ti = scan_closest(sh->kf[i], qx, qy, curr_radius);
+  int ti = scan_closest(CFEAR_GENERIC(const GridView, sh->kf[i]), qx, qy, curr_radius);
   if (ti >= 0) {
     const double2 tn = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti)[1];
     const double nx = T[0] * snx + T[1] * sny;
@@ -376,9 +393,9 @@ __device__ __noinline__ int associate_pair(const ScanDev* src, const RegShared* 
   }
   return ti;
 }
-__device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, int nsrc, int p, int ti, int o, bool use_lds) {
-  const RegParams& P = sh->rp;
-  const RegScratch& W = sh->rw;
+__device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nsrc, int p, int ti, int o, bool use_lds) {
+  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
+  const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   const int i = p / nsrc, j = p - i * nsrc;
   const RCell cs = rcell_src(src, j);
   RCell ct;
@@ -388,8 +405,10 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
     ct.mx = r0.x; ct.my = r0.y; ct.nx = r1.x; ct.ny = r1.y; ct.ns = r2.x; ct.scale = r2.y;
   }
   const cfear_cell* ctf = (P.cost == CFEAR_COST_P2D) ? &scans[i]->cells[ti] : nullptr;
-  if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
-  else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, sh->Trel[i], sh->Ttar[i], cs, ct, ctf);
+  const double* Trel = (const double*)sh->Trel[i];  // generic views for the by-pointer interface of write_match
+  const double* Ttar = (const double*)sh->Ttar[i];
+  if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, Trel, Ttar, cs, ct, ctf);
+  else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, Trel, Ttar, cs, ct, ctf);
 }
 
 // ---- association of one source cell against up to four keyframes at once ------------------------------------
@@ -403,7 +422,7 @@ __device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0
 // keyframes i0 .. i0 + NI - 1 (those below nk) of source cell j; NC candidates per keyframe per round trip.
 // ti[u] = matched target cell of keyframe i0 + u or -1.
 template <int NI, int NC>
-__device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegShared* sh, int nk, int i0, int j, double curr_radius, int* ti) {
+__device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegShared* sh, int nk, int i0, int j, double curr_radius, int* ti) {
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const size_t cc = (size_t)src->cap_cells;
   const double* rs = src->rsrc + j;
@@ -419,7 +438,7 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
 #pragma unroll
     for (int r = 0; r < 3; r++) { lo[u][r] = 0; hi[u][r] = 0; }
     if (i < nk) {
-      const double* T = sh->Trel[i];
+      const auto* T = sh->Trel[i];
       qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
       qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
       const int gw = sh->kf[i].gw, gh = sh->kf[i].gh;
@@ -493,7 +512,7 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
 #pragma unroll
   for (int u = 0; u < NI; u++) {
     if (ti[u] >= 0) {
-      const double* T = sh->Trel[i0 + u];
+      const auto* T = sh->Trel[i0 + u];
       const double nx = T[0] * snx + T[1] * sny;
       const double ny = T[2] * snx + T[3] * sny;
       const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
@@ -505,12 +524,12 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const RegSh
   }
 }
 // two keyframes per call (register budget of the registration kernels): (ti of i0) | (ti of i0 + 1) << 32
-__device__ __noinline__ unsigned long long associate_cell2(const ScanDev* src, const RegShared* sh, int nk, int i0, int j, double curr_radius) {
+__device__ __noinline__ unsigned long long associate_cell2(const ScanDev* src, const LRegShared* sh, int nk, int i0, int j, double curr_radius) {
   int ti[2];
   associate_cell_t<2, 4>(src, sh, nk, i0, j, curr_radius, ti);
   return (unsigned long long)(unsigned)ti[0] | ((unsigned long long)(unsigned)ti[1] << 32);
 }
-__device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const RegShared* sh, int nk, int j, double curr_radius) {
+__device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegShared* sh, int nk, int j, double curr_radius) {
   Assoc4 a = {-1, -1, -1, -1};
   const unsigned long long p = associate_cell2(src, sh, nk, 0, j, curr_radius);
   a.t0 = (int)(unsigned)p; a.t1 = (int)(unsigned)(p >> 32);
@@ -531,9 +550,9 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const RegSh
 // residual blocks of one source cell (up to four keyframes); pos = four 16-bit positions in the match arrays.
 // The source cell is read once; matches that fit the LDS array are stored through an LDS-typed pointer (ds_write, not
 // flat stores through the address unit). Same arithmetic as write_match.
-__device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const RegShared* sh,
+__device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
-  const RegParams& P = sh->rp;
+  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
   const RCell cs = rcell_src(src, j);
   typedef __attribute__((address_space(3))) double lds_double;
 #pragma unroll 1
@@ -548,8 +567,8 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
     auto put = [&](int q, double val) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; };
     const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti);
     const double2 r0 = r[0], r1 = r[1], r2 = r[2];  // mean, normal, (samples, scale)
-    const double* T = sh->Trel[i];
-    const double* Tt = sh->Ttar[i];
+    const auto* T = sh->Trel[i];
+    const auto* Tt = sh->Ttar[i];
     put(5, cs.mx); put(6, cs.my);
     put(0, (Tt[0] * r0.x + Tt[1] * r0.y) + Tt[4]);
     put(1, (Tt[2] * r0.x + Tt[3] * r0.y) + Tt[5]);
@@ -591,7 +610,7 @@ __device__ __forceinline__ unsigned long long assoc_counts(const Assoc4& a) {
   return (unsigned long long)(a.t0 >= 0) | ((unsigned long long)(a.t1 >= 0) << 16) | ((unsigned long long)(a.t2 >= 0) << 32) |
          ((unsigned long long)(a.t3 >= 0) << 48);
 }
-__device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const RegShared* sh, int nk, int nsrc, int itr, int b) {
+__device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int itr, int b) {
   AssocBlock R;
   R.a.t0 = R.a.t1 = R.a.t2 = R.a.t3 = -1;
   const int j = b * blockDim.x + threadIdx.x;
@@ -606,7 +625,7 @@ __device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const RegS
 }
 // residual blocks of block b of the source cells; before = matches in front of this block, per keyframe. Returns the
 // matches of the block per keyframe (0 when the block is the only one: nothing follows it).
-__device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const RegShared* sh, int nk, int nsrc, int b,
+__device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int b,
                                                       Assoc4 a, unsigned long long e, unsigned long long before, bool use_lds) {
   const int j = b * blockDim.x + threadIdx.x;
   unsigned long long tb = 0;
@@ -619,9 +638,9 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
   return tb;
 }
 
-__device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, RegShared* sh, int itr) {
-  const RegParams& P = sh->rp;  // in LDS: addresses derived from sh, nothing to keep alive across the calls below
-  const RegScratch& W = sh->rw;
+__device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, LRegShared* sh, int itr) {
+  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);  // in LDS: addresses derived from sh, nothing to keep alive across the calls below
+  const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
@@ -675,22 +694,22 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
 // Same arithmetic, in the same order, as the CPU oracle's register / LM routines (tests compare iteration counts).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void ctl_publish_eval(RegShared* sh, double x0, double x1, double x2, int state) {
+__device__ __forceinline__ void ctl_publish_eval(LRegShared* sh, double x0, double x1, double x2, int state) {
   sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
   { double sn, cs; sincos(x2, &sn, &cs); sh->c = cs; sh->s = sn; }
   sh->cmd = REG_CMD_EVAL; sh->state = state;
 }
 
-__device__ __noinline__ void ctl_publish_candidate(RegShared* sh) { ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND); }
+__device__ __noinline__ void ctl_publish_candidate(LRegShared* sh) { ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND); }
 
 // transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
-__device__ __noinline__ void ctl_publish_build(RegShared* sh, const RegIo& io) {
+__device__ __noinline__ void ctl_publish_build(LRegShared* sh, const RegIo& io) {
   const int n = io.n, L = 3 * (n - 1);
   const Aff2 Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
   for (int i = lane_id(); i < n - 1; i += 64) {
     const Aff2 Tt = aff_from_xyt(io.par[3 * i], io.par[3 * i + 1], io.par[3 * i + 2]);
     const Aff2 Tr = aff_mul(aff_inv(Tt), Tsrc);  // Tsrctotar (:224)
-    double* a = sh->Ttar[i]; double* b = sh->Trel[i];
+    auto* a = sh->Ttar[i]; auto* b = sh->Trel[i];
     a[0] = Tt.l0; a[1] = Tt.l1; a[2] = Tt.l2; a[3] = Tt.l3; a[4] = Tt.t0; a[5] = Tt.t1;
     b[0] = Tr.l0; b[1] = Tr.l1; b[2] = Tr.l2; b[3] = Tr.l3; b[4] = Tr.t0; b[5] = Tr.t1;
   }
@@ -699,8 +718,8 @@ __device__ __noinline__ void ctl_publish_build(RegShared* sh, const RegIo& io) {
   sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
 }
 
-__device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const NormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
-  const NormalEq& E = *Ep;
+__device__ __noinline__ void ctl_finish(LRegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const LNormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
+  const NormalEq E = neq_load(Ep);
   const int n = io.n, L = 3 * (n - 1);
   int ret = 0;
   if (lane_id() == 0) {
@@ -743,7 +762,7 @@ __device__ __noinline__ void ctl_finish(RegShared* sh, const RegIo& io, const Re
 enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND };
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
-__device__ __noinline__ int ctl_lm_done(RegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_done(LRegShared* sh, const RegIo& io, const RegParams& P) {
   const int itr = sh->itr;
   sh->success = (sh->ss.termination != 2);
   if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
@@ -774,14 +793,13 @@ __device__ __noinline__ int ctl_lm_done(RegShared* sh, const RegIo& io, const Re
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
-__device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_next(LRegShared* sh, const RegParams& P) {
   const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
   for (;;) {
     if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; return CTL_LM_DONE; }
     if (sh->radius < min_radius) { sh->ss.termination = 0; return CTL_LM_DONE; }
     sh->iteration++;
-    __builtin_amdgcn_sched_barrier(0);  // keeps the (scalar) controller from holding all its LDS state in registers at once
-    const NormalEq E = sh->E;
+    const NormalEq E = neq_load(&sh->E);
     const double sc0 = sh->sc0, sc1 = sh->sc1, sc2 = sh->sc2;
     double Hs[6], gs[3];
     Hs[0] = E.h00 * sc0 * sc0; Hs[1] = E.h01 * sc0 * sc1; Hs[2] = E.h02 * sc0 * sc2;
@@ -797,9 +815,7 @@ __device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
     const double Am[6] = {Hs[0] + sh->dg0 * inv_radius, Hs[1], Hs[2], Hs[3] + sh->dg1 * inv_radius, Hs[4], Hs[5] + sh->dg2 * inv_radius};
     const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
     double y[3];
-    __builtin_amdgcn_sched_barrier(0);
     bool valid = chol3_solve(Am, rhs, y);
-    __builtin_amdgcn_sched_barrier(0);
     sh->reuse_diagonal = 1;
     double mcc = 0;
     if (valid) {
@@ -816,7 +832,6 @@ __device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
       if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
       continue;
     }
-    __builtin_amdgcn_sched_barrier(0);
     sh->num_invalid = 0;
     sh->model_cost_change = mcc;
     sh->xc[0] = sh->xcur[0] + y[0] * sc0; sh->xc[1] = sh->xcur[1] + y[1] * sc1; sh->xc[2] = sh->xcur[2] + y[2] * sc2;
@@ -827,7 +842,7 @@ __device__ __noinline__ int ctl_lm_next(RegShared* sh, const RegParams& P) {
 
 // mahalanobisDistanceError (n_scan_normal.h:259-290) at x: r = L (alpha (guess - x)), J = -alpha L, no loss
 // (forceinline, by value: a NormalEq handed to an out-of-line function by reference would live in per-thread scratch)
-__device__ __forceinline__ NormalEq add_prior(const RegShared* sh, NormalEq E, double x0, double x1, double x2) {
+__device__ __forceinline__ NormalEq add_prior(const LRegShared* sh, NormalEq E, double x0, double x1, double x2) {
   const double a = sh->palpha;
   const double d0 = a * (sh->pguess[0] - x0), d1 = a * (sh->pguess[1] - x1), d2 = a * (sh->pguess[2] - x2);
 #pragma unroll
@@ -844,7 +859,7 @@ __device__ __forceinline__ NormalEq add_prior(const RegShared* sh, NormalEq E, d
 
 // ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
 // over its callees, and it decides how many workgroups share a compute unit) ----
-__device__ __noinline__ int ctl_after_build(RegShared* sh, const RegParams& P) {
+__device__ __noinline__ int ctl_after_build(LRegShared* sh, const RegParams& P) {
   const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
   sh->nres = sh->M * rpb;
   if (sh->nres <= 1) {  // :370-371 -> :114-115
@@ -856,12 +871,12 @@ __device__ __noinline__ int ctl_after_build(RegShared* sh, const RegParams& P) {
   return CTL_WAIT;
 }
 
-__device__ __noinline__ int ctl_after_it0(RegShared* sh, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_it0(LRegShared* sh, const RegScratch& W) {
   const double gradient_tolerance = 1e-10;
   gather_partials(W, &sh->G);
-  NormalEq E = sh->G;
+  NormalEq E = neq_load(&sh->G);
   if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
-  sh->E = E; sh->x_cost = E.cost;
+  neq_store(&sh->E, E); sh->x_cost = E.cost;
   sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
   const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
@@ -872,28 +887,25 @@ __device__ __noinline__ int ctl_after_it0(RegShared* sh, const RegScratch& W) {
   return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ int ctl_after_candidate(RegShared* sh, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_candidate(LRegShared* sh, const RegParams& P, const RegScratch& W) {
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
   gather_partials(W, &sh->G);
-  NormalEq C = sh->G;
+  NormalEq C = neq_load(&sh->G);
   if (sh->prior_on) C = add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
-  __builtin_amdgcn_sched_barrier(0);
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
   const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
   if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; return CTL_LM_DONE; }
   const double cost_change = sh->x_cost - cand_cost;
   if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; return CTL_LM_DONE; }
-  __builtin_amdgcn_sched_barrier(0);
   const double relative_decrease = cost_change / sh->model_cost_change;
   sh->ss.num_iterations++;
   sh->ss.last_relative_decrease = relative_decrease;
   if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
     sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
     sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
-    sh->E = C; sh->x_cost = cand_cost;
-    __builtin_amdgcn_sched_barrier(0);
+    neq_store(&sh->E, C); sh->x_cost = cand_cost;
     const double t = 2.0 * relative_decrease - 1.0;
     sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
     sh->radius = fmin(max_radius, sh->radius);
@@ -906,18 +918,17 @@ __device__ __noinline__ int ctl_after_candidate(RegShared* sh, const RegParams& 
     sh->radius = sh->radius / sh->decrease_factor; sh->decrease_factor *= 2.0; sh->reuse_diagonal = 1;
     if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
   }
-  __builtin_amdgcn_sched_barrier(0);
   return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ int ctl_after_cov(RegShared* sh, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_cov(LRegShared* sh, const RegScratch& W) {
   gather_partials(W, &sh->G);
-  if (sh->prior_on) sh->G = add_prior(sh, sh->G, sh->x[0], sh->x[1], sh->x[2]);
+  if (sh->prior_on) neq_store(&sh->G, add_prior(sh, neq_load(&sh->G), sh->x[0], sh->x[1], sh->x[2]));
   return CTL_FINISH_G;
 }
 
 // consumes the result of the command just executed and publishes the next one
-__device__ __forceinline__ void ctl_step(RegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __forceinline__ void ctl_step(LRegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
   int nx;
   switch (sh->state) {
     case REG_ST_BUILD: nx = ctl_after_build(sh, P); break;
@@ -945,13 +956,14 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
                                      const RegScratch& W_in, double* par_lds, RegShared* sh, cfear_reg_summary* out,
                                      PhaseTimer* pt = nullptr, const double* prior_cov6 = nullptr) {
   const int tid = threadIdx.x;
+  LRegShared* ls = (LRegShared*)sh;  // the same object through an LDS-typed pointer (see LRegShared)
   if (tid == 0) {
     sh->rp = P_in; sh->rw = W_in;
     sh->rio.poses = poses; sh->rio.cov6 = cov6; sh->rio.out = out; sh->rio.par = par_lds; sh->rio.n = n;
   }
   __syncthreads();
-  const RegParams& P = sh->rp;
-  const RegScratch& W = sh->rw;
+  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
+  const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   const RegIo& io = sh->rio;
   const bool master = (tid >> 6) == 0;
   // Affine3dToVectorXYeZ(Tsrc[i]) (:88-92): theta -> atan2(sin, cos)
@@ -990,7 +1002,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     sh->prev_score = 1.7976931348623157e308;
     sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1;
     sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
-    ctl_publish_build(sh, io);
+    ctl_publish_build(ls, io);
   }
   for (;;) {
     __syncthreads();  // command visible to every wave
@@ -998,14 +1010,14 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     if (cmd == REG_CMD_DONE) break;
     if (cmd == REG_CMD_BUILD) {
       if (pt) pt->mark();
-      const int M = build_problem_block(scans, n, sh, sh->itr);
+      const int M = build_problem_block(scans, n, ls, ls->itr);
       if (tid == 0) sh->M = M;
       if (pt) pt->mark();
     } else {
       evaluate_partial(W, sh->M, sh->lds_match, P, sh->x[0], sh->x[1], sh->c, sh->s);
     }
     __syncthreads();  // results visible to the controller
-    if (master) ctl_step(sh, io, P, W);
+    if (master) ctl_step(ls, io, P, W);
   }
   const int ret = sh->ret;
   __syncthreads();
@@ -1019,6 +1031,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
 __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double* poses, const RegParams& P_in, const RegScratch& W_in,
                                       double* par_lds, RegShared* sh, int itr, double* score, double* residuals, int cap, int* n_res) {
   const int tid = threadIdx.x;
+  LRegShared* ls = (LRegShared*)sh;
   if (tid == 0) {
     sh->rp = P_in; sh->rw = W_in;
     sh->rio.poses = nullptr; sh->rio.cov6 = nullptr; sh->rio.out = nullptr; sh->rio.par = par_lds; sh->rio.n = n;
@@ -1030,16 +1043,16 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
     sh->kf[i] = grid_view(scans[i]);
   }
   __syncthreads();
-  const RegParams& P = sh->rp;
-  const RegScratch& W = sh->rw;
+  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
+  const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   if ((tid >> 6) == 0) {
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
     sh->prior_on = 0;
-    ctl_publish_build(sh, sh->rio);
+    ctl_publish_build(ls, sh->rio);
   }
   __syncthreads();
-  const int M = build_problem_block(scans, n, sh, itr);
+  const int M = build_problem_block(scans, n, ls, itr);
   const int nres = M * ((P.cost == CFEAR_COST_P2L) ? 1 : 2);
   if (nres <= 1) {  // :205-208
     if (tid == 0) { *n_res = -1; *score = 0.0; }
@@ -1050,8 +1063,8 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
   evaluate_partial(W, M, sh->lds_match, P, sh->xcur[0], sh->xcur[1], cs, sn, residuals, cap);
   __syncthreads();
   if (tid == 0) {
-    gather_partials(W, &sh->G);
-    *score = sh->G.cost; *n_res = nres;
+    gather_partials(W, &ls->G);
+    *score = ls->G.cost; *n_res = nres;
   }
 }
 
