@@ -142,6 +142,11 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
                                        float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
                                        double m0, double m1, double m2, int ccw, int* red_i, float* red_f, double* tab,
                                        int tab_bearings, float bounds[4]) {
+  // the sweep's slots, the trigonometric table and the cloud are global arrays: global-typed pointers give global_load /
+  // global_store instead of flat instructions (which also count against the LDS counter)
+  const __attribute__((address_space(1))) uint32_t* const g_slots = (const __attribute__((address_space(1))) uint32_t*)slots;
+  const __attribute__((address_space(1))) double* const g_trig = (const __attribute__((address_space(1))) double*)trig;
+  __attribute__((address_space(1))) float* const g_xyi = (__attribute__((address_space(1))) float*)xyi;
   const double range_res = (double)range_res_f;
   const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // radar_filters.cpp:315
   const double range_res_half = range_res / 2.0;
@@ -162,7 +167,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   }
   int cnt = 0;
   for (int i = i0; i < i1; i++) {
-    const uint32_t s = slots[i];
+    const uint32_t s = g_slots[i];
     cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
   }
   int total;
@@ -171,10 +176,10 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
   for (int i = i0; i < i1; i++, jb++) {
     if (jb == k) { jb = 0; b++; }
-    const uint32_t s = slots[i];
+    const uint32_t s = g_slots[i];
     const int range = CFEAR_SLOT_RANGE(s);
     if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
-      const double cb = trig[2 * b], sb = trig[2 * b + 1];
+      const double cb = g_trig[2 * b], sb = g_trig[2 * b + 1];
       const double rad = range_res_half + range_res * range;
       float x = (float)(rad * cb);  // :329
       float y = (float)(rad * sb);  // :330
@@ -198,7 +203,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
         x = (float)((c1 * px + (-s1) * py) + d * m0);
         y = (float)((s1 * px + c1 * py) + d * m1);
       }
-      xyi[3 * o + 0] = x; xyi[3 * o + 1] = y; xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
+      g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       o++;
     }
@@ -264,8 +269,18 @@ __device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, i
 // p2 = power of two >= n with p2 <= capacity of W.keys.
 __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2,
                                       PhaseTimer* pt = nullptr, const float* bounds = nullptr) {
+  // global working arrays through global-typed pointers: global_load / global_store instead of flat instructions (a flat
+  // access also counts against the LDS counter, so waiting for LDS data would wait for it as well)
+  typedef __attribute__((address_space(1))) double g_f64;
+  typedef __attribute__((address_space(1))) float g_f32;
+  typedef __attribute__((address_space(1))) int g_i32;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) i32x4 g_i32x4;
+  g_f64* const g_part = (g_f64*)W.part;
+  g_f32* const g_samples = (g_f32*)W.samples;
+  g_i32* const g_rng = (g_i32*)W.rng;
   const int tid = threadIdx.x, nt = blockDim.x;
-  const float* __restrict__ xyi = S->xyi;
+  const g_f32* const xyi = (const g_f32*)S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
     if (tid == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = 0; S->status = CFEAR_ERR_EMPTY; S->gw = 0; S->gh = 0; }
     __syncthreads();
@@ -404,7 +419,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     float sx = 0.f, sy = 0.f, si = 0.f;
     for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
     const float cnt = (float)(b - a);
-    W.samples[3 * v] = sx / cnt; W.samples[3 * v + 1] = sy / cnt; W.samples[3 * v + 2] = si / cnt;
+    g_samples[3 * v] = sx / cnt; g_samples[3 * v + 1] = sy / cnt; g_samples[3 * v + 2] = si / cnt;
   }
   __syncthreads();
   if (pt) pt->mark();
@@ -419,7 +434,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   // chunk order (deterministic).
   int* __restrict__ T = W.order;  // the sorted order has been consumed by the staging above
   for (int v = tid; v < nv; v += nt) {
-    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+    const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
     int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
     int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
     gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
@@ -444,8 +459,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
     }
     if (nr > 4) R[0] = -1;  // only with leaf < radius: the chunk lanes search again (copies made below)
-    int4* Rg = reinterpret_cast<int4*>(W.rng + 8 * (size_t)v);
-    Rg[0] = make_int4(R[0], R[1], R[2], R[3]); Rg[1] = make_int4(R[4], R[5], R[6], R[7]);
+    g_i32x4* Rg = (g_i32x4*)(g_rng + 8 * (size_t)v);
+    Rg[0] = i32x4{R[0], R[1], R[2], R[3]}; Rg[1] = i32x4{R[4], R[5], R[6], R[7]};
     T[v] = tot >= 6 ? tot : 0;  // fewer than six candidates can never make a cell (pointnormal.cpp:291): no chunks, no partial sums
   }
   const bool wide = (int)(2.0f * rq * inv) + 2 > 4;  // block-uniform
@@ -480,9 +495,9 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   for (int w = tid; w < NC; w += nt) {
     const int v = W.vlist[w];
     const int j = w - W.vstart[v];
-    const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
-    const int* R = W.rng + 8 * (size_t)v;
-    const int4 r0 = *reinterpret_cast<const int4*>(R), r1 = *reinterpret_cast<const int4*>(R + 4);
+    const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
+    const g_i32x4* R = (const g_i32x4*)(g_rng + 8 * (size_t)v);
+    const i32x4 r0 = R[0], r1 = R[1];
     const int tot = T[v];
     int skip = j * C, left = min(C, tot - skip);
     CellAcc A = {0, 0, 0, 0, 0, 0, 0};
@@ -519,8 +534,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
     }
     const size_t cs = (size_t)W.cap;
-    W.part[w] = (double)A.m; W.part[cs + w] = A.s0; W.part[2 * cs + w] = A.s1x; W.part[3 * cs + w] = A.s1y;
-    W.part[4 * cs + w] = A.sxx; W.part[5 * cs + w] = A.sxy; W.part[6 * cs + w] = A.syy;
+    g_part[w] = (double)A.m; g_part[cs + w] = A.s0; g_part[2 * cs + w] = A.s1x; g_part[3 * cs + w] = A.s1y;
+    g_part[4 * cs + w] = A.sxx; g_part[5 * cs + w] = A.sxy; g_part[6 * cs + w] = A.syy;
   }
   __syncthreads();
   if (pt) pt->mark();
@@ -537,12 +552,12 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
         const size_t cs = (size_t)W.cap;
         for (int w = W.vstart[v]; w < W.vstart[v + 1]; w++) {
-          md += W.part[w]; s0 += W.part[cs + w]; s1x += W.part[2 * cs + w]; s1y += W.part[3 * cs + w];
-          sxx += W.part[4 * cs + w]; sxy += W.part[5 * cs + w]; syy += W.part[6 * cs + w];
+          md += g_part[w]; s0 += g_part[cs + w]; s1x += g_part[2 * cs + w]; s1y += g_part[3 * cs + w];
+          sxx += g_part[4 * cs + w]; sxy += g_part[5 * cs + w]; syy += g_part[6 * cs + w];
         }
         const int m = (int)md;
         if (m >= 6) {  // :291
-          const float cx = W.samples[3 * v], cy = W.samples[3 * v + 1];
+          const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
           const double m1x = s1x / s0, m1y = s1y / s0;
           const double ux = (double)cx + m1x, uy = (double)cy + m1y;
           const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
@@ -567,16 +582,24 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       int round_total;
       const int o = base + block_exclusive_scan(valid, W.red_i, &round_total);
       if (valid && o < cap_cells) {
-        S->cells[o] = c;
-        S->mean_f[2 * o] = (float)c.mean[0];
-        S->mean_f[2 * o + 1] = (float)c.mean[1];
+        typedef __attribute__((address_space(1))) cfear_cell g_cell;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) f64x2 g_f64x2;
+        g_cell* gc = (g_cell*)S->cells + o;
+        gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
+        gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
+        gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
+        gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        g_f32* mf = (g_f32*)S->mean_f;
+        mf[2 * o] = (float)c.mean[0];
+        mf[2 * o + 1] = (float)c.mean[1];
         const size_t cc = (size_t)cap_cells;
-        double* rs = S->rsrc + o;
+        g_f64* rs = (g_f64*)S->rsrc + o;
         rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
         rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
-        double2* rt = reinterpret_cast<double2*>(S->rtar + 8 * (size_t)o);
-        rt[0] = make_double2(c.mean[0], c.mean[1]); rt[1] = make_double2(c.normal[0], c.normal[1]);
-        rt[2] = make_double2((double)c.nsamples, c.scale);
+        g_f64x2* rt = (g_f64x2*)(S->rtar + 8 * (size_t)o);
+        rt[0] = f64x2{c.mean[0], c.mean[1]}; rt[1] = f64x2{c.normal[0], c.normal[1]};
+        rt[2] = f64x2{(double)c.nsamples, c.scale};
       }
       base += round_total;
     }
@@ -587,9 +610,15 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   if (pt) pt->mark();
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
   const int nc = S->n_cells;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  g_f32* const g_mean = (g_f32*)S->mean_f;
+  g_i32* const g_gstart = (g_i32*)S->gstart;
+  __attribute__((address_space(1))) f32x4* const g_gpts = (__attribute__((address_space(1))) f32x4*)S->gpts;
+  __attribute__((address_space(1))) u32x2* const g_rows3 = (__attribute__((address_space(1))) u32x2*)grid_rows3(S->gstart);
   float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
   for (int i = tid; i < nc; i += nt) {
-    const float x = S->mean_f[2 * i], y = S->mean_f[2 * i + 1];
+    const float x = g_mean[2 * i], y = g_mean[2 * i + 1];
     gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
   }
   { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
@@ -616,7 +645,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     for (int g = tid; g <= G; g += nt) gc[g] = 0;
     __syncthreads();
     for (int i = tid; i < nc; i += nt) {
-      int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+      int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
       cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
       atomicAdd(&gc[cy * gw + cx + 1], 1);
     }
@@ -632,31 +661,30 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       int* gl = gc + (G + 1);
       rows3_done = 2 * (G + 1) <= W.tab_voxels / 2;
       for (int g = i0; g < i1; g++) {  // cursor / end offset
-        const int c = gc[g + 1]; gc[g + 1] = o; S->gstart[g + 1] = o + c; o += c;
+        const int c = gc[g + 1]; gc[g + 1] = o; g_gstart[g + 1] = o + c; o += c;
         if (rows3_done) gl[g + 1] = o;
       }
-      if (tid == 0) { S->gstart[0] = 0; if (rows3_done) gl[0] = 0; }
+      if (tid == 0) { g_gstart[0] = 0; if (rows3_done) gl[0] = 0; }
       __syncthreads();
       if (rows3_done) {
-        uint2* g3 = grid_rows3(S->gstart);
         for (int g = tid; g <= G; g += nt) {
           const unsigned a = (unsigned)gl[g], b = (unsigned)gl[min(g + gw, G)], c = (unsigned)gl[min(g + 2 * gw, G)];
-          g3[g] = make_uint2((a & 0xFFFFu) | (b << 16), c & 0xFFFFu);
+          g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
         }
       }
     }
     for (int i = tid; i < nc; i += nt) {
-      const float mx = S->mean_f[2 * i], my = S->mean_f[2 * i + 1];
+      const float mx = g_mean[2 * i], my = g_mean[2 * i + 1];
       int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
       cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
       const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
-      S->gpts[pos] = make_float4(mx, my, __int_as_float(i), 0.f);
+      g_gpts[pos] = f32x4{mx, my, __int_as_float(i), 0.f};
     }
   } else {
-  for (int g = tid; g <= G; g += nt) S->gstart[g] = 0;
+  for (int g = tid; g <= G; g += nt) g_gstart[g] = 0;
   __syncthreads();
   for (int i = tid; i < nc; i += nt) {
-    int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
     cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
     atomicAdd(&S->gstart[cy * gw + cx + 1], 1);
   }
@@ -665,26 +693,25 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     const int ipt = (G + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
     int cnt = 0;
-    for (int g = i0; g < i1; g++) cnt += S->gstart[g + 1];
+    for (int g = i0; g < i1; g++) cnt += g_gstart[g + 1];
     int tot;
     int o = block_exclusive_scan(cnt, W.red_i, &tot);
-    for (int g = i0; g < i1; g++) { const int c = S->gstart[g + 1]; W.vcur[g] = o; S->gstart[g + 1] = o + c; o += c; }
+    for (int g = i0; g < i1; g++) { const int c = g_gstart[g + 1]; W.vcur[g] = o; g_gstart[g + 1] = o + c; o += c; }
     __syncthreads();
   }
   // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query breaks
   // exact ties by cell index)
   for (int i = tid; i < nc; i += nt) {
-    int cx = (int)floorf((S->mean_f[2 * i] - gx0) / gcell), cy = (int)floorf((S->mean_f[2 * i + 1] - gy0) / gcell);
+    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
     cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
-    S->gpts[pos] = make_float4(S->mean_f[2 * i], S->mean_f[2 * i + 1], __int_as_float(i), 0.f);
+    g_gpts[pos] = f32x4{g_mean[2 * i], g_mean[2 * i + 1], __int_as_float(i), 0.f};
   }
   }
   if (!rows3_done) {  // from the offsets in global memory (final at the barrier before the scatter)
-    uint2* g3 = grid_rows3(S->gstart);
     for (int g = tid; g <= G; g += nt) {
-      const unsigned a = (unsigned)S->gstart[g], b = (unsigned)S->gstart[min(g + gw, G)], c = (unsigned)S->gstart[min(g + 2 * gw, G)];
-      g3[g] = make_uint2((a & 0xFFFFu) | (b << 16), c & 0xFFFFu);
+      const unsigned a = (unsigned)g_gstart[g], b = (unsigned)g_gstart[min(g + gw, G)], c = (unsigned)g_gstart[min(g + 2 * gw, G)];
+      g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
     }
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
