@@ -255,8 +255,9 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
 #pragma unroll
   for (int i = 0; i < 10; i++) v[i] = wave_sum_dpp(v[i]);
   if (lane_id() == 0) {
+    auto* red = CFEAR_LDS_PTR(double, W.red);  // ds_write, not flat stores
 #pragma unroll
-    for (int i = 0; i < 10; i++) W.red[i * CFEAR_RED_STRIDE + wave] = v[i];
+    for (int i = 0; i < 10; i++) red[i * CFEAR_RED_STRIDE + wave] = v[i];
   }
 }
 template <int COST, bool HUBER>
@@ -1006,20 +1007,20 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   }
   for (;;) {
     __syncthreads();  // command visible to every wave
-    const int cmd = sh->cmd;
+    const int cmd = ls->cmd;
     if (cmd == REG_CMD_DONE) break;
     if (cmd == REG_CMD_BUILD) {
       if (pt) pt->mark();
       const int M = build_problem_block(scans, n, ls, ls->itr);
-      if (tid == 0) sh->M = M;
+      if (tid == 0) ls->M = M;
       if (pt) pt->mark();
     } else {
-      evaluate_partial(W, sh->M, sh->lds_match, P, sh->x[0], sh->x[1], sh->c, sh->s);
+      evaluate_partial(W, ls->M, ls->lds_match, P, ls->x[0], ls->x[1], ls->c, ls->s);
     }
     __syncthreads();  // results visible to the controller
     if (master) ctl_step(ls, io, P, W);
   }
-  const int ret = sh->ret;
+  const int ret = ls->ret;
   __syncthreads();
   return ret;
 }
