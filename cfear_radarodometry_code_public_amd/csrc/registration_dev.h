@@ -186,7 +186,7 @@ __device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
 template <bool LDS, int COST, bool HUBER>
-__device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, const RegParams& P, double x0, double x1, double c, double s,
+__device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, double x0, double x1, double c, double s,
                                                    double* res_out, int res_cap) {
   const int wave = threadIdx.x >> 6;
   if (wave >= CFEAR_EVAL_WAVES) return;
@@ -196,7 +196,8 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     lds_cdouble* l; const double* g; size_t cap;
     __device__ __forceinline__ double operator()(int arr, int i) const { return LDS ? l[arr * CFEAR_MATCH_LDS_CAP + i] : g[arr * cap + i]; }
   } rd;
-  rd.l = (lds_cdouble*)lds_match_base(); rd.g = W.tmx; rd.cap = (size_t)W.cap;
+  rd.l = (lds_cdouble*)lds_match_base(); rd.g = ls->rw.tmx; rd.cap = (size_t)ls->rw.cap;
+  const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
   const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < M; i += nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
@@ -231,11 +232,11 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
     Rho rho;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
     if (HUBER) {  // the default loss inline: a function with a call inside saves and restores a register through scratch, a
                   // round trip to memory at its exit, whichever path is taken (the other losses are out of line)
-      const double la = P.loss_limit, lb = la * la;
+      const double la = loss_limit, lb = la * la;
       if (sq > lb) { const double r = sqrt(sq); rho.v = 2.0 * la * r - lb; rho.d1 = fmax(CFEAR_DBL_MIN, la / r); }
       else { rho.v = sq; rho.d1 = 1.0; }
     } else {
-      rho = loss_eval(P.loss, P.loss_limit, sq);
+      rho = loss_eval(ls->rp.loss, loss_limit, sq);
     }
     a.cost += 0.5 * (rho.v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
     const double sr = sqrt(rho.d1 * wgt);
@@ -255,27 +256,28 @@ __device__ __forceinline__ void evaluate_partial_t(const RegScratch& W, int M, c
 #pragma unroll
   for (int i = 0; i < 10; i++) v[i] = wave_sum_dpp(v[i]);
   if (lane_id() == 0) {
-    auto* red = CFEAR_LDS_PTR(double, W.red);  // ds_write, not flat stores
+    auto* red = CFEAR_LDS_PTR(double, ls->rw.red);  // ds_write, not flat stores
 #pragma unroll
     for (int i = 0; i < 10; i++) red[i * CFEAR_RED_STRIDE + wave] = v[i];
   }
 }
 template <int COST, bool HUBER>
-__device__ __noinline__ void evaluate_partial_c(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
+__device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                 double* res_out, int res_cap) {
-  if (lds_match) evaluate_partial_t<true, COST, HUBER>(W, M, P, x0, x1, c, s, res_out, res_cap);
-  else evaluate_partial_t<false, COST, HUBER>(W, M, P, x0, x1, c, s, res_out, res_cap);
+  if (lds_match) evaluate_partial_t<true, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_t<false, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
 }
-__device__ __forceinline__ void evaluate_partial(const RegScratch& W, int M, int lds_match, const RegParams& P, double x0, double x1, double c, double s,
+__device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                  double* res_out = nullptr, int res_cap = 0) {
-  if (P.loss == CFEAR_LOSS_HUBER) {
-    if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-    else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-    else evaluate_partial_c<CFEAR_COST_P2P, true>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+  const int cost = ls->rp.cost;
+  if (ls->rp.loss == CFEAR_LOSS_HUBER) {
+    if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    else evaluate_partial_c<CFEAR_COST_P2P, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
   } else {
-    if (P.cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-    else if (P.cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
-    else evaluate_partial_c<CFEAR_COST_P2P, false>(W, M, lds_match, P, x0, x1, c, s, res_out, res_cap);
+    if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    else evaluate_partial_c<CFEAR_COST_P2P, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
   }
 }
 
@@ -1015,7 +1017,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       if (tid == 0) ls->M = M;
       if (pt) pt->mark();
     } else {
-      evaluate_partial(W, ls->M, ls->lds_match, P, ls->x[0], ls->x[1], ls->c, ls->s);
+      evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
     }
     __syncthreads();  // results visible to the controller
     if (master) ctl_step(ls, io, P, W);
@@ -1061,7 +1063,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
   }
   double sn, cs;
   sincos(sh->xcur[2], &sn, &cs);
-  evaluate_partial(W, M, sh->lds_match, P, sh->xcur[0], sh->xcur[1], cs, sn, residuals, cap);
+  evaluate_partial(ls, M, ls->lds_match, ls->xcur[0], ls->xcur[1], cs, sn, residuals, cap);
   __syncthreads();
   if (tid == 0) {
     gather_partials(W, &ls->G);
