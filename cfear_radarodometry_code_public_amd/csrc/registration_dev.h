@@ -555,7 +555,7 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 // flat stores through the address unit). Same arithmetic as write_match.
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
-  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
+  const int cost = sh->rp.cost, weight_opt = sh->rp.weight_opt;  // through the LDS-typed pointer
   const RCell cs = rcell_src(src, j);
   typedef __attribute__((address_space(3))) double lds_double;
 #pragma unroll 1
@@ -579,18 +579,18 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
       const double nx = T[0] * cs.nx + T[1] * cs.ny;
       const double ny = T[2] * cs.nx + T[3] * cs.ny;
       const double sim = fmax(nx * r1.x + ny * r1.y, 0.0);
-      put(7, get_weight(P.weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y));
+      put(7, get_weight(weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y));
     }
-    if (P.cost == CFEAR_COST_P2D) {  // :290-299
+    if (cost == CFEAR_COST_P2D) {  // :290-299
       const cfear_cell* ctf = &scans[i]->cells[ti];
       const double ca = ctf->cov[0], cb = ctf->cov[1], cc = ctf->cov[2];
       const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
       const double m00 = r00 * ca + r01 * cb, m01 = r00 * cb + r01 * cc;
       const double m10 = r10 * ca + r11 * cb, m11 = r10 * cb + r11 * cc;
-      const double c00 = (P.regularization + (m00 * r00 + m01 * r01)) * P.covar_scale;
-      const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * P.covar_scale;
-      const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * P.covar_scale;
-      const double c11 = (P.regularization + (m10 * r10 + m11 * r11)) * P.covar_scale;
+      const double c00 = (sh->rp.regularization + (m00 * r00 + m01 * r01)) * sh->rp.covar_scale;
+      const double c10 = (0.0 + (m10 * r00 + m11 * r01)) * sh->rp.covar_scale;
+      const double c01 = (0.0 + (m00 * r10 + m01 * r11)) * sh->rp.covar_scale;
+      const double c11 = (sh->rp.regularization + (m10 * r10 + m11 * r11)) * sh->rp.covar_scale;
       const double det = c00 * c11 - c01 * c10, id = 1.0 / det;
       const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
       const double l00 = sqrt(i00), l10 = i10 / l00;
@@ -642,8 +642,6 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
 }
 
 __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, LRegShared* sh, int itr) {
-  const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);  // in LDS: addresses derived from sh, nothing to keep alive across the calls below
-  const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
@@ -651,7 +649,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   int M;
   bool use_lds;
   const int nk = n - 1;
-  const bool can_park = 4 * (long long)nsrc <= (long long)W.cap && (reinterpret_cast<uintptr_t>(W.assoc) & 15) == 0;
+  const bool can_park = 4 * (long long)nsrc <= (long long)sh->rw.cap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
   if (nk <= 4 && (nsrc <= nt || (nsrc <= 4 * nt && can_park))) {
     const Assoc4 none = {-1, -1, -1, -1};
     if (nsrc <= nt) {  // one block of cells: its matches stay in registers
@@ -671,19 +669,19 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
     }
   } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
-    const double curr_radius = (itr == 1) ? 2 * P.assoc_radius : P.assoc_radius;  // :222
+    const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
     const int ipt = (pairs + nt - 1) / nt;
     const int p0 = tid * ipt, p1 = min(pairs, p0 + ipt);
     int cnt = 0;
     for (int p = p0; p < p1; p++) {
       const int ti = associate_pair(src, sh, nsrc, p, curr_radius);
-      W.assoc[p] = ti;
+      sh->rw.assoc[p] = ti;
       cnt += (ti >= 0) ? 1 : 0;
     }
-    int o = block_exclusive_scan(cnt, W.red_i, &M);
+    int o = block_exclusive_scan(cnt, sh->rw.red_i, &M);
     use_lds = M <= CFEAR_MATCH_LDS_CAP;
     for (int p = p0; p < p1; p++) {
-      const int ti = W.assoc[p];
+      const int ti = sh->rw.assoc[p];
       if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, use_lds);
     }
   }
