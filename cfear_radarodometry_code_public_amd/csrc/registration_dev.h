@@ -283,9 +283,9 @@ __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, in
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
 // generic pointer every partial sum was a flat load the running sum had to wait for (2.8 us per evaluation).
-__device__ __forceinline__ void gather_partials(const RegScratch& W, LNormalEq* out) {
+__device__ __forceinline__ void gather_partials(const double* red_lds, LNormalEq* out) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
-  lds_cdouble* red = (lds_cdouble*)W.red;
+  lds_cdouble* red = (lds_cdouble*)red_lds;
   const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
   double r[10];
 #pragma unroll
@@ -704,7 +704,8 @@ __device__ __forceinline__ void ctl_publish_eval(LRegShared* sh, double x0, doub
 __device__ __noinline__ void ctl_publish_candidate(LRegShared* sh) { ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND); }
 
 // transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
-__device__ __noinline__ void ctl_publish_build(LRegShared* sh, const RegIo& io) {
+__device__ __noinline__ void ctl_publish_build(LRegShared* sh) {
+  const auto& io = sh->rio;  // fields read through the LDS-typed pointer
   const int n = io.n, L = 3 * (n - 1);
   const Aff2 Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
   for (int i = lane_id(); i < n - 1; i += 64) {
@@ -719,8 +720,9 @@ __device__ __noinline__ void ctl_publish_build(LRegShared* sh, const RegIo& io) 
   sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
 }
 
-__device__ __noinline__ void ctl_finish(LRegShared* sh, const RegIo& io, const RegParams& P, bool have_cov, const LNormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
+__device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
   const NormalEq E = neq_load(Ep);
+  const auto& io = sh->rio;
   const int n = io.n, L = 3 * (n - 1);
   int ret = 0;
   if (lane_id() == 0) {
@@ -763,7 +765,9 @@ __device__ __noinline__ void ctl_finish(LRegShared* sh, const RegIo& io, const R
 enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND };
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
-__device__ __noinline__ int ctl_lm_done(LRegShared* sh, const RegIo& io, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
+  const auto& io = sh->rio;
+  const auto& P = sh->rp;
   const int itr = sh->itr;
   sh->success = (sh->ss.termination != 2);
   if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
@@ -794,7 +798,8 @@ __device__ __noinline__ int ctl_lm_done(LRegShared* sh, const RegIo& io, const R
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
-__device__ __noinline__ int ctl_lm_next(LRegShared* sh, const RegParams& P) {
+__device__ __noinline__ int ctl_lm_next(LRegShared* sh) {
+  const auto& P = sh->rp;
   const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
   for (;;) {
     if (sh->iteration >= P.max_inner) { sh->ss.termination = 1; return CTL_LM_DONE; }
@@ -860,7 +865,8 @@ __device__ __forceinline__ NormalEq add_prior(const LRegShared* sh, NormalEq E, 
 
 // ---- one function per controller state (kept out of line: the kernel's register budget is the maximum
 // over its callees, and it decides how many workgroups share a compute unit) ----
-__device__ __noinline__ int ctl_after_build(LRegShared* sh, const RegParams& P) {
+__device__ __noinline__ int ctl_after_build(LRegShared* sh) {
+  const auto& P = sh->rp;
   const int rpb = (P.cost == CFEAR_COST_P2L) ? 1 : 2;
   sh->nres = sh->M * rpb;
   if (sh->nres <= 1) {  // :370-371 -> :114-115
@@ -872,9 +878,9 @@ __device__ __noinline__ int ctl_after_build(LRegShared* sh, const RegParams& P) 
   return CTL_WAIT;
 }
 
-__device__ __noinline__ int ctl_after_it0(LRegShared* sh, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_it0(LRegShared* sh) {
   const double gradient_tolerance = 1e-10;
-  gather_partials(W, &sh->G);
+  gather_partials(sh->rw.red, &sh->G);
   NormalEq E = neq_load(&sh->G);
   if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   neq_store(&sh->E, E); sh->x_cost = E.cost;
@@ -888,10 +894,11 @@ __device__ __noinline__ int ctl_after_it0(LRegShared* sh, const RegScratch& W) {
   return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ int ctl_after_candidate(LRegShared* sh, const RegParams& P, const RegScratch& W) {
+__device__ __noinline__ int ctl_after_candidate(LRegShared* sh) {
+  const auto& P = sh->rp;
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
-  gather_partials(W, &sh->G);
+  gather_partials(sh->rw.red, &sh->G);
   NormalEq C = neq_load(&sh->G);
   if (sh->prior_on) C = add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
   const double cand_cost = C.cost;
@@ -922,30 +929,30 @@ __device__ __noinline__ int ctl_after_candidate(LRegShared* sh, const RegParams&
   return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ int ctl_after_cov(LRegShared* sh, const RegScratch& W) {
-  gather_partials(W, &sh->G);
+__device__ __noinline__ int ctl_after_cov(LRegShared* sh) {
+  gather_partials(sh->rw.red, &sh->G);
   if (sh->prior_on) neq_store(&sh->G, add_prior(sh, neq_load(&sh->G), sh->x[0], sh->x[1], sh->x[2]));
   return CTL_FINISH_G;
 }
 
 // consumes the result of the command just executed and publishes the next one
-__device__ __forceinline__ void ctl_step(LRegShared* sh, const RegIo& io, const RegParams& P, const RegScratch& W) {
+__device__ __forceinline__ void ctl_step(LRegShared* sh) {
   int nx;
   switch (sh->state) {
-    case REG_ST_BUILD: nx = ctl_after_build(sh, P); break;
-    case REG_ST_LM_IT0: nx = ctl_after_it0(sh, W); break;
-    case REG_ST_LM_CAND: nx = ctl_after_candidate(sh, P, W); break;
-    default: nx = ctl_after_cov(sh, W); break;
+    case REG_ST_BUILD: nx = ctl_after_build(sh); break;
+    case REG_ST_LM_IT0: nx = ctl_after_it0(sh); break;
+    case REG_ST_LM_CAND: nx = ctl_after_candidate(sh); break;
+    default: nx = ctl_after_cov(sh); break;
   }
   while (nx != CTL_WAIT) {
     switch (nx) {
-      case CTL_LM_NEXT: nx = ctl_lm_next(sh, P); break;
-      case CTL_LM_DONE: nx = ctl_lm_done(sh, io, P); break;
-      case CTL_BUILD: ctl_publish_build(sh, io); nx = CTL_WAIT; break;
+      case CTL_LM_NEXT: nx = ctl_lm_next(sh); break;
+      case CTL_LM_DONE: nx = ctl_lm_done(sh); break;
+      case CTL_BUILD: ctl_publish_build(sh); nx = CTL_WAIT; break;
       case CTL_EVAL_CAND: ctl_publish_candidate(sh); nx = CTL_WAIT; break;
-      case CTL_FINISH_E: ctl_finish(sh, io, P, true, &sh->E); nx = CTL_WAIT; break;
-      case CTL_FINISH_G: ctl_finish(sh, io, P, true, &sh->G); nx = CTL_WAIT; break;
-      default: ctl_finish(sh, io, P, false, &sh->E); nx = CTL_WAIT; break;
+      case CTL_FINISH_E: ctl_finish(sh, true, &sh->E); nx = CTL_WAIT; break;
+      case CTL_FINISH_G: ctl_finish(sh, true, &sh->G); nx = CTL_WAIT; break;
+      default: ctl_finish(sh, false, &sh->E); nx = CTL_WAIT; break;
     }
   }
 }
@@ -1003,7 +1010,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     sh->prev_score = 1.7976931348623157e308;
     sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1;
     sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
-    ctl_publish_build(ls, io);
+    ctl_publish_build(ls);
   }
   for (;;) {
     __syncthreads();  // command visible to every wave
@@ -1018,7 +1025,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
     }
     __syncthreads();  // results visible to the controller
-    if (master) ctl_step(ls, io, P, W);
+    if (master) ctl_step(ls);
   }
   const int ret = ls->ret;
   __syncthreads();
@@ -1050,7 +1057,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
     sh->prior_on = 0;
-    ctl_publish_build(ls, sh->rio);
+    ctl_publish_build(ls);
   }
   __syncthreads();
   const int M = build_problem_block(scans, n, ls, itr);
@@ -1064,7 +1071,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
   evaluate_partial(ls, M, ls->lds_match, ls->xcur[0], ls->xcur[1], cs, sn, residuals, cap);
   __syncthreads();
   if (tid == 0) {
-    gather_partials(W, &ls->G);
+    gather_partials(ls->rw.red, &ls->G);
     *score = ls->G.cost; *n_res = nres;
   }
 }
