@@ -24,6 +24,7 @@ namespace {
 
 constexpr int BLOCK_F = 1024;  // features / cloud kernels
 constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
+static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
 constexpr int MAX_SCANS = 64;  // keyframes + current
 constexpr int LDS_P2 = 8192;   // sort keys held in LDS (clouds up to CFEAR_LDS_POINT_CAP points)
 

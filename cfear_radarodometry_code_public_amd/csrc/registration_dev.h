@@ -286,7 +286,7 @@ __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, in
 __device__ __forceinline__ void gather_partials(const double* red_lds, LNormalEq* out) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   lds_cdouble* red = (lds_cdouble*)red_lds;
-  const int nw = min((int)((blockDim.x + 63) >> 6), CFEAR_EVAL_WAVES);
+  // every registration kernel runs CFEAR_EVAL_WAVES or more waves (static_assert next to BLOCK_R): all slots hold sums
   double r[10];
 #pragma unroll
   for (int h = 0; h < 10; h += 5) {  // five quantities at a time: 20 loads in flight, 40 VGPRs
@@ -299,7 +299,7 @@ __device__ __forceinline__ void gather_partials(const double* red_lds, LNormalEq
     for (int i = 0; i < 5; i++) {
       double t = 0;
 #pragma unroll
-      for (int j = 0; j < CFEAR_EVAL_WAVES; j++) t += (j < nw) ? p[i][j] : 0.0;
+      for (int j = 0; j < CFEAR_EVAL_WAVES; j++) t += p[i][j];
       r[h + i] = t;
     }
     __builtin_amdgcn_sched_barrier(0);
