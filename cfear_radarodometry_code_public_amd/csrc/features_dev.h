@@ -138,6 +138,17 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
 //   sin/cos(arg) around arg_b = d_b * m2 to second order in (arg - arg_b) ~ 1e-9
 // which agrees with evaluating the reference's expressions to within f64 rounding (the test tolerance on
 // compensated points stays one float ulp, as for any two libm implementations).
+// Compensate (utils.cpp:96-107) of one point as written: atan2, sweep fraction, rotation by the scaled motion
+__device__ __noinline__ float2 compensate_point_plain(float x, float y, double m0, double m1, double m2, int ccw) {
+  const double px = (double)x, py = (double)y;
+  const double a = atan2(py, px);
+  const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+  const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+  double s1, c1;
+  sincos(d * m2, &s1, &c1);
+  return make_float2((float)((c1 * px + (-s1) * py) + d * m0), (float)((s1 * px + c1 * py) + d * m1));
+}
+
 __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
                                        float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
                                        double m0, double m1, double m2, int ccw, int* red_i, float* red_f, double* tab,
@@ -153,48 +164,58 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   const int items = A * k;
   const int ipt = (items + blockDim.x - 1) / blockDim.x;
   const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
-  const bool expand = compensate && A <= tab_bearings;  // block-uniform; more bearings than the table holds: plain formulas
-  if (expand) {
+  // per-bearing table in LDS, six doubles each: principal angle, sin / cos of the compensation rotation at the bearing's
+  // angle, its sweep fraction, cos / sin of the bearing (so that the per-point loop has no global load to wait for)
+  auto* ltab = CFEAR_LDS_PTR(double, tab);
+  const bool tabbed = A <= tab_bearings;       // block-uniform; more bearings than the table holds: plain formulas
+  const bool expand = compensate && tabbed;
+  if (tabbed) {
     for (int b = threadIdx.x; b < A; b += blockDim.x) {
-      const double theta = ((double)(b + 1) / A) * CFEAR_TWO_PI;                   // radar_filters.cpp:317
-      const double a = theta > 3.14159265358979323846 ? theta - CFEAR_TWO_PI : theta;  // principal value, as atan2 returns it
-      const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);   // utils.h:28-32
-      const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-      double sb, cb;
-      sincos(d * m2, &sb, &cb);
-      tab[4 * b] = a; tab[4 * b + 1] = sb; tab[4 * b + 2] = cb; tab[4 * b + 3] = d;
+      ltab[6 * b + 4] = g_trig[2 * b]; ltab[6 * b + 5] = g_trig[2 * b + 1];
+      if (compensate) {
+        const double theta = ((double)(b + 1) / A) * CFEAR_TWO_PI;                   // radar_filters.cpp:317
+        const double a = theta > 3.14159265358979323846 ? theta - CFEAR_TWO_PI : theta;  // principal value, as atan2 returns it
+        const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);   // utils.h:28-32
+        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+        double sb, cb;
+        sincos(d * m2, &sb, &cb);
+        ltab[6 * b] = a; ltab[6 * b + 1] = sb; ltab[6 * b + 2] = cb; ltab[6 * b + 3] = d;
+      }
     }
   }
+  // the thread's slots in registers (one batch of loads) when there are few of them, as in every reference configuration
+  constexpr int SV = 8;
+  const bool few = ipt <= SV;  // block-uniform
+  uint32_t sv[SV];
+#pragma unroll
+  for (int u = 0; u < SV; u++) sv[u] = (few && i0 + u < i1) ? g_slots[i0 + u] : 0u;
   int cnt = 0;
-  for (int i = i0; i < i1; i++) {
-    const uint32_t s = g_slots[i];
-    cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
+  if (few) {
+#pragma unroll
+    for (int u = 0; u < SV; u++) cnt += (i0 + u < i1 && CFEAR_SLOT_VALID(sv[u]) && CFEAR_SLOT_RANGE(sv[u]) > min_range_bin) ? 1 : 0;  // :327
+  } else {
+    for (int i = i0; i < i1; i++) {
+      const uint32_t s = g_slots[i];
+      cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
+    }
   }
   int total;
-  int o = block_exclusive_scan(cnt, red_i, &total);  // (its barriers also publish tab)
+  int o = block_exclusive_scan(cnt, red_i, &total);  // (its barriers also publish the table)
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
   int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
-  for (int i = i0; i < i1; i++, jb++) {
-    if (jb == k) { jb = 0; b++; }
-    const uint32_t s = g_slots[i];
+  auto point = [&](uint32_t s) {
     const int range = CFEAR_SLOT_RANGE(s);
     if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
-      const double cb = g_trig[2 * b], sb = g_trig[2 * b + 1];
+      const double cb = tabbed ? ltab[6 * b + 4] : g_trig[2 * b], sb = tabbed ? ltab[6 * b + 5] : g_trig[2 * b + 1];
       const double rad = range_res_half + range_res * range;
       float x = (float)(rad * cb);  // :329
       float y = (float)(rad * sb);  // :330
-      if (compensate && !expand) {  // utils.cpp:96-107 as written
-        const double px = (double)x, py = (double)y;
-        const double a = atan2(py, px);
-        const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
-        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-        double s1, c1;
-        sincos(d * m2, &s1, &c1);
-        x = (float)((c1 * px + (-s1) * py) + d * m0);
-        y = (float)((s1 * px + c1 * py) + d * m1);
+      if (compensate && !expand) {  // utils.cpp:96-107 as written (out of line: atan2 + sincos would cost the common path registers)
+        const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
+        x = p.x; y = p.y;
       } else if (compensate) {
         const double px = (double)x, py = (double)y;
-        const double ab = tab[4 * b], s_b = tab[4 * b + 1], c_b = tab[4 * b + 2], d_b = tab[4 * b + 3];
+        const double ab = ltab[6 * b], s_b = ltab[6 * b + 1], c_b = ltab[6 * b + 2], d_b = ltab[6 * b + 3];
         const double a = ab + (py * cb - px * sb) / (px * cb + py * sb);
         const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
         const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
@@ -206,6 +227,21 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       o++;
+    }
+  };
+  if (few) {
+#pragma unroll 1
+    for (int u = 0; u < ipt && i0 + u < i1; u++, jb++) {  // one copy of the per-point arithmetic; the slot comes out of its register by selects
+      if (jb == k) { jb = 0; b++; }
+      uint32_t s = sv[0];
+#pragma unroll
+      for (int w = 1; w < SV; w++) s = (u == w) ? sv[w] : s;
+      point(s);
+    }
+  } else {
+    for (int i = i0; i < i1; i++, jb++) {
+      if (jb == k) { jb = 0; b++; }
+      point(g_slots[i]);
     }
   }
   bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;

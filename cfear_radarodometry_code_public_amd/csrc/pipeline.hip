@@ -224,8 +224,8 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
                                  reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f),
-                                 reinterpret_cast<double*>(lds + FeatLds::order),  // 4 doubles per bearing in the (still unused) order array
-                                 (int)(CFEAR_LDS_POINT_CAP * sizeof(int) / (4 * sizeof(double))), bounds);
+                                 reinterpret_cast<double*>(lds + FeatLds::order),  // 6 doubles per bearing in the (still unused) order array
+                                 (int)(CFEAR_LDS_POINT_CAP * sizeof(int) / (6 * sizeof(double))), bounds);
   if (TIMED) { pt.mark(); pt.mark(); }
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true);  // :161
 }
