@@ -984,8 +984,9 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   if (tid == 0 && out) {
     out->success = 0; out->usable = 0; out->outer_iterations = 0; out->num_residuals = 0; out->num_residual_blocks = 0;
     out->reserved = 0; out->final_cost = 0; out->score = 0;
-    for (int i = 0; i < CFEAR_MAX_OUTER; i++) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
   }
+  if (out)  // one thread per outer iteration (448 stores by a single thread were a measurable part of the start-up)
+    for (int i = tid; i < CFEAR_MAX_OUTER; i += blockDim.x) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
   __syncthreads();
   if (master) {
     const int L = 3 * (n - 1);
@@ -1013,6 +1014,8 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     ctl_publish_build(ls);
   }
   for (;;) {
+    long long t0c = 0;
+    if (pt && pt->acc && tid == 0) t0c = (long long)wall_clock64();
     __syncthreads();  // command visible to every wave
     const int cmd = ls->cmd;
     if (cmd == REG_CMD_DONE) break;
@@ -1024,8 +1027,14 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     } else {
       evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
     }
+    long long t1 = 0;
+    if (pt && pt->acc && tid == 0) t1 = (long long)wall_clock64();
     __syncthreads();  // results visible to the controller
     if (master) ctl_step(ls);
+    if (pt && pt->acc && tid == 0 && cmd != REG_CMD_BUILD) {  // tools: time in evaluations (incl. the barrier before) and in the controller
+      const long long t2 = (long long)wall_clock64();
+      pt->acc[0] += t1 - t0c; pt->acc[1] += t2 - t1; pt->acc[2] += 1;
+    }
   }
   const int ret = ls->ret;
   __syncthreads();

@@ -26,12 +26,16 @@ for t in range(frames):
         n = (ts > 0).sum(1)
         q = int(np.argmax(n))
         S, nc, nk = odo.summary(q)
-        row = ts[q][:n[q]]
-        d_us = np.diff(row) / 100.0
-        names = ["cloud", "compensate", "minmax+keys", "sort", "segments", "centroids", "cells-ranges", "cells-chunks", "cells-acc", "cells-epi", "compact", "grid"]
-        print("   nv(voxels) =", odo_nv if False else "")
-        print("frame %d seq %d: cells %d kf %d outer %d inner %s total %.1f us" % (t, q, nc, nk, S.outer_iterations, list(S.inner_iterations[:8]), (row[-1] - row[0]) / 100.0))
-        print("   " + "  ".join("%s %.1f" % (names[i] if i < len(names) else "r%d" % (i - len(names)), d_us[i]) for i in range(len(d_us))))
+        feat = ts[q][:14]; feat = feat[feat > 0]      # features kernel: slots 0..13
+        reg = ts[q][14:29]; reg = reg[reg > 0]         # registration kernel: slots 14..28
+        fn = ["cloud", "compensate", "minmax+keys", "sort", "segments", "centroids", "cells-ranges", "cells-chunks", "cells-acc", "cells-epi", "compact", "grid"]
+        rn = ["setup"] + [s + str(k) for k in range(1, 9) for s in ("build", "LM")]
+        print("frame %d seq %d: cells %d kf %d outer %d inner %s  features %.1f us  registration %.1f us" %
+              (t, q, nc, nk, S.outer_iterations, list(S.inner_iterations[:8]), (feat[-1] - feat[0]) / 100.0, (reg[-1] - reg[0]) / 100.0 if len(reg) > 1 else 0.0))
+        print("   features:     " + "  ".join("%s %.1f" % (fn[i] if i < len(fn) else "f%d" % i, d) for i, d in enumerate(np.diff(feat) / 100.0)))
+        print("   registration: " + "  ".join("%s %.1f" % (rn[i] if i < len(rn) else "r%d" % i, d) for i, d in enumerate(np.diff(reg) / 100.0)))
         print("   LM: evals %d  eval %.2f us each  controller %.2f us each" % (acc[q][2], acc[q][0] / 100.0 / max(acc[q][2], 1), acc[q][1] / 100.0 / max(acc[q][2], 1)))
-        allt = np.array([(ts[b][:n[b]][-1] - ts[b][0]) / 100.0 for b in range(B) if n[b] > 1])
-        print("   per-block total us: min %.1f med %.1f max %.1f" % (allt.min(), np.median(allt), allt.max()))
+        tf = np.array([(r[:14][r[:14] > 0][-1] - r[0]) / 100.0 for r in ts if (r[:14] > 0).sum() > 1])
+        tr = np.array([(r[14:29][r[14:29] > 0][-1] - r[14]) / 100.0 for r in ts if (r[14:29] > 0).sum() > 1])
+        print("   per workgroup, us: features min %.1f med %.1f max %.1f   registration min %.1f med %.1f max %.1f" %
+              (tf.min(), np.median(tf), tf.max(), tr.min(), np.median(tr), tr.max()))
