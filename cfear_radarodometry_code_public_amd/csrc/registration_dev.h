@@ -723,32 +723,39 @@ __device__ __noinline__ void ctl_publish_build(LRegShared* sh) {
 __device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNormalEq* Ep /* sh->E or sh->G; unused without have_cov */) {
   const NormalEq E = neq_load(Ep);
   const auto& io = sh->rio;
-  const int n = io.n, L = 3 * (n - 1);
+  const int n = io.n, L = 3 * (n - 1), lane = lane_id();
   int ret = 0;
-  if (lane_id() == 0) {
-    if (sh->success) {
-      for (int i = 0; i < n - 1; i++) { io.poses[3 * i] = io.par[3 * i]; io.poses[3 * i + 1] = io.par[3 * i + 1]; io.poses[3 * i + 2] = io.par[3 * i + 2]; }
-      io.poses[L] = sh->xcur[0]; io.poses[L + 1] = sh->xcur[1]; io.poses[L + 2] = sh->xcur[2];
-      // GetCovariance (:392-433): (J~^T J~)^-1 of the last built problem at the final parameters
-      const double a = E.h00, b = E.h01, c = E.h02, d = E.h11, e = E.h12, f = E.h22;
-      const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
-      const double det = a * C00 + b * C01 + c * C02;
-      const int dof = sh->nres - 3;
-      const bool ok = have_cov && det > 0 && isfinite(det) && dof != 0;
-      ret = ok ? 1 : 0;
-      if (io.cov6) {
-        for (int i = 0; i < 36; i++) io.cov6[i] = 0;
-        io.cov6[0] = 0.1 * 0.1; io.cov6[7] = 0.1 * 0.1; io.cov6[35] = 0.01 * 0.01;  // :173
-        if (ok) {
-          const double sc = 30 * (sh->ss.final_cost / dof) / det;
-          for (int i = 0; i < 36; i++) io.cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-          io.cov6[0] = sc * C00; io.cov6[1] = sc * C01; io.cov6[6] = sc * C01; io.cov6[7] = sc * (a * f - c * c);
-          io.cov6[35] = sc * (a * d - b * b); io.cov6[5] = sc * C02; io.cov6[30] = sc * C02;  // (1,5)/(5,1) stay 0 (:426-430)
-        }
+  // every lane of the controller wave computes the same values; the stores are spread over the lanes
+  if (sh->success) {
+    for (int i = lane; i < L; i += 64) io.poses[i] = io.par[i];
+    if (lane < 3) io.poses[L + lane] = sh->xcur[lane];
+    // GetCovariance (:392-433): (J~^T J~)^-1 of the last built problem at the final parameters
+    const double a = E.h00, b = E.h01, c = E.h02, d = E.h11, e = E.h12, f = E.h22;
+    const double C00 = d * f - e * e, C01 = c * e - b * f, C02 = b * e - c * d;
+    const double det = a * C00 + b * C01 + c * C02;
+    const int dof = sh->nres - 3;
+    const bool ok = have_cov && det > 0 && isfinite(det) && dof != 0;
+    ret = ok ? 1 : 0;
+    if (io.cov6 && lane < 36) {
+      double v = 0;  // entry `lane` of the 6 x 6 matrix
+      if (ok) {
+        const double sc = 30 * (sh->ss.final_cost / dof) / det;
+        v = (lane % 7 == 0) ? 1.0 : 0.0;
+        if (lane == 0) v = sc * C00;
+        if (lane == 1 || lane == 6) v = sc * C01;
+        if (lane == 7) v = sc * (a * f - c * c);
+        if (lane == 35) v = sc * (a * d - b * b);
+        if (lane == 5 || lane == 30) v = sc * C02;  // (1,5)/(5,1) stay 0 (:426-430)
+      } else {
+        if (lane == 0 || lane == 7) v = 0.1 * 0.1;  // :173
+        if (lane == 35) v = 0.01 * 0.01;
       }
-    } else {
-      io.poses[L] = sh->tsrc_last[0]; io.poses[L + 1] = sh->tsrc_last[1]; io.poses[L + 2] = sh->tsrc_last[2];
+      io.cov6[lane] = v;
     }
+  } else if (lane < 3) {
+    io.poses[L + lane] = sh->tsrc_last[lane];
+  }
+  if (lane == 0) {
     if (io.out) {
       io.out->success = ret; io.out->usable = sh->success ? 1 : 0; io.out->outer_iterations = sh->itr;
       io.out->num_residuals = sh->nres; io.out->num_residual_blocks = sh->M; io.out->final_cost = sh->ss.final_cost;
