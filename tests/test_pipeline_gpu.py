@@ -362,3 +362,27 @@ def test_register_many_cells(oracle, cost, res, rev):
         assert np.allclose(Sg.final_cost, So.final_cost, rtol=1e-9)
         assert np.linalg.norm(Pg[-1, :2] - gt[-1, :2]) < 0.1  # known answer
     ctx.close()
+
+
+def test_profile_hooks_time_every_stage(oracle):
+    """cfear_odometry_profile / _profile_read / _profile_read_stages (the HIP-event timing bench.py's roofline leg reads):
+    one filter launch and one features + registration pair per profiled step, positive durations, results untouched."""
+    imgs, _ = synth.world_sequence(5, seed=21)
+    pg = mk_params(capi)
+    ctx = capi.Context(pg, 400, 3360)
+    odo, ref = ctx.odometry(2), ctx.odometry(2)
+    batch = lambda t: np.stack([imgs[t], imgs[t]])
+    odo.step_host(batch(0)); ref.step_host(batch(0))
+    odo.profile(True)
+    for t in range(1, 5):
+        odo.step_host(batch(t)); ref.step_host(batch(t))
+    tf, nf = odo.profile_read()
+    tfeat, treg, ns = odo.profile_read_stages()
+    assert nf == 4 and ns == 4
+    assert 0 < tf < 1.0 and 0 < tfeat < 1.0 and 0 < treg < 1.0
+    assert np.array_equal(odo.poses(), ref.poses())
+    odo.profile(False)
+    odo.step_host(batch(4))
+    assert odo.profile_read()[1] == 0 and odo.profile_read_stages()[2] == 0
+    odo.release(); ref.release()
+    ctx.close()
