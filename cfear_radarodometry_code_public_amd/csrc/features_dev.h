@@ -341,6 +341,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
   const long long Gll = (long long)div0 * (long long)div1;
+  int nv_out = 0;
   if (W.lds && Gll <= (long long)W.tab_voxels && n <= 8 * nt) {
     // ---- LDS counting sort over the dense voxel grid: 16-bit counters packed two per word in the (not yet
     // used) key region; the atomic scatter is unordered, ranking by point index inside each voxel restores the point order,
@@ -380,6 +381,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         const int s1 = o; o += c1;
         tab[g >> 1] = (uint32_t)s0 | ((uint32_t)s1 << 16);  // counters become start offsets (scatter cursors)
       }
+      nv_out = nvv;
       if (tid == 0) { W.vstart[nvv] = n; S->n_samples = nvv; S->n_points = n; S->status = 0; }
       __syncthreads();
     }
@@ -436,11 +438,12 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       W.order[i] = (int)(uint32_t)k;
       if (i == 0 || (k >> 32) != (W.keys[i - 1] >> 32)) { W.vstart[o] = i; W.vlist[o] = (int)(k >> 32); o++; }
     }
+    nv_out = nv;
     if (tid == 0) { W.vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
   }
   }
-  const int nv = S->n_samples;
+  const int nv = nv_out;  // known to every thread: no read-back of S->n_samples through memory
   // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)
   for (int q = tid; q < n; q += nt) {
     const int pi = W.order[q];
@@ -577,6 +580,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   if (pt) pt->mark();
   // ---- cell epilogue + compaction: a cell is built in registers and, if it is valid, written straight to
   // its final slot; one block scan per round of blockDim samples keeps the sample order (pointnormal.cpp:292-294)
+  int n_cells_out;  // every thread knows it (sum of the block scans): no read-back of S->n_cells through memory
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
@@ -639,13 +643,14 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
       base += round_total;
     }
-    if (tid == 0) S->n_cells = base < cap_cells ? base : cap_cells;
+    n_cells_out = base < cap_cells ? base : cap_cells;
+    if (tid == 0) S->n_cells = n_cells_out;
     __syncthreads();
   }
   if (pt) pt->mark();
   if (pt) pt->mark();
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
-  const int nc = S->n_cells;
+  const int nc = n_cells_out;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   g_f32* const g_mean = (g_f32*)S->mean_f;
