@@ -83,6 +83,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one explicit stream for torch and for the library: the default stream's handle is 0, which cfear_create reads as
+    # "create a stream of your own" -- not ordered with what torch queues on its default stream
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     from cfear_radarodometry_code_public_amd import build, capi
     build.build()
@@ -127,7 +130,7 @@ def main():
     odo = ctx.odometry(B)
 
     def barrier():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(); ctx.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -139,7 +142,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(W, W + K):
         odo.step_device(d_polar[frame_of(t)].data_ptr())
-    torch.cuda.synchronize()
+    ctx.synchronize(); torch.cuda.synchronize()  # the library's streams, then the whole device
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
@@ -147,6 +150,9 @@ def main():
     t_feat, t_reg, n_stage = odo.profile_read_stages()
     poses = odo.poses()
     S, n_cells, n_kf = odo.summary(0)
+    # self-check: sequences that replayed the same sweeps must have ended bit-identical, whatever workgroup slot they had
+    kinds = idx.cpu().numpy()
+    replicas_identical = all(bool(np.all(poses[kinds == u] == poses[kinds == u][0])) for u in range(args.unique) if np.any(kinds == u))
 
     from cfear_radarodometry_code_public_amd.dist import reduce_throughput
     # RCCL over xGMI: two 8-byte all-reduces, the only collective on the path
@@ -194,7 +200,7 @@ def main():
                         "features_us_per_scan": 1e6 * t_feat / max(n_stage, 1) / scans_per_launch,
                         "registration_us_per_scan": 1e6 * t_reg / max(n_stage, 1) / scans_per_launch},
             "state": {"cells_seq0": n_cells, "keyframes_seq0": n_kf, "outer_iterations_seq0": S.outer_iterations,
-                      "pose_seq0": [float(x) for x in poses[0]], "datagen_s": t_gen},
+                      "pose_seq0": [float(x) for x in poses[0]], "replicas_bit_identical": replicas_identical, "datagen_s": t_gen},
         }
         if world == 1 and args.stream_steps > 0:
             # the boundary also takes host buffers (cfear_odometry_step_host): PCIe-inclusive rate, reported beside

@@ -65,7 +65,9 @@ void cfear_default_params(cfear_params* p);
 typedef struct cfear_ctx cfear_ctx;
 
 /* One context = one HIP device + stream + scratch. `stream` may be NULL (the context creates its
- * own) or an existing hipStream_t passed as void*. A, R = polar image shape the context is sized
+ * own: note that the handle of a framework's *default* stream is NULL too, and the stream created here is not
+ * ordered with that default stream) or an existing hipStream_t passed as void*: device buffers handed to the
+ * *_device entry points must be complete on that stream (or synchronized) before the call. A, R = polar image shape the context is sized
  * for (rows = azimuths, cols = range bins; radar_driver.cpp:92-98). */
 int cfear_create(cfear_ctx** out, int device, void* stream, const cfear_params* p, int A, int R);
 void cfear_destroy(cfear_ctx* ctx);

@@ -2,6 +2,7 @@
 import ctypes as C, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+torch.cuda.set_stream(torch.cuda.Stream())  # explicit stream shared with the library (handle 0 = torch's default stream would make the context create its own, unordered with torch)
 from cfear_radarodometry_code_public_amd import capi
 frames = int(os.environ.get('ODO_FRAMES', '30'))
 world = bench.make_streams(4, frames, 0)

@@ -2,6 +2,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfear_radarodometry_code_public_amd import capi
+torch.cuda.set_stream(torch.cuda.Stream())  # explicit stream shared with the library (handle 0 = torch's default stream would make the context create its own, unordered with torch)
 n = 256
 ctx = capi.Context(capi.default_params(), 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
 d_in = torch.randint(0, 256, (n, 3360, 400), dtype=torch.uint8, device="cuda")
