@@ -27,6 +27,18 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile if a source is newer than the library. Safe to call from several processes at once (one rank per GPU):
+    an exclusive file lock serialises them, the later ones find the library up to date."""
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     if not force and not needs_build():
         return LIB
     objs = []
@@ -47,8 +59,10 @@ def build(force=False, verbose=False):
             fail = True
     if fail:
         raise RuntimeError("hipcc failed")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".tmp"  # linked beside the target and renamed: nobody ever maps a half-written library
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 
