@@ -217,6 +217,22 @@ def main():
                                   "note": "host -> device copy of every sweep inside the timed region (pinned memory, cfear_odometry_step_host)",
                                   "h2d_GBps": B * A * R * args.stream_steps / dt / 1e9}
         if world == 1 and not args.no_cpu_baseline:
+            # parity of what was just timed: the oracle replays the same sweeps in the same order for every generated stream
+            # (checker only, outside the timed region) and the final poses are compared
+            from oracle import binding as ob
+            po = params(ob)
+            epos, erot = 0.0, 0.0
+            for u in range(args.unique):
+                if not np.any(kinds == u):
+                    continue
+                fz = ob.Fuser(po)
+                for step in range(W + K):
+                    e = fz.process_polar(streams[u, frame_of(step)])
+                g = poses[np.argmax(kinds == u)]
+                epos = max(epos, float(np.max(np.abs(g[:2] - e[:2])))); erot = max(erot, float(abs(g[2] - e[2])))
+            out["parity"] = {"max_position_error_m": epos, "max_rotation_error_rad": erot, "streams_checked": int(args.unique),
+                             "sweeps_per_stream": W + K, "within_1e-4_m_and_1e-5_rad": bool(epos < 1e-4 and erot < 1e-5),
+                             "replicas_bit_identical": replicas_identical}
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     odo.release()
