@@ -195,6 +195,7 @@ def main():
                          "launches_per_step": launches_per_step},
             # features / registration are latency-bound chains: reported as time, not as a roofline fraction
             "kernels": {"kstrongest_launch_us": filt * 1e6, "kstrongest_launches": n_filter,
+                        "filter_stage_alone_scans_per_s": scans_per_launch / filt,  # the filter-only rate
                         "features_launch_us": 1e6 * t_feat / max(n_stage, 1), "registration_launch_us": 1e6 * t_reg / max(n_stage, 1),
                         "sequences_per_launch": scans_per_launch,
                         "features_us_per_scan": 1e6 * t_feat / max(n_stage, 1) / scans_per_launch,
