@@ -558,31 +558,31 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
   const int cost = sh->rp.cost, weight_opt = sh->rp.weight_opt;  // through the LDS-typed pointer
   const RCell cs = rcell_src(src, j);
   typedef __attribute__((address_space(3))) double lds_double;
-#pragma unroll 1
-  for (int i = 0; i < nk; i++) {
+#pragma unroll 2
+  for (int i = 0; i < nk; i++) {  // two keyframes per trip, branch-free (stores predicated): their independent chains of
+                                  // double-precision arithmetic interleave instead of running one after the other
     const int ti = assoc_get(a, i);
-    if (ti < 0) continue;
+    const bool on = ti >= 0;
+    const int tix = on ? ti : 0;
     const int o = (int)((pos >> (16 * i)) & 0xFFFF);
     lds_double* lm = (lds_double*)lds_match_base() + o;
     double* gm = sh->rw.tmx + o;
     const size_t gcap = (size_t)sh->rw.cap;
     // array q of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
-    auto put = [&](int q, double val) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; };
-    const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti);
+    auto put = [&](int q, double val) { if (on) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; } };
+    const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)tix);
     const double2 r0 = r[0], r1 = r[1], r2 = r[2];  // mean, normal, (samples, scale)
     const auto* T = sh->Trel[i];
     const auto* Tt = sh->Ttar[i];
-    put(5, cs.mx); put(6, cs.my);
-    put(0, (Tt[0] * r0.x + Tt[1] * r0.y) + Tt[4]);
-    put(1, (Tt[2] * r0.x + Tt[3] * r0.y) + Tt[5]);
-    {
-      const double nx = T[0] * cs.nx + T[1] * cs.ny;
-      const double ny = T[2] * cs.nx + T[3] * cs.ny;
-      const double sim = fmax(nx * r1.x + ny * r1.y, 0.0);
-      put(7, get_weight(weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y));
-    }
+    const double tmx = (Tt[0] * r0.x + Tt[1] * r0.y) + Tt[4];
+    const double tmy = (Tt[2] * r0.x + Tt[3] * r0.y) + Tt[5];
+    const double nx = T[0] * cs.nx + T[1] * cs.ny;
+    const double ny = T[2] * cs.nx + T[3] * cs.ny;
+    const double sim = fmax(nx * r1.x + ny * r1.y, 0.0);
+    const double wgt = get_weight(weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y);
+    double a0, a1, a2;
     if (cost == CFEAR_COST_P2D) {  // :290-299
-      const cfear_cell* ctf = &scans[i]->cells[ti];
+      const cfear_cell* ctf = &scans[i]->cells[tix];
       const double ca = ctf->cov[0], cb = ctf->cov[1], cc = ctf->cov[2];
       const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
       const double m00 = r00 * ca + r01 * cb, m01 = r00 * cb + r01 * cc;
@@ -594,13 +594,13 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
       const double det = c00 * c11 - c01 * c10, id = 1.0 / det;
       const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
       const double l00 = sqrt(i00), l10 = i10 / l00;
-      const double l11 = sqrt(i11 - l10 * l10);
-      put(2, l00); put(3, l10); put(4, l11);
+      a0 = l00; a1 = l10; a2 = sqrt(i11 - l10 * l10);
     } else {
-      put(2, Tt[0] * r1.x + Tt[1] * r1.y);
-      put(3, Tt[2] * r1.x + Tt[3] * r1.y);
-      put(4, 0.0);
+      a0 = Tt[0] * r1.x + Tt[1] * r1.y;
+      a1 = Tt[2] * r1.x + Tt[3] * r1.y;
+      a2 = 0.0;
     }
+    put(0, tmx); put(1, tmy); put(2, a0); put(3, a1); put(4, a2); put(5, cs.mx); put(6, cs.my); put(7, wgt);
   }
 }
 
