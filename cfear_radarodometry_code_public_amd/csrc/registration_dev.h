@@ -5,9 +5,11 @@
 // (:392-433) for this path. Ceres trust-region LM semantics restated per SURVEY.md 9.H; same
 // formulas, in double, as oracle/cfear_oracle.c so that iteration counts agree.
 //
-// All threads of the block keep identical copies of the solver state (uniform control flow); the
-// only data-parallel parts are the association pass and the residual pass, each followed by a
-// deterministic block reduction.
+// Structure: the solver state lives in LDS (RegShared). Wave 0 is the controller: a state machine of leaf functions
+// (ctl_*) that consumes the result of the command just executed and publishes the next one (BUILD: re-associate at the
+// current pose; EVAL: robustified cost / gradient / Gauss-Newton matrix at a point); all waves execute the commands
+// (association: thread <-> source cell; evaluation: thread <-> residual block), each followed by a deterministic
+// reduction. Everything reaches RegShared through an LDS-typed pointer (LRegShared).
 #pragma once
 #include "features_dev.h"
 
