@@ -229,7 +229,46 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       o++;
     }
   };
-  if (few) {
+  if (few && expand && ipt <= k) {
+    // two points per trip, branch-free: each point is one chain of dependent double-precision operations (two divisions),
+    // and one wave running one chain issues an instruction every 8-10 cycles; two chains interleave
+    struct Pt { float x, y, w; bool on; };
+    auto calc = [&](int u) {
+      Pt p;
+      const uint32_t s = u < SV ? sv[u < SV ? u : 0] : 0u;
+      const int range = CFEAR_SLOT_RANGE(s);
+      p.on = (u < SV) && (i0 + u < i1) && CFEAR_SLOT_VALID(s) && range > min_range_bin;
+      const int bb = min(b + ((jb + u >= k) ? 1 : 0), A - 1);  // at most one bearing change inside a thread's items (ipt <= k)
+      const double cb = ltab[6 * bb + 4], sb = ltab[6 * bb + 5];
+      const double rad = range_res_half + range_res * range;
+      const double px = (double)(float)(rad * cb), py = (double)(float)(rad * sb);  // :329-330 (float store, read back)
+      const double ab = ltab[6 * bb], s_b = ltab[6 * bb + 1], c_b = ltab[6 * bb + 2], d_b = ltab[6 * bb + 3];
+      const double den = px * cb + py * sb;
+      const double a = ab + (py * cb - px * sb) / (p.on ? den : 1.0);
+      const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+      const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+      const double e = d * m2 - d_b * m2;
+      const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
+      p.x = (float)((c1 * px + (-s1) * py) + d * m0);
+      p.y = (float)((s1 * px + c1 * py) + d * m1);
+      p.w = (float)CFEAR_SLOT_INTENSITY(s);
+      return p;
+    };
+    auto emit = [&](const Pt& p) {
+      if (p.on && o < cap) {
+        g_xyi[3 * o + 0] = p.x; g_xyi[3 * o + 1] = p.y; g_xyi[3 * o + 2] = p.w;
+        mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x); mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+        o++;
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < SV; u += 2) {  // static slot indices (a runtime index would move the slots out of registers)
+      if (u < ipt) {
+        const Pt p0 = calc(u), p1 = calc(u + 1);
+        emit(p0); emit(p1);
+      }
+    }
+  } else if (few) {
 #pragma unroll 1
     for (int u = 0; u < ipt && i0 + u < i1; u++, jb++) {  // one copy of the per-point arithmetic; the slot comes out of its register by selects
       if (jb == k) { jb = 0; b++; }
