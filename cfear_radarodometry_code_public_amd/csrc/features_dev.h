@@ -492,14 +492,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   if (pt) pt->mark();
   const float* __restrict__ sp = W.spts;
   // ---- centroids: float sums in ascending (voxel, point) order, divided by float(count) ([3P] PCL CentroidPoint) ----
-  for (int v = tid; v < nv; v += nt) {
-    const int a = W.vstart[v], b = W.vstart[v + 1];
-    float sx = 0.f, sy = 0.f, si = 0.f;
-    for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
-    const float cnt = (float)(b - a);
-    g_samples[3 * v] = sx / cnt; g_samples[3 * v + 1] = sy / cnt; g_samples[3 * v + 2] = si / cnt;
-  }
-  __syncthreads();
+  // (the same loop goes on to the sample's candidate ranges below: the centroid stays in registers instead of being read
+  // back from memory behind a barrier)
   if (pt) pt->mark();
   // ---- radius search + cell statistics per sample point (pointnormal.cpp:286-296, :7-63) ----
   // One pass over the candidates with moments shifted by the sample point c:
@@ -512,7 +506,15 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   // chunk order (deterministic).
   int* __restrict__ T = W.order;  // the sorted order has been consumed by the staging above
   for (int v = tid; v < nv; v += nt) {
-    const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
+    float cx, cy;
+    {
+      const int a = W.vstart[v], b = W.vstart[v + 1];
+      float sx = 0.f, sy = 0.f, si = 0.f;
+      for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
+      const float cnt = (float)(b - a);
+      cx = sx / cnt; cy = sy / cnt;
+      g_samples[3 * v] = cx; g_samples[3 * v + 1] = cy; g_samples[3 * v + 2] = si / cnt;  // read by the chunk lanes and the epilogue
+    }
     int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
     int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
     gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
