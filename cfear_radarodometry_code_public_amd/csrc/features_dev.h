@@ -674,6 +674,10 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         g_f32* mf = (g_f32*)S->mean_f;
         mf[2 * o] = (float)c.mean[0];
         mf[2 * o + 1] = (float)c.mean[1];
+        if (W.lds && o < CFEAR_LDS_POINT_CAP / 2) {  // a copy for the grid build below (the voxel list is not needed any more)
+          auto* lmw = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
+          lmw[2 * o] = (float)c.mean[0]; lmw[2 * o + 1] = (float)c.mean[1];
+        }
         const size_t cc = (size_t)cap_cells;
         g_f64* rs = (g_f64*)S->rsrc + o;
         rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
@@ -692,6 +696,9 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   if (pt) pt->mark();
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
   const int nc = n_cells_out;
+  // the cell means come from the LDS copy the epilogue left in the voxel-list array when they fit (no read-back from memory)
+  const bool lm_ok = W.lds && nc <= CFEAR_LDS_POINT_CAP / 2;  // block-uniform
+  const auto* lmr = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   g_f32* const g_mean = (g_f32*)S->mean_f;
@@ -700,7 +707,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   __attribute__((address_space(1))) u32x2* const g_rows3 = (__attribute__((address_space(1))) u32x2*)grid_rows3(S->gstart);
   float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
   for (int i = tid; i < nc; i += nt) {
-    const float x = g_mean[2 * i], y = g_mean[2 * i + 1];
+    const float x = lm_ok ? lmr[2 * i] : g_mean[2 * i], y = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
     gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
   }
   { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
@@ -727,7 +734,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     for (int g = tid; g <= G; g += nt) gc[g] = 0;
     __syncthreads();
     for (int i = tid; i < nc; i += nt) {
-      int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
+      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
+      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
       cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
       atomicAdd(&gc[cy * gw + cx + 1], 1);
     }
@@ -756,7 +764,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
     }
     for (int i = tid; i < nc; i += nt) {
-      const float mx = g_mean[2 * i], my = g_mean[2 * i + 1];
+      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
       int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
       cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
       const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
