@@ -72,7 +72,10 @@ struct FeatureScratch {
   int cap;          // capacity (entries) of order/vstart/vlist/rng/part
   bool tab_zeroed;  // the caller already cleared the whole key region (saves a barrier)
   int tab_voxels;   // voxels the dense counting-sort table may cover (two 16-bit counters per word of the key region)
+  unsigned char* srng;  // LDS, CFEAR_LDS_SAMPLE_CAP x (uint4 of eight 16-bit candidate ranges) then x (float2 centroid): what the
+                        // range pass hands to the chunk lanes and the epilogue without a trip through memory (nullptr: global arrays)
 };
+#define CFEAR_LDS_SAMPLE_CAP 1365
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
 
@@ -354,6 +357,10 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   g_f64* const g_part = (g_f64*)W.part;
   g_f32* const g_samples = (g_f32*)W.samples;
   g_i32* const g_rng = (g_i32*)W.rng;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __attribute__((address_space(3))) u32x4* const l_rng = (__attribute__((address_space(3))) u32x4*)W.srng;
+  __attribute__((address_space(3))) f32x2* const l_cxy = (__attribute__((address_space(3))) f32x2*)(W.srng + (size_t)CFEAR_LDS_SAMPLE_CAP * 16);
   const int tid = threadIdx.x, nt = blockDim.x;
   const g_f32* const xyi = (const g_f32*)S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
@@ -483,6 +490,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   }
   const int nv = nv_out;  // known to every thread: no read-back of S->n_samples through memory
+  const bool lds_samples = W.srng != nullptr && nv <= CFEAR_LDS_SAMPLE_CAP && n < 65535;  // block-uniform
   // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)
   for (int q = tid; q < n; q += nt) {
     const int pi = W.order[q];
@@ -513,7 +521,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
       const float cnt = (float)(b - a);
       cx = sx / cnt; cy = sy / cnt;
-      g_samples[3 * v] = cx; g_samples[3 * v + 1] = cy; g_samples[3 * v + 2] = si / cnt;  // read by the chunk lanes and the epilogue
+      if (lds_samples) l_cxy[v] = f32x2{cx, cy};  // read by the chunk lanes and the epilogue
+      else { g_samples[3 * v] = cx; g_samples[3 * v + 1] = cy; g_samples[3 * v + 2] = si / cnt; }
     }
     int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
     int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
@@ -539,8 +548,14 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
     }
     if (nr > 4) R[0] = -1;  // only with leaf < radius: the chunk lanes search again (copies made below)
-    g_i32x4* Rg = (g_i32x4*)(g_rng + 8 * (size_t)v);
-    Rg[0] = i32x4{R[0], R[1], R[2], R[3]}; Rg[1] = i32x4{R[4], R[5], R[6], R[7]};
+    if (lds_samples) {  // offsets into the sorted points are below 65536 here; 0xFFFF in the first field = "search again"
+      const unsigned f = (nr > 4) ? 0xFFFFu : (unsigned)R[0];
+      l_rng[v] = u32x4{f | ((unsigned)R[1] << 16), (unsigned)R[2] | ((unsigned)R[3] << 16), (unsigned)R[4] | ((unsigned)R[5] << 16),
+                       (unsigned)R[6] | ((unsigned)R[7] << 16)};
+    } else {
+      g_i32x4* Rg = (g_i32x4*)(g_rng + 8 * (size_t)v);
+      Rg[0] = i32x4{R[0], R[1], R[2], R[3]}; Rg[1] = i32x4{R[4], R[5], R[6], R[7]};
+    }
     T[v] = tot >= 6 ? tot : 0;  // fewer than six candidates can never make a cell (pointnormal.cpp:291): no chunks, no partial sums
   }
   const bool wide = (int)(2.0f * rq * inv) + 2 > 4;  // block-uniform
@@ -575,9 +590,18 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   for (int w = tid; w < NC; w += nt) {
     const int v = W.vlist[w];
     const int j = w - W.vstart[v];
-    const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
-    const g_i32x4* R = (const g_i32x4*)(g_rng + 8 * (size_t)v);
-    const i32x4 r0 = R[0], r1 = R[1];
+    float cx, cy;
+    i32x4 r0, r1;
+    if (lds_samples) {
+      const f32x2 cc = l_cxy[v]; cx = cc.x; cy = cc.y;
+      const u32x4 q = l_rng[v];
+      r0 = i32x4{(q.x & 0xFFFFu) == 0xFFFFu ? -1 : (int)(q.x & 0xFFFFu), (int)(q.x >> 16), (int)(q.y & 0xFFFFu), (int)(q.y >> 16)};
+      r1 = i32x4{(int)(q.z & 0xFFFFu), (int)(q.z >> 16), (int)(q.w & 0xFFFFu), (int)(q.w >> 16)};
+    } else {
+      cx = g_samples[3 * v]; cy = g_samples[3 * v + 1];
+      const g_i32x4* R = (const g_i32x4*)(g_rng + 8 * (size_t)v);
+      r0 = R[0]; r1 = R[1];
+    }
     const int tot = T[v];
     int skip = j * C, left = min(C, tot - skip);
     CellAcc A = {0, 0, 0, 0, 0, 0, 0};
@@ -638,7 +662,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         }
         const int m = (int)md;
         if (m >= 6) {  // :291
-          const float cx = g_samples[3 * v], cy = g_samples[3 * v + 1];
+          float cx, cy;
+          if (lds_samples) { const f32x2 cc = l_cxy[v]; cx = cc.x; cy = cc.y; } else { cx = g_samples[3 * v]; cy = g_samples[3 * v + 1]; }
           const double m1x = s1x / s0, m1y = s1y / s0;
           const double ux = (double)cx + m1x, uy = (double)cy + m1y;
           const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;

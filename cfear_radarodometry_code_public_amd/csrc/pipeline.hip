@@ -35,8 +35,10 @@ struct FeatLds {  // byte offsets into the static LDS segment of the features ke
   static constexpr size_t order = keys + LDS_P2 * sizeof(uint64_t);   // CFEAR_LDS_POINT_CAP ints
   static constexpr size_t vstart = order + CFEAR_LDS_POINT_CAP * sizeof(int);      // +1 (padded)
   static constexpr size_t vlist = vstart + (CFEAR_LDS_POINT_CAP + 8) * sizeof(int);
-  static constexpr size_t total = vlist + CFEAR_LDS_POINT_CAP * sizeof(int);
+  static constexpr size_t srng = vlist + CFEAR_LDS_POINT_CAP * sizeof(int);  // per sample: 8 x u16 candidate ranges + centroid xy
+  static constexpr size_t total = srng + CFEAR_LDS_SAMPLE_CAP * 24;
 };
+static_assert(FeatLds::total <= 160 * 1024, "a workgroup can have 160 KB of LDS");
 struct RegLds {  // registration kernels
   static constexpr size_t red_d = 0;                                  // 10 sums x CFEAR_RED_STRIDE waves
   static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*MAX_SCANS doubles
@@ -91,8 +93,10 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
     W.order = reinterpret_cast<int*>(lds + FeatLds::order);
     W.vstart = reinterpret_cast<int*>(lds + FeatLds::vstart);
     W.vlist = reinterpret_cast<int*>(lds + FeatLds::vlist);
+    W.srng = lds + FeatLds::srng;
   } else {
     W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
+    W.srng = nullptr;
   }
   W.vcur = B.vcur; W.lds = LDS; W.tab_zeroed = LDS && tab_zeroed;
   W.tab_voxels = LDS ? (LDS_P2 * 4 < 32768 ? LDS_P2 * 4 - 2 : 32768) : 0;  // 16-bit counters over the key region, values < 65536
