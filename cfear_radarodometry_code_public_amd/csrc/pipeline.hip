@@ -5,7 +5,7 @@
 // One radar sweep of B independent sequences = three launches on the context stream, no host round trip:
 //   kstrongest_kernel      (kstrongest.hip)  B*A wavefront-rows, HBM streaming
 //   features_step_kernel   one 1024-thread workgroup per sequence: cloud + motion compensation, counting sort over
-//                          the voxel grid and sorted points in ~125 KB of LDS, chunked cell statistics, cell-mean grid
+//                          the voxel grid and sorted points in LDS (all 160 KB of a compute unit), chunked cell statistics, cell-mean grid
 //   register_step_kernel   one 256-thread workgroup per sequence (53 KB LDS incl. the match array, three per compute
 //                          unit so that the serial Levenberg-Marquardt controllers of different sequences overlap):
 //                          association, robust normal equations, LM, outer loop, keyframe logic
