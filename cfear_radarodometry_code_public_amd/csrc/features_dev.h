@@ -656,9 +656,16 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       if (v < nv) {
         double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
         const size_t cs = (size_t)W.cap;
-        for (int w = W.vstart[v]; w < W.vstart[v + 1]; w++) {
-          md += g_part[w]; s0 += g_part[cs + w]; s1x += g_part[2 * cs + w]; s1y += g_part[3 * cs + w];
-          sxx += g_part[4 * cs + w]; sxy += g_part[5 * cs + w]; syy += g_part[6 * cs + w];
+        const int w0 = W.vstart[v], w1 = W.vstart[v + 1];
+        // two chunks per trip: all fourteen loads in flight together, added in chunk order (a sample has one to three chunks
+        // as a rule: one round trip to memory instead of one per chunk)
+        for (int w = w0; w < w1; w += 2) {
+          const int wb = min(w + 1, w1 - 1);
+          double pa[7], pb[7];
+#pragma unroll
+          for (int q = 0; q < 7; q++) { pa[q] = g_part[q * cs + w]; pb[q] = g_part[q * cs + wb]; }
+          md += pa[0]; s0 += pa[1]; s1x += pa[2]; s1y += pa[3]; sxx += pa[4]; sxy += pa[5]; syy += pa[6];
+          if (w + 1 < w1) { md += pb[0]; s0 += pb[1]; s1x += pb[2]; s1y += pb[3]; sxx += pb[4]; sxy += pb[5]; syy += pb[6]; }
         }
         const int m = (int)md;
         if (m >= 6) {  // :291
