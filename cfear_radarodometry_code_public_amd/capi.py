@@ -59,13 +59,13 @@ class RegSummary(C.Structure):
 
 EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
-    "cfear_set_params", "cfear_synchronize", "cfear_kstrongest_device", "cfear_kstrongest_host",
+    "cfear_set_params", "cfear_synchronize", "cfear_tune", "cfear_kstrongest_device", "cfear_kstrongest_host",
     "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
-    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_time_kstrongest",
+    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         "cfear_last_error": (C.c_char_p, [vp]),
         "cfear_set_params": (C.c_int, [vp, C.POINTER(Params)]),
         "cfear_synchronize": (C.c_int, [vp]),
+        "cfear_tune": (C.c_int, [vp, C.c_int, C.c_int]),
         "cfear_kstrongest_device": (C.c_int, [vp, u8p, C.c_int, u32p]),
         "cfear_kstrongest_host": (C.c_int, [vp, u8p, C.c_int, u32p]),
         "cfear_rotate_polar": (C.c_int, [vp, u8p, C.c_int, C.c_int, u8p]),
@@ -130,6 +131,7 @@ def lib():
         "cfear_odometry_profile": (C.c_int, [vp, vp, C.c_int]),
         "cfear_odometry_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
         "cfear_odometry_profile_read_stages": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+        "cfear_odometry_phase_times": (C.c_int, [vp, vp, C.c_int, vp]),
         "cfear_time_kstrongest": (C.c_int, [vp, u8p, C.c_int, u32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -157,6 +159,9 @@ def _addr(a):
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     return a.ctypes.data
+
+
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP = 1, 2, 3
 
 
 class Context:
@@ -198,6 +203,10 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.cfear_synchronize(self._h), "cfear_synchronize")
+
+    def tune(self, key, value):
+        """cfear_tune: TUNE_FILTER_OCCUPANCY / TUNE_FILTER_ROWS_PER_WAVE / TUNE_ODOMETRY_OVERLAP (results do not depend on them)"""
+        self._check(self._L.cfear_tune(self._h, int(key), int(value)), "cfear_tune")
 
     # ---- stage 1 ----
     def kstrongest_host(self, polar):
@@ -315,7 +324,10 @@ class Context:
                                                   costs.ctypes.data), "cfear_cov_by_sampling")
         return bool(ok.value), cov.reshape(6, 6), costs
 
-    def odometry(self, n_sequences):
+    def odometry(self, n_sequences, overlap=None):
+        """overlap: None = the context's setting (default on), True / False = filter one sweep ahead on its own stream or not"""
+        if overlap is not None:
+            self.tune(TUNE_ODOMETRY_OVERLAP, 1 if overlap else 0)
         return Odometry(self, n_sequences)
 
 
@@ -434,6 +446,20 @@ class Odometry:
         self._ctx._check(self._ctx._L.cfear_odometry_profile_read_stages(self._ctx._h, self._h, C.byref(tf), C.byref(tr), C.byref(n)),
                          "cfear_odometry_profile_read_stages")
         return tf.value, tr.value, n.value
+
+    def phase_times(self, mode):
+        """None: switch to the timed kernel instantiations; True: read + clear the [B][32] tick table of the steps since the
+        last read; False: back to the production kernels."""
+        L, c = self._ctx._L, self._ctx
+        if mode is None:
+            c._check(L.cfear_odometry_phase_times(c._h, self._h, 1, None), "cfear_odometry_phase_times")
+            return None
+        if mode is False:
+            c._check(L.cfear_odometry_phase_times(c._h, self._h, 0, None), "cfear_odometry_phase_times")
+            return None
+        buf = np.zeros((self.B, 32), dtype=np.int64)
+        c._check(L.cfear_odometry_phase_times(c._h, self._h, 1, buf.ctypes.data), "cfear_odometry_phase_times")
+        return buf
 
     def poses(self):
         out = np.zeros((self.B, 3))

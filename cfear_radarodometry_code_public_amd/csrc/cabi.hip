@@ -44,6 +44,13 @@ static int validate_params(cfear_ctx* ctx, const cfear_params* p) {
   if (p->max_itr_association < 1 || p->max_itr_association > CFEAR_MAX_OUTER) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "max_itr_association must be in 1..64");
   if (p->cost < 0 || p->cost > 2) return cfear_fail(ctx, CFEAR_ERR_INVALID, "unknown cost");
   if (p->loss < 0 || p->loss > 5) return cfear_fail(ctx, CFEAR_ERR_INVALID, "unknown loss");
+  // the cell-mean grid is sized by assoc_radius (a non-positive or non-finite value would never let the grid fit)
+  if (!(p->assoc_radius > 0) || !isfinite(p->assoc_radius)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "assoc_radius must be finite and > 0");
+  if (p->max_solver_iterations < 1) return cfear_fail(ctx, CFEAR_ERR_INVALID, "max_solver_iterations must be >= 1");
+  if (p->min_itr < 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "min_itr must be >= 0");
+  if (!(p->min_distance >= 0.f) || !isfinite(p->min_distance)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "min_distance must be finite and >= 0");
+  if (!isfinite(p->z_min) || !isfinite(p->range_res) || !isfinite(p->res) || !isfinite(p->loss_limit))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "z_min, range_res, res and loss_limit must be finite");
   return CFEAR_OK;
 }
 
@@ -104,8 +111,19 @@ int cfear_set_params(cfear_ctx* ctx, const cfear_params* p) {
   return CFEAR_OK;
 }
 
+int cfear_tune(cfear_ctx* ctx, int key, int value) {
+  if (!ctx) return CFEAR_ERR_INVALID;
+  switch (key) {
+    case CFEAR_TUNE_FILTER_OCCUPANCY: ctx->tune_k1_occ = value; return CFEAR_OK;
+    case CFEAR_TUNE_FILTER_ROWS_PER_WAVE: ctx->tune_k1_rows = value > 0 ? value : 1; return CFEAR_OK;
+    case CFEAR_TUNE_ODOMETRY_OVERLAP: ctx->tune_odo_overlap = value ? 1 : 0; return CFEAR_OK;
+    default: return cfear_fail(ctx, CFEAR_ERR_INVALID, "tune: unknown key");
+  }
+}
+
 int cfear_synchronize(cfear_ctx* ctx) {
   if (!ctx) return CFEAR_ERR_INVALID;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (hipStream_t st : ctx->aux_streams) CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(st));
   return CFEAR_OK;
@@ -113,6 +131,7 @@ int cfear_synchronize(cfear_ctx* ctx) {
 
 int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots) {
   if (!ctx) return CFEAR_ERR_INVALID;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots, ctx->stream);
 }
 

@@ -207,7 +207,7 @@ template <int NCH, int OCC>
 __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __restrict__ polar,
                                                             uint32_t* __restrict__ slots, int A, int R,
                                                             long long n_rows, int u_zmin, int k,
-                                                            long long alloc_bytes, int rows_per_wave, int dbg) {
+                                                            long long alloc_bytes, int rows_per_wave) {
   constexpr int WIN = NCH * 1024;  // LDS window bytes per wave
   constexpr int SUMBITS = NCH == 4 ? 7 : (NCH == 8 ? 8 : 9);
   __shared__ uint4 lds_win[4][NCH * 64];
@@ -306,13 +306,6 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     const uint32_t vtail = (~lds_ge[tb] & 0x0F0F0F0Fu) & (jt == 0 ? vhead : 0x0F0F0F0Fu);
     const uint32_t vtail2 = 0u;  // groups after jt hold no row bytes
     wave_lds_fence();
-    if (dbg == 1) {  // bring-up: streaming ceiling of the load phase
-      uint32_t acc = 0;
-#pragma unroll
-      for (int j = 0; j < NCH; j++) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
-      if (acc == 0x12345678u) slots[g * (long long)k] = acc;
-      continue;
-    }
 
     // ---- threshold search: first probe = previous row's threshold ----
     int lo = Tprev;
@@ -347,10 +340,6 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
         }
       }
     }
-    if (dbg == 2) {
-      if (cnt == 0x1234567) slots[g * (long long)k] = (uint32_t)cnt;
-      continue;
-    }
     // next row starts from this threshold (one higher when the candidate set is getting large)
     Tprev = (cnt > 40 && lo < 255) ? lo + 1 : lo;
 
@@ -384,7 +373,6 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     // candidates). Lane l's candidates take the slots ex[l] .. ex[l] + count - 1 (DPP prefix sum). The lane that
     // owns slot s finds its producer l (producers scatter their id to their first slot, a DPP max-scan spreads it),
     // fetches l's mask words from LDS and picks set bit number s - ex[l] (popcount split + byte table) ----
-    const int nbase = cnt;
     const int C = cnt < 64 ? cnt : 64;
     const int kk = k < C ? k : C;  // number of emitted points
     uint32_t key = 0u;
@@ -403,10 +391,6 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       if (c > 0 && ex < 64) keys[ex] = (uint32_t)(lane + 1);
       wave_lds_fence();
       const int owner = wave_inclusive_max((int)keys[lane]) - 1;
-      if (dbg == 3) {
-        if (owner == 0x1234567) slots[g * (long long)k] = (uint32_t)nbase;
-        continue;
-      }
       if (lane < C) {
         const int l = owner;
         int r = lane - (int)cmp_ex[l];
@@ -495,30 +479,15 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     }
     // ---- emit: ascending (intensity, range), unused slots 0 ----
     uint32_t* out = slots + g * (long long)k;
-    if (dbg == 6) {  // bring-up: cost of the stores
-      if (__ballot(kept && (key | peak) == 0x7777u) != 0) out[0] = 1u;
-    } else {
     if (kept) out[kk - 1 - rank] = key | peak;
     if (lane >= kk && lane < k) out[lane] = 0u;
-    }
     wave_lds_fence();
   }
 }
 
 }  // namespace
 
-// bring-up / tuning knobs (tools/): 0 dbg phase, 1 occupancy variant, 2 rows per wave
-static int g_k1_dbg = 0, g_k1_occ = 7, g_k1_rows = 4;
-int g_cfear_odo_streams = 0;  // 0 = automatic (pipeline.hip)
-int g_cfear_odo_fork = 1;
-extern "C" void cfear_debug_set(int key, int value) {  // tuning hook of tools/, not part of the ABI
-  if (key == 0) g_k1_dbg = value;
-  if (key == 1) g_k1_occ = value;
-  if (key == 2) g_k1_rows = value > 0 ? value : 1;
-  if (key == 3) g_cfear_odo_streams = value;
-  if (key == 4) g_cfear_odo_fork = value;
-}
-
+// Launch-shape knobs live in the context (cfear_tune, include/cfear_hip.h): occupancy variant and rows per wave.
 int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream) {
   const int A = ctx->A, R = ctx->R, k = ctx->par.k_strongest;
   if (!d_polar || !d_slots || n_scans <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "kstrongest: null buffer or n_scans <= 0");
@@ -527,31 +496,30 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const long long n_rows = (long long)n_scans * A;
   const long long alloc = n_rows * R;
   const int u_zmin = (int)(uint8_t)(int)ctx->par.z_min;  // float -> int (radar_filters.cpp:198) -> uchar (:212)
-  const int dbg = g_k1_dbg;
   // one resident wave per SIMD slot (256 CUs x 4 SIMDs x occupancy); each wave walks consecutive rows
-  const int occ_eff = (R + 27 <= 4 * 1024) ? (g_k1_occ >= 7 ? 7 : (g_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
+  const int occ_eff = (R + 27 <= 4 * 1024) ? (ctx->tune_k1_occ >= 7 ? 7 : (ctx->tune_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
   // A wave walks a few consecutive rows (the threshold of one azimuth is the first guess for the next): four rows
   // per wave measured best from 256-scan to 1024-scan launches (shorter: every row pays the cold threshold search;
   // longer: fewer, longer workgroups balance worse). Small launches spread their rows over the resident slots.
   const long long slots_total = 1024LL * occ_eff;
   int rows_per_wave = (int)((n_rows + slots_total - 1) / slots_total);
-  if (rows_per_wave > g_k1_rows) rows_per_wave = g_k1_rows;
+  if (rows_per_wave > ctx->tune_k1_rows) rows_per_wave = ctx->tune_k1_rows;
   if (rows_per_wave < 1) rows_per_wave = 1;
   const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
   const long long blocks = (n_waves + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  const int occ = g_k1_occ;
+  const int occ = ctx->tune_k1_occ;
   if (R + 27 <= 4 * 1024) {
     if (occ >= 7)
-      hipLaunchKernelGGL((kstrongest_kernel<4, 7>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 7>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
     else if (occ <= 5)
-      hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 5>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
     else
-      hipLaunchKernelGGL((kstrongest_kernel<4, 6>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+      hipLaunchKernelGGL((kstrongest_kernel<4, 6>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
   } else if (R + 27 <= 8 * 1024)
-    hipLaunchKernelGGL((kstrongest_kernel<8, 3>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    hipLaunchKernelGGL((kstrongest_kernel<8, 3>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
   else if (R + 27 <= 16 * 1024)
-    hipLaunchKernelGGL((kstrongest_kernel<16, 2>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave, dbg);
+    hipLaunchKernelGGL((kstrongest_kernel<16, 2>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
   else
     return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "kstrongest: R > 16357 range bins not supported");
   CFEAR_HIP_CHECK(ctx, hipGetLastError());

@@ -441,27 +441,47 @@ struct cfear_odometry {
   double* d_cov_work = nullptr;
   cfear_reg_summary* d_summaries = nullptr;
   double* d_poses_out = nullptr;
-  uint32_t* d_slots = nullptr;
+  uint32_t* d_slots[2] = {nullptr, nullptr};  // filter output, double-buffered: the filter runs one sweep ahead
   uint8_t* d_polar = nullptr;  // staging for step_host
   long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
-  // Sub-batches of sequences run filter -> features -> registration on their own streams. A step forks them from
-  // the context stream (input ready) but the context stream only joins them when results are read, so the
-  // sub-batches drift apart over the steps: the HBM-bound filter of one overlaps the latency-bound features /
-  // registration kernels of the others, and partial last rounds of workgroups get filled.
-  int nsub = 1;
-  std::vector<hipStream_t> sub_streams;
-  std::vector<hipEvent_t> sub_done;
-  hipEvent_t fork = nullptr;
-  bool profile = false;        // record HIP events around the filter launches
-  std::vector<hipEvent_t> filter_events;  // 2 per profiled filter launch
-  std::vector<hipEvent_t> stage_events;   // 3 per profiled sub-batch: before features, between, after registration
+  // The filter of a sweep needs nothing but its input, and it is bound by HBM while features / registration are chains
+  // of short dependent phases. With overlap on it runs on a stream of its own (sf) into the slot buffer of its parity;
+  // features / registration follow on a second stream (so) once their slot buffer is written (ev_filt) and release it
+  // when features has consumed it (ev_free). The host issues step t+1 while so still works on step t, so filter(t+1)
+  // fills the compute units that the last rounds of registration(t) leave idle. The context stream joins in the
+  // reading calls (odo_join). With overlap off the three kernels run in turn on the context stream.
+  int overlap = 0;
+  long long step_no = 0;
+  hipStream_t sf = nullptr, so = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_copied = nullptr;
+  hipEvent_t ev_filt[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  bool filt_pending[2] = {false, false};  // ev_filt / ev_free have been recorded at least once
+  // profiling: timing events taken from a pool that is created up front (and grown in blocks)
+  bool profile = false;
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  std::vector<hipEvent_t> filter_events;  // 2 per profiled filter launch (borrowed from the pool)
+  std::vector<hipEvent_t> stage_events;   // 3 per profiled step: before features, between, after registration
 };
-extern int g_cfear_odo_streams, g_cfear_odo_fork;  // kstrongest.hip (cfear_debug_set)
-// make everything the sub-batch streams have been given so far visible to the context stream
+// a timing event from the pool, recorded on `st`
+static int odo_timed_event(cfear_ctx* ctx, cfear_odometry* o, std::vector<hipEvent_t>& list, hipStream_t st) {
+  if (o->pool_used == o->pool.size()) {
+    for (int i = 0; i < 1024; i++) {
+      hipEvent_t e = nullptr;
+      CFEAR_HIP_CHECK(ctx, hipEventCreate(&e));
+      o->pool.push_back(e);
+    }
+  }
+  hipEvent_t e = o->pool[o->pool_used++];
+  list.push_back(e);
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(e, st));
+  return CFEAR_OK;
+}
+// make everything the internal streams have been given so far visible to the context stream
 static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
-  for (size_t i = 0; i < o->sub_streams.size(); i++) {
-    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->sub_done[i], o->sub_streams[i]));
-    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->sub_done[i], 0));
+  if (o->overlap && o->step_no > 0) {
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_done, o->so));  // so waits for every filter it consumes: joining so joins sf
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_done, 0));
   }
   return CFEAR_OK;
 }
@@ -542,9 +562,11 @@ int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cl
   cfear_cloud* c = nullptr;
   int rc = cfear_cloud_alloc(ctx, n, &c);
   if (rc != CFEAR_OK) return rc;
-  if (n > 0) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_xyi, xyi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(c->d_n, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t e = hipSuccess;
+  if (n > 0) e = hipMemcpyAsync(c->d_xyi, xyi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_n, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { cfear_cloud_release(ctx, c); return cfear_fail(ctx, CFEAR_ERR_HIP, "cloud_upload", e); }
   *cloud = c;
   return CFEAR_OK;
 }
@@ -598,17 +620,24 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   const ScanLayout L = scan_layout(cap);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
   const ScanDev h = scan_header(s->d_block, cap);
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-  const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
-  const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
-  const FeatureParams P = feature_params(ctx);
-  hipLaunchKernelGGL(features_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi,
-                     cloud->d_n, P, B);
-  CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
   ScanDev back;
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&back, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);  // h lives until the synchronize below
+  if (e == hipSuccess) {
+    const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
+    const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
+    const FeatureParams P = feature_params(ctx);
+    hipLaunchKernelGGL(features_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi,
+                       cloud->d_n, P, B);
+    e = hipGetLastError();
+  }
+  // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
+  if (e == hipSuccess) e = hipMemcpyAsync(&back, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(s->d_block);
+    delete s;
+    return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_create", e);
+  }
   if (back.status != 0) {
     (void)hipFree(s->d_block);
     delete s;
@@ -921,7 +950,8 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   if (!o) return;
   if (ctx) {
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t st : o->sub_streams) {
+    for (hipStream_t st : {o->sf, o->so}) {
+      if (!st) continue;
       (void)hipStreamSynchronize(st);
       for (size_t i = 0; i < ctx->aux_streams.size(); i++)
         if (ctx->aux_streams[i] == st) { ctx->aux_streams.erase(ctx->aux_streams.begin() + i); break; }
@@ -929,13 +959,12 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
     (void)hipStreamSynchronize(ctx->stream);
   }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
-                  o->d_summaries, o->d_poses_out, o->d_slots, o->d_polar, o->d_phase_times};
+                  o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : o->stage_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : o->sub_done) (void)hipEventDestroy(e);
-  for (hipStream_t st : o->sub_streams) (void)hipStreamDestroy(st);
-  if (o->fork) (void)hipEventDestroy(o->fork);
+  for (hipEvent_t e : o->pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {o->ev_in, o->ev_done, o->ev_copied, o->ev_filt[0], o->ev_filt[1], o->ev_free[0], o->ev_free[1]}) if (e) (void)hipEventDestroy(e);
+  if (o->sf) (void)hipStreamDestroy(o->sf);
+  if (o->so) (void)hipStreamDestroy(o->so);
   delete o;
 }
 
@@ -978,42 +1007,36 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_cov_work, sizeof(double) * 36 * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_summaries, sizeof(cfear_reg_summary) * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_poses_out, sizeof(double) * 3 * (size_t)B) == hipSuccess;
-  ok = ok && hipMalloc(&o->d_slots, sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+  ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc odometry state"); }
   std::vector<ScanDev*> ptrs((size_t)B * o->nslots);
   std::vector<BlockScratch> hdrs((size_t)B);
+  std::vector<ScanDev> scan_hdrs((size_t)B * o->nslots);  // all headers built on the host, uploaded with one strided copy
   for (int q = 0; q < B; q++) {
     for (int j = 0; j < o->nslots; j++) {
       unsigned char* blk = o->d_scans + SL.total * ((size_t)q * o->nslots + j);
-      const ScanDev h = scan_header(blk, o->cap_points);
-      if (hipMemcpyAsync(blk, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ok = false;
+      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points);
       ptrs[(size_t)q * o->nslots + j] = reinterpret_cast<ScanDev*>(blk);
     }
     hdrs[q] = scratch_header(o->d_scratch + WL.total * (size_t)q, o->cap_points, o->pair_cap);
   }
-  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;  // the header temporaries above are stack objects
+  ok = ok && hipMemcpy2D(o->d_scans, SL.total, scan_hdrs.data(), sizeof(ScanDev), sizeof(ScanDev), scan_hdrs.size(), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy(o->d_scan_ptrs, ptrs.data(), sizeof(ScanDev*) * ptrs.size(), hipMemcpyHostToDevice) == hipSuccess;
   ok = ok && hipMemcpy(o->d_scratch_hdr, hdrs.data(), sizeof(BlockScratch) * hdrs.size(), hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry state upload"); }
   rc = cfear_odometry_reset(ctx, o);
   if (rc != CFEAR_OK) { cfear_odometry_destroy(ctx, o); return rc; }
-  // one stream by default; tools/ can ask for sub-batches (cfear_debug_set key 3), at most 8
-  o->nsub = g_cfear_odo_streams > 0 ? g_cfear_odo_streams : 1;
-  if (o->nsub > 8) o->nsub = 8;
-  if (o->nsub > B) o->nsub = B;
-  if (o->nsub < 1) o->nsub = 1;
-  if (o->nsub > 1) {
-    ok = hipEventCreateWithFlags(&o->fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i < o->nsub; i++) {
-      hipStream_t st = nullptr; hipEvent_t ev = nullptr;
-      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-      if (ok) o->sub_streams.push_back(st);
-      ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
-      if (ok) o->sub_done.push_back(ev);
-    }
-    if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry stream creation"); }
-    for (hipStream_t st : o->sub_streams) ctx->aux_streams.push_back(st);
+  ok = hipEventCreateWithFlags(&o->ev_copied, hipEventDisableTiming) == hipSuccess;
+  o->overlap = ctx->tune_odo_overlap ? 1 : 0;
+  if (ok && o->overlap) {
+    ok = ok && hipStreamCreateWithFlags(&o->sf, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&o->so, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t* e : {&o->ev_in, &o->ev_done, &o->ev_filt[0], &o->ev_filt[1], &o->ev_free[0], &o->ev_free[1]})
+      ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   }
+  if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry stream creation"); }
+  if (o->overlap) { ctx->aux_streams.push_back(o->sf); ctx->aux_streams.push_back(o->so); }
   *out = o;
   return CFEAR_OK;
 }
@@ -1022,6 +1045,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   OdoParams OP;
   OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
   OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
@@ -1029,92 +1053,87 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
   OP.phase_times = o->d_phase_times;
   OP.seq0 = 0;
-  auto timed_event = [&](std::vector<hipEvent_t>& list, hipStream_t st) -> int {
-    hipEvent_t e = nullptr;
-    CFEAR_HIP_CHECK(ctx, hipEventCreate(&e));
-    list.push_back(e);
-    CFEAR_HIP_CHECK(ctx, hipEventRecord(e, st));
-    return CFEAR_OK;
-  };
-  auto launch_filter = [&](int seq0, int count, hipStream_t st) -> int {  // radar_driver.cpp:58
-    int rc = CFEAR_OK;
-    if (o->profile && (rc = timed_event(o->filter_events, st)) != CFEAR_OK) return rc;
-    rc = cfear_launch_kstrongest(ctx, d_polar + (size_t)seq0 * ctx->A * ctx->R, count,
-                                 o->d_slots + (size_t)seq0 * ctx->A * ctx->par.k_strongest, st);
-    if (rc != CFEAR_OK) return rc;
-    if (o->profile && (rc = timed_event(o->filter_events, st)) != CFEAR_OK) return rc;
-    return CFEAR_OK;
-  };
-  auto launch_odometry = [&](int seq0, int count, hipStream_t st) -> int {
-    OdoParams P = OP; P.seq0 = seq0;
-    int rc = CFEAR_OK;
-    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
-    if (o->d_phase_times)
-      hipLaunchKernelGGL(features_step_kernel<true>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
-                         o->d_scan_ptrs, o->d_scratch_hdr);
-    else
-      hipLaunchKernelGGL(features_step_kernel<false>, dim3(count), dim3(BLOCK_F), 0, st, o->d_slots, ctx->d_trig, P, o->d_states,
-                         o->d_scan_ptrs, o->d_scratch_hdr);
-    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
-    if (o->d_phase_times)
-      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-    else
-      hipLaunchKernelGGL(register_step_kernel<false>, dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-    if (o->profile && (rc = timed_event(o->stage_events, st)) != CFEAR_OK) return rc;
-    return CFEAR_OK;
-  };
+  const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
+  hipStream_t sf = o->overlap ? o->sf : ctx->stream, so = o->overlap ? o->so : ctx->stream;
   int rc = CFEAR_OK;
-  if (o->nsub <= 1) {
-    if ((rc = launch_filter(0, o->B, ctx->stream)) != CFEAR_OK) return rc;
-    if ((rc = launch_odometry(0, o->B, ctx->stream)) != CFEAR_OK) return rc;
-  } else {
-    if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipEventRecord(o->fork, ctx->stream));  // the sweeps are ready at this point of the context stream
-    const int per = (o->B + o->nsub - 1) / o->nsub;
-    for (int i = 0; i < o->nsub; i++) {
-      const int seq0 = i * per, count = std::min(per, o->B - seq0);
-      if (count <= 0) break;
-      hipStream_t st = o->sub_streams[i];
-      if (g_cfear_odo_fork) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(st, o->fork, 0));
-      if ((rc = launch_filter(seq0, count, st)) != CFEAR_OK) return rc;
-      if ((rc = launch_odometry(seq0, count, st)) != CFEAR_OK) return rc;
-    }
+  if (o->overlap) {
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_in, ctx->stream));  // the sweeps are ready at this point of the context stream
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(sf, o->ev_in, 0));
+    if (o->filt_pending[buf]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(sf, o->ev_free[buf], 0));  // features(t-2) has read this buffer
   }
+  // radar_driver.cpp:58
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, sf)) != CFEAR_OK) return rc;
+  rc = cfear_launch_kstrongest(ctx, d_polar, o->B, o->d_slots[buf], sf);
+  if (rc != CFEAR_OK) return rc;
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, sf)) != CFEAR_OK) return rc;
+  if (o->overlap) {
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_filt[buf], sf));
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(so, o->ev_filt[buf], 0));
+  }
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+  if (o->d_phase_times)
+    hipLaunchKernelGGL(features_step_kernel<true>, dim3(o->B), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, OP, o->d_states,
+                       o->d_scan_ptrs, o->d_scratch_hdr);
+  else
+    hipLaunchKernelGGL(features_step_kernel<false>, dim3(o->B), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, OP, o->d_states,
+                       o->d_scan_ptrs, o->d_scratch_hdr);
+  if (o->overlap) { CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_free[buf], so)); o->filt_pending[buf] = true; }
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+  if (o->d_phase_times)
+    hipLaunchKernelGGL(register_step_kernel<true>, dim3(o->B), dim3(BLOCK_R), 0, so, OP, o->d_states, o->d_scan_ptrs,
+                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  else
+    hipLaunchKernelGGL(register_step_kernel<false>, dim3(o->B), dim3(BLOCK_R), 0, so, OP, o->d_states, o->d_scan_ptrs,
+                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+  o->step_no++;
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
 
-// bring-up / tuning (tools/): per-sequence phase timestamps of the last step, 32 ticks of 10 ns each
-int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, long long* host_ticks /*[B][32]*/) {
-  if (!ctx || !o) return CFEAR_ERR_INVALID;
+int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, int enable, long long* host_ticks /*[B][32]*/) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_phase_times: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!o->d_phase_times) {
-    if (hipMalloc(&o->d_phase_times, sizeof(long long) * 32 * (size_t)o->B) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc phase times");
-    CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
-    return CFEAR_OK;
-  }
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  if (host_ticks) CFEAR_HIP_CHECK(ctx, hipMemcpy(host_ticks, o->d_phase_times, sizeof(long long) * 32 * (size_t)o->B, hipMemcpyDeviceToHost));
-  CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, sizeof(long long) * 32 * (size_t)o->B));
+  const size_t bytes = sizeof(long long) * 32 * (size_t)o->B;
+  if (!enable) {
+    if (o->d_phase_times) (void)hipFree(o->d_phase_times);
+    o->d_phase_times = nullptr;
+    return CFEAR_OK;
+  }
+  if (!o->d_phase_times) {
+    if (hipMalloc(&o->d_phase_times, bytes) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc phase times");
+    CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, bytes));
+    return CFEAR_OK;
+  }
+  if (host_ticks) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpy(host_ticks, o->d_phase_times, bytes, hipMemcpyDeviceToHost));
+    CFEAR_HIP_CHECK(ctx, hipMemset(o->d_phase_times, 0, bytes));
+  }
   return CFEAR_OK;
 }
 
 int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* o, int enable) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (hipEvent_t e : o->filter_events) (void)hipEventDestroy(e);
-  o->filter_events.clear();
-  for (hipEvent_t e : o->stage_events) (void)hipEventDestroy(e);
-  o->stage_events.clear();
+  o->filter_events.clear(); o->stage_events.clear(); o->pool_used = 0;  // the events go back to the pool
+  if (enable && o->pool.empty()) {  // created here, outside any timed region
+    for (int i = 0; i < 1024; i++) {
+      hipEvent_t e = nullptr;
+      CFEAR_HIP_CHECK(ctx, hipEventCreate(&e));
+      o->pool.push_back(e);
+    }
+  }
   o->profile = enable != 0;
   return CFEAR_OK;
 }
 
 int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filter_seconds, int* filter_launches) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile_read: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   double tf = 0;
@@ -1131,6 +1150,7 @@ int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* o, double* filte
 
 int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* o, double* features_seconds, double* registration_seconds, int* launches) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_profile_read_stages: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   double tf = 0, tr = 0;
@@ -1151,10 +1171,16 @@ int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h
   if (!ctx || !o || !h_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_host: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)o->B * ctx->A * ctx->R;
-  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }  // the staging buffer is reused
   if (!o->d_polar && hipMalloc(&o->d_polar, bytes + 64) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc polar batch");
+  // the staging buffer is reused: the copy waits for the filter of the previous sweep (its only reader), not for that
+  // sweep's features / registration
+  if (o->overlap && o->step_no > 0) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_filt[(o->step_no - 1) & 1], 0));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->d_polar, h_polar, bytes, hipMemcpyHostToDevice, ctx->stream));
-  return cfear_odometry_step_device(ctx, o, o->d_polar);
+  // h_polar belongs to the caller again when this returns (pinned memory makes the copy truly asynchronous)
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_copied, ctx->stream));
+  const int rc = cfear_odometry_step_device(ctx, o, o->d_polar);
+  CFEAR_HIP_CHECK(ctx, hipEventSynchronize(o->ev_copied));
+  return rc;
 }
 
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {

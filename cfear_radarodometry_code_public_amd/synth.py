@@ -7,6 +7,8 @@ Three families, all uint8 [A, R] with rows = azimuth, cols = range bin (radar_dr
   * world   : 2-D polygonal world ray-cast from a sensor on a circular trajectory
               (1.0 m / 0.02 rad per frame), Gaussian range blobs over a noise floor.
 """
+import os
+
 import numpy as np
 
 
@@ -118,3 +120,57 @@ def world_sequence(T, A=400, R=3360, range_res=np.float32(0.0595238), seed=0, wo
         d = g[:2] - g0[:2]
         gts.append([c * d[0] + s * d[1], -s * d[0] + c * d[1], g[2] - g0[2]])
     return imgs, np.asarray(gts)
+
+
+def _stream_file(cache_dir, seed, T, A, R, range_res, ccw):
+    return "%s/cfear_world_s%d_T%d_%dx%d_r%08x_c%d.npy" % (cache_dir, seed, T, A, R, np.float32(range_res).view(np.uint32), int(ccw))
+
+
+def _stream_worker(job):
+    path, seed, T, A, R, range_res, ccw = job
+    imgs, _ = world_sequence(T, A, R, np.float32(range_res), seed=seed, world_seed=1234 + seed, ccw=bool(ccw), t0=17 * (seed % 64))
+    tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+    np.save(tmp, imgs)
+    os.replace(tmp, path)  # atomic: several ranks may want the same stream
+    return path
+
+
+def world_streams(seeds, T, A=400, R=3360, range_res=np.float32(0.0595238), ccw=True, procs=None, cache_dir=None):
+    """uint8 [len(seeds), T, A, R]: one world sequence per seed (own world, own start point on the path), generated by
+    worker processes (fresh interpreters: `python -m ...synth --gen`; one sweep costs ~50 ms of one core) and cached as
+    .npy files so that the next run maps them back in."""
+    import subprocess
+    import sys
+    cache_dir = cache_dir or os.environ.get("CFEAR_SYNTH_CACHE", "/tmp/cfear_synth_cache")
+    os.makedirs(cache_dir, exist_ok=True)
+    files = [_stream_file(cache_dir, s, T, A, R, range_res, ccw) for s in seeds]
+    jobs = [(f, s, T, A, R, float(range_res), int(ccw)) for f, s in zip(files, seeds) if not os.path.exists(f)]
+    n = max(1, min(len(jobs), procs or len(os.sched_getaffinity(0))))
+    if len(jobs) == 1 or n == 1:
+        for j in jobs:
+            _stream_worker(j)
+    elif jobs:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        running, todo = [], list(jobs)
+        while todo or running:
+            while todo and len(running) < n:
+                j = todo.pop()
+                running.append(subprocess.Popen([sys.executable, "-m", "cfear_radarodometry_code_public_amd.synth", "--gen"] + [str(x) for x in j],
+                                                cwd=root, env=env))
+            p = running.pop(0)
+            if p.wait(timeout=3600) != 0:
+                for q in running:
+                    q.kill()
+                raise RuntimeError("synthetic stream worker failed")
+    out = np.empty((len(seeds), T, A, R), dtype=np.uint8)
+    for i, f in enumerate(files):
+        out[i] = np.load(f, mmap_mode="r")
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 9 and sys.argv[1] == "--gen":
+        a = sys.argv[2:]
+        _stream_worker((a[0], int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]), int(a[6])))

@@ -75,6 +75,14 @@ const char* cfear_last_error(const cfear_ctx* ctx);
 int cfear_set_params(cfear_ctx* ctx, const cfear_params* p);
 int cfear_synchronize(cfear_ctx* ctx);
 
+/* Launch-shape knobs of a context (tuning; an integration never needs them, tools/ and bench.py do). Results do not depend on
+ * them. FILTER_OCCUPANCY: 5..7 filter waves per SIMD (default 7); FILTER_ROWS_PER_WAVE: consecutive azimuths walked by one
+ * filter wave (default 4); ODOMETRY_OVERLAP: batched odometry objects created afterwards run the filter of a sweep on a stream
+ * of their own, one sweep ahead of the features / registration kernels (default 1; 0 = the three kernels strictly in turn on
+ * the context stream). */
+enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3 };
+int cfear_tune(cfear_ctx* ctx, int key, int value);
+
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------
  * Packed slot: bits 0..15 range bin | 16..23 intensity | 24 valid | 25 peak (AxialNonMaxSupress).
  * Per azimuth row k slots in ascending (intensity, range) order, unused slots = 0. */
@@ -209,10 +217,13 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** odo)
 void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* odo);
 int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* odo);
 /* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous: the sweeps must be ready at this
- * point of the context stream; the work itself runs on internal streams (one per sub-batch of sequences) that the
- * context stream joins only in the reading calls below (poses / summary / profile_read / reset / step_host) and in
- * cfear_synchronize(). Keep d_polar valid and unmodified until one of those has returned. */
+ * point of the context stream; the work itself runs on two internal streams (the filter of sweep t+1 may run beside
+ * the features / registration kernels of sweep t) that the context stream joins only in the reading calls below
+ * (poses / summary / profile_read / reset) and in cfear_synchronize(). Keep d_polar valid and unmodified until one
+ * of those has returned. */
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_polar);
+/* Same from a host buffer (n_sequences * A * R bytes): the sweeps are copied to a staging buffer on the device; the call
+ * returns when that copy has completed (h_polar may be reused or freed at once), the kernels run asynchronously as above. */
 int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_polar);
 /* Tcurrent of every sequence as (x, y, theta); synchronises the stream. */
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt);
@@ -221,14 +232,21 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cf
                            int* n_cells, int* n_keyframes);
 
 /* Filter-kernel timing with HIP events (bench.py roofline leg): enable, run steps, read. filter_seconds is the sum
- * of the durations of the filter launches, each measured on the stream it ran on (a step launches the filter once
- * per sub-batch of sequences). */
+ * of the durations of the filter launches, each measured on the stream it ran on. The events come from a pool created
+ * when profiling is enabled (and grown in blocks), not one hipEventCreate per launch. */
 int cfear_odometry_profile(cfear_ctx* ctx, cfear_odometry* odo, int enable);
 int cfear_odometry_profile_read(cfear_ctx* ctx, cfear_odometry* odo, double* filter_seconds, int* filter_launches);
 /* The same for the two kernels behind the filter (stages 1.5-2: cloud + compensation + oriented surface points;
  * stage 3 + caller: registration and keyframe logic), summed over the profiled launches. */
 int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* odo, double* features_seconds, double* registration_seconds,
                                        int* launches);
+
+/* Per-workgroup phase timestamps (tuning / bench.py's workgroup-time percentiles): enable = 1 switches the odometry steps
+ * to the timed instantiations of the features and registration kernels (thread 0 of every workgroup stores wall_clock64()
+ * ticks of 10 ns: slots 0..13 features phases, 14..28 registration phases, 29..31 accumulated evaluation / controller
+ * ticks and evaluation count); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
+ * copied out (synchronises) and cleared. enable = 0 frees the table: back to the production kernels. */
+int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* odo, int enable, long long* host_ticks);
 
 /* Timing hook used by bench.py: seconds of the filter kernel measured with HIP events on the
  * context stream over `iters` launches (after `warmup`). */

@@ -182,42 +182,50 @@ def test_reference_presets_through_device_fuser(oracle, k, cost, res, submap):
     ctx.close()
 
 
-def test_sub_batch_streams_give_identical_results(oracle):
-    """The optional sub-batch streams (tuning hook cfear_debug_set(3, n): filter / features / registration of disjoint
-    sequence ranges on their own HIP streams, joined by the reading calls) must not change any result, for device-resident
-    input (free-running streams) and for host input (staging buffer reuse)."""
-    import ctypes as C
+def test_filter_ahead_streams_give_identical_results(oracle):
+    """The batched odometry runs the filter of a sweep on a stream of its own, one sweep ahead of the features /
+    registration kernels (double-buffered slots; cfear_tune ODOMETRY_OVERLAP). It must not change any result, for
+    device-resident input (free-running streams) and for host input (staging buffer reuse), with reads in between."""
     import torch
-    L = capi.lib()
-    L.cfear_debug_set.argtypes = [C.c_int, C.c_int]
-    imgs, _ = synth.world_sequence(6, seed=13)
-    imgs2, _ = synth.world_sequence(6, seed=14, t0=20)
+    imgs, _ = synth.world_sequence(8, seed=13)
+    imgs2, _ = synth.world_sequence(8, seed=14, t0=20)
     B = 6
     streams = [imgs, imgs2, imgs[:, ::-1].copy(), imgs2[:, ::-1].copy(), imgs, imgs2]
-    batches = np.stack([np.stack([s[t] for s in streams]) for t in range(6)])  # [T][B][A][R]
+    batches = np.stack([np.stack([s[t] for s in streams]) for t in range(8)])  # [T][B][A][R]
     d_batches = torch.from_numpy(batches).cuda()
+    torch.cuda.synchronize()
     pg = mk_params(capi)
     results = {}
-    try:
-        for nsub in (1, 3):
-            L.cfear_debug_set(3, nsub)
-            ctx = capi.Context(pg, 400, 3360)
-            odo = ctx.odometry(B)
-            for t in range(6):
-                if t % 2 == 0:
-                    odo.step_device(d_batches[t].data_ptr())
-                else:
-                    odo.step_host(batches[t])
-            poses = odo.poses()
-            summ = [odo.summary(q) for q in range(B)]
-            results[nsub] = (poses, [(s[0].outer_iterations, list(s[0].inner_iterations[:8]), s[1], s[2]) for s in summ])
-            odo.release()
-            ctx.close()
-    finally:
-        L.cfear_debug_set(3, 0)
-    assert np.array_equal(results[1][0], results[3][0])
-    assert results[1][1] == results[3][1]
-    assert np.all(np.isfinite(results[1][0])) and np.abs(results[1][0][:, :2]).max() > 1.0  # the sequences moved
+    for overlap in (False, True):
+        ctx = capi.Context(pg, 400, 3360)
+        odo = ctx.odometry(B, overlap=overlap)
+        mid = None
+        for t in range(8):
+            if t % 3 == 1:
+                h = batches[t].copy()
+                odo.step_host(h)
+                h[:] = 0  # the host buffer belongs to the caller again when step_host returns
+            else:
+                odo.step_device(d_batches[t].data_ptr())
+            if t == 4:
+                mid = odo.poses()  # a reading call in the middle of the run joins the streams
+        poses = odo.poses()
+        summ = [odo.summary(q) for q in range(B)]
+        results[overlap] = (poses, mid, [(s[0].outer_iterations, list(s[0].inner_iterations[:8]), s[1], s[2]) for s in summ])
+        odo.release()
+        ctx.close()
+    assert np.array_equal(results[False][0], results[True][0])
+    assert np.array_equal(results[False][1], results[True][1])
+    assert results[False][2] == results[True][2]
+    assert np.all(np.isfinite(results[True][0])) and np.abs(results[True][0][:, :2]).max() > 1.0  # the sequences moved
+    # against the oracle's fuser, sweep by sweep order
+    po = mk_params(oracle)
+    for q in (0, 3):
+        fu = oracle.Fuser(po)
+        for t in range(8):
+            exp = fu.process_polar(streams[q][t])
+        got = results[True][0][q]
+        assert np.all(np.abs(got[:2] - exp[:2]) < POS_TOL) and abs(got[2] - exp[2]) < ROT_TOL, (q, got, exp)
 
 
 def _fuser_parity(oracle, imgs, A, R, **kw):

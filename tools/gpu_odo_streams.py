@@ -1,4 +1,4 @@
-# throughput of the batched odometry for different sub-batch stream settings: ODO_CFG="streams,split_filter,sequences;..."
+# throughput of the batched odometry with the filter one sweep ahead on its own stream or not: ODO_CFG="overlap,sequences;..."
 import ctypes as C, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -8,21 +8,18 @@ frames = int(os.environ.get('ODO_FRAMES', '30'))
 world = bench.make_streams(4, frames, 0)
 d_unique = torch.from_numpy(world).cuda()
 p = bench.params(capi)
-L = capi.lib()
-L.cfear_debug_set.argtypes = [C.c_int, C.c_int]
-for cfg in os.environ.get("ODO_CFG", "1,1,1024;2,1,1024;4,1,1024;4,0,1024;8,1,1024;8,1,2048").split(";"):
-    S, split, B = [int(v) for v in cfg.split(",")]
-    L.cfear_debug_set(3, S); L.cfear_debug_set(4, split)
+for cfg in os.environ.get("ODO_CFG", "0,1536;1,1536;0,768;1,768").split(";"):
+    S, B = [int(v) for v in cfg.split(",")]
     idx = torch.arange(B, device="cuda") % 4
     d_polar = d_unique[idx].permute(1, 0, 2, 3).contiguous()
     ctx = capi.Context(p, 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
-    odo = ctx.odometry(B)
+    odo = ctx.odometry(B, overlap=bool(S))
     for t in range(10):
         odo.step_device(d_polar[t].data_ptr())
-    torch.cuda.synchronize(); a = time.perf_counter()
+    ctx.synchronize(); torch.cuda.synchronize(); a = time.perf_counter()
     for t in range(10, frames):
         odo.step_device(d_polar[t].data_ptr())
-    torch.cuda.synchronize(); b = time.perf_counter()
-    print("streams %d split_filter %d sequences %d: %.0f scans/s (%.3f ms/step)" % (S, split, B, B * (frames - 10) / (b - a), (b - a) / (frames - 10) * 1e3), flush=True)
+    ctx.synchronize(); torch.cuda.synchronize(); b = time.perf_counter()
+    print("overlap %d sequences %d: %.0f scans/s (%.3f ms/step)" % (S, B, B * (frames - 10) / (b - a), (b - a) / (frames - 10) * 1e3), flush=True)
     odo.release(); del ctx, d_polar
     torch.cuda.empty_cache()

@@ -6,21 +6,19 @@ import bench
 torch.cuda.set_stream(torch.cuda.Stream())  # explicit stream shared with the library (handle 0 = torch's default stream would make the context create its own, unordered with torch)
 from cfear_radarodometry_code_public_amd import capi
 B = int(os.environ.get("ODO_B", "256")); frames = 16
-streams = bench.make_streams(4, frames, 0)
+U = int(os.environ.get('ODO_U', '4'))
+streams = bench.make_streams(U, frames, 0)
 d_unique = torch.from_numpy(streams).cuda()
-idx = torch.arange(B, device="cuda") % 4
+idx = torch.arange(B, device="cuda") % U
 p = bench.params(capi)
 ctx = capi.Context(p, 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
 odo = ctx.odometry(B)
-L = capi.lib()
-L.cfear_odometry_phase_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-L.cfear_odometry_phase_times(ctx.handle, odo._h, None)  # allocate
-buf = np.zeros((B, 32), dtype=np.int64)
+odo.phase_times(None)  # timed kernel instantiations from here on
 for t in range(frames):
     d = d_unique[idx, t].contiguous()
     odo.step_device(d)
     torch.cuda.synchronize()
-    L.cfear_odometry_phase_times(ctx.handle, odo._h, buf.ctypes.data)
+    buf = odo.phase_times(True)
     if t >= 12:
         ts = buf.astype(np.float64)
         acc = ts[:, 29:32].copy(); ts[:, 29:32] = 0

@@ -1,4 +1,4 @@
-# K1 (k-strongest) timing / tuning on the GPU box: interleaved A/B over (occ, oversub, dbg) settings
+# K1 (k-strongest) timing / tuning on the GPU box: interleaved A/B over (occupancy variant, rows per wave) settings
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfear_radarodometry_code_public_amd import capi, synth
@@ -6,8 +6,6 @@ A, R, k = 400, 3360, 12
 n = int(os.environ.get("K1_N", "256"))
 p = capi.default_params(range_res=np.float32(0.0595238))
 ctx = capi.Context(p, A, R)
-L = capi.lib()
-L.cfear_debug_set.argtypes = [ctypes.c_int, ctypes.c_int]
 data = {}
 data["uniform"] = torch.randint(0, 256, (n, A, R), dtype=torch.uint8, device="cuda")
 w = synth.World(1234)
@@ -15,15 +13,15 @@ base = torch.from_numpy(np.stack([synth.world_scan(w, t, seed=1) for t in range(
 data["world"] = base.repeat(n // 8, 1, 1).contiguous()
 out = torch.zeros((n, A, k), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-configs = [tuple(int(x) for x in c.split(",")) for c in os.environ.get("K1_CONFIGS", "6,1,0").split(";")]
+configs = [tuple(int(x) for x in c.split(",")) for c in os.environ.get("K1_CONFIGS", "7,4").split(";")]
 res = {}
 for rep in range(int(os.environ.get("K1_REPS", "5"))):
-    for (occ, over, dbg) in configs:
-        L.cfear_debug_set(0, dbg); L.cfear_debug_set(1, occ); L.cfear_debug_set(2, over)
+    for (occ, over) in configs:
+        ctx.tune(capi.TUNE_FILTER_OCCUPANCY, occ); ctx.tune(capi.TUNE_FILTER_ROWS_PER_WAVE, over)
         for name, d in data.items():
             t = ctx.time_kstrongest(d, n, out, 2, 10)
-            res.setdefault((occ, over, dbg, name), []).append(t)
+            res.setdefault((occ, over, name), []).append(t)
 for key, ts in res.items():
     t = min(ts)
-    print("occ=%d over=%d dbg=%d %-8s min %.1f us (med %.1f)  %.2f TB/s  %.0f scans/s" % (
-        key[0], key[1], key[2], key[3], t * 1e6, np.median(ts) * 1e6, n * (A * R + A * k * 4) / t / 1e12, n / t))
+    print("occ=%d rows/wave=%d %-8s min %.1f us (med %.1f)  %.2f TB/s  %.0f scans/s" % (
+        key[0], key[1], key[2], t * 1e6, np.median(ts) * 1e6, n * (A * R + A * k * 4) / t / 1e12, n / t))
