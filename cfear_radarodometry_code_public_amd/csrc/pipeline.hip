@@ -448,8 +448,9 @@ struct cfear_odometry {
   // of short dependent phases. With overlap on it runs on a stream of its own (sf) into the slot buffer of its parity;
   // features / registration follow on a second stream (so) once their slot buffer is written (ev_filt) and release it
   // when features has consumed it (ev_free). The host issues step t+1 while so still works on step t, so filter(t+1)
-  // fills the compute units that the last rounds of registration(t) leave idle. The context stream joins in the
-  // reading calls (odo_join). With overlap off the three kernels run in turn on the context stream.
+  // can start on compute units that the last rounds of registration(t) leave idle. The context stream joins in the
+  // reading calls (odo_join). With overlap off (the default, see DESIGN.md: the three kernels want the same registers and
+  // LDS of a compute unit, so running them side by side stretches all of them) they run in turn on the context stream.
   int overlap = 0;
   long long step_no = 0;
   hipStream_t sf = nullptr, so = nullptr;
@@ -1069,6 +1070,9 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (o->overlap) {
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_filt[buf], sf));
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(so, o->ev_filt[buf], 0));
+    // d_polar keeps its stream-order meaning for the caller: whatever the context stream is given after this call (the
+    // caller's next write into the buffer, its release to a caching allocator) waits for the filter, the only reader
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_filt[buf], 0));
   }
   if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
   if (o->d_phase_times)

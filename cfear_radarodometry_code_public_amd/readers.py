@@ -1,8 +1,8 @@
 """Dataset readers - host-side I/O in front of the accelerated path, no third-party packages.
 
 * ``BagReader``: rosbag v2.0 files, the input of the reference's offline harness (offline_odometry.cpp:64-68: topics
-  /Navtech/Polar (sensor_msgs/Image, mono8) and /gt (nav_msgs/Odometry)). Chunks may be uncompressed or bz2 (lz4 needs
-  a module this environment lacks and is reported as such).
+  /Navtech/Polar (sensor_msgs/Image, mono8) and /gt (nav_msgs/Odometry)). Chunks may be uncompressed, bz2 or lz4 (LZ4 frames decoded
+  by a block decoder written here: the image carries no lz4 module).
 * ``read_oxford_png``: one sweep of the Oxford Radar RobotCar dataset in its native PNG layout (one row per azimuth:
   8 bytes timestamp, 2 bytes encoder count, 1 byte valid flag, then the power readings) - the format the reference's
   README lists as future work.
@@ -128,6 +128,134 @@ def oxford_png_rows(polar, timestamps=None, encoder=None, valid=None):
 # ---------------------------------------------------------------------------------------------------------------
 # rosbag v2.0
 # ---------------------------------------------------------------------------------------------------------------
+# LZ4 frame format (rosbag "lz4" chunks are roslz4 streams = LZ4 frames, magic 0x184D2204), standard library only.
+# ---------------------------------------------------------------------------------------------------------------
+_LZ4_MAGIC = 0x184D2204
+
+
+def lz4_block_decompress(src, max_out=None):
+    """one LZ4 block (sequences of literals + matches) -> bytes"""
+    out = bytearray()
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]; i += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                b = src[i]; i += 1
+                ll += b
+                if b != 255:
+                    break
+        if i + ll > n:
+            raise ValueError("lz4: literal run past the end of the block")
+        out += src[i:i + ll]; i += ll
+        if i >= n:
+            break  # the last sequence has literals only
+        off = src[i] | (src[i + 1] << 8); i += 2
+        if off == 0 or off > len(out):
+            raise ValueError("lz4: bad match offset")
+        ml = (tok & 15) + 4
+        if (tok & 15) == 15:
+            while True:
+                b = src[i]; i += 1
+                ml += b
+                if b != 255:
+                    break
+        start = len(out) - off
+        if off >= ml:
+            out += out[start:start + ml]
+        else:  # overlapping match: the pattern of `off` bytes repeats
+            pat = bytes(out[start:])
+            out += (pat * (ml // off + 1))[:ml]
+        if max_out is not None and len(out) > max_out:
+            raise ValueError("lz4: block larger than announced")
+    return bytes(out)
+
+
+def lz4_frame_decompress(data):
+    """LZ4 frame (possibly several, concatenated) -> bytes. Checksums are skipped, not verified."""
+    out, i, n = [], 0, len(data)
+    while i + 4 <= n:
+        magic, = struct.unpack_from("<I", data, i); i += 4
+        if 0x184D2A50 <= magic <= 0x184D2A5F:  # skippable frame
+            sz, = struct.unpack_from("<I", data, i); i += 4 + sz
+            continue
+        if magic != _LZ4_MAGIC:
+            raise ValueError("not an LZ4 frame (magic %08x)" % magic)
+        flg, bd = data[i], data[i + 1]; i += 2
+        if (flg >> 6) != 1:
+            raise ValueError("lz4 frame version %d" % (flg >> 6))
+        block_checksum, content_size, content_checksum, dict_id = (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+        block_max = {4: 1 << 16, 5: 1 << 18, 6: 1 << 20, 7: 1 << 22}.get((bd >> 4) & 7)
+        if block_max is None:
+            raise ValueError("lz4 frame: bad block size code")
+        i += 8 * content_size + 4 * dict_id + 1  # + header checksum byte
+        if not (flg >> 5) & 1:
+            raise NotImplementedError("lz4 frame with linked blocks")  # roslz4 writes independent blocks
+        while True:
+            sz, = struct.unpack_from("<I", data, i); i += 4
+            if sz == 0:
+                break
+            raw = sz >> 31
+            sz &= 0x7FFFFFFF
+            blk = data[i:i + sz]; i += sz + 4 * block_checksum
+            out.append(bytes(blk) if raw else lz4_block_decompress(blk, block_max))
+        i += 4 * content_checksum
+    return b"".join(out)
+
+
+def lz4_block_compress(src):
+    """greedy hash-chain-free LZ4 block compressor (fixtures: produces literal runs, matches and overlapping matches)"""
+    n, out, anchor, i, table = len(src), bytearray(), 0, 0, {}
+
+    def emit(lit_end, mlen, off):
+        ll = lit_end - anchor
+        tok_l = 15 if ll >= 15 else ll
+        tok_m = 0 if mlen == 0 else (15 if mlen - 4 >= 15 else mlen - 4)
+        out.append((tok_l << 4) | tok_m)
+        if ll >= 15:
+            r = ll - 15
+            while r >= 255:
+                out.append(255); r -= 255
+            out.append(r)
+        out.extend(src[anchor:lit_end])
+        if mlen:
+            out.append(off & 255); out.append(off >> 8)
+            if mlen - 4 >= 15:
+                r = mlen - 4 - 15
+                while r >= 255:
+                    out.append(255); r -= 255
+                out.append(r)
+    while i + 12 < n:  # the last 12 bytes are literals (end-of-block rules)
+        key = bytes(src[i:i + 4])
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand <= 65535:
+            m = 4
+            while i + m < n - 5 and src[cand + m] == src[i + m]:
+                m += 1
+            emit(i, m, i - cand)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    emit(n, 0, 0)
+    return bytes(out)
+
+
+def lz4_frame_compress(data, block_size=1 << 22):
+    """LZ4 frame with independent 4 MB blocks, no checksums (the header checksum byte is not verified by readers here;
+    0 is written) -- fixtures only"""
+    out = [struct.pack("<IBBB", _LZ4_MAGIC, 0x60, 0x70, 0)]
+    for a in range(0, len(data), block_size):
+        raw = data[a:a + block_size]
+        c = lz4_block_compress(raw)
+        out.append(struct.pack("<I", len(c)) + c if len(c) < len(raw) else struct.pack("<I", len(raw) | 0x80000000) + bytes(raw))
+    out.append(struct.pack("<I", 0))
+    return b"".join(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 _BAG_MAGIC = b"#ROSBAG V2.0\n"
 OP_MSG, OP_BAG_HEADER, OP_INDEX, OP_CHUNK, OP_CHUNK_INFO, OP_CONNECTION = 2, 3, 4, 5, 6, 7
 
@@ -214,8 +342,10 @@ class BagReader:
     """Iterates (topic, datatype, time_ns, raw message bytes) in file order; ``topics`` filters like rosbag::TopicQuery."""
 
     def __init__(self, path):
-        self.buf = open(path, "rb").read()
-        if not self.buf.startswith(_BAG_MAGIC):
+        import mmap
+        self._fh = open(path, "rb")
+        self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)  # recordings are tens of GB: map, do not read
+        if self.buf[:len(_BAG_MAGIC)] != _BAG_MAGIC:
             raise ValueError("not a rosbag v2.0 file")
         self.connections = {}
 
@@ -236,8 +366,13 @@ class BagReader:
                     body = data
                 elif comp == "bz2":
                     body = bz2.decompress(data)
+                elif comp == "lz4":
+                    body = lz4_frame_decompress(data)
+                    want, = struct.unpack("<I", hdr["size"])
+                    if len(body) != want:
+                        raise ValueError("lz4 chunk: %d bytes after decompression, header says %d" % (len(body), want))
                 else:
-                    raise NotImplementedError("rosbag chunk compression '%s' (only none and bz2 are supported here)" % comp)
+                    raise NotImplementedError("rosbag chunk compression '%s' (none, bz2 and lz4 are supported)" % comp)
                 for h2, d2 in _records(body):
                     op2 = h2["op"][0]
                     if op2 == OP_CONNECTION:
@@ -270,11 +405,13 @@ def polar_image(msg, dataset="oxford"):
 
 
 class BagWriter:
-    """minimal rosbag v2.0 writer (fixtures): one chunk per flush, compression none or bz2, no index records."""
+    """minimal rosbag v2.0 writer (fixtures): a chunk is closed when it passes chunk_threshold bytes (rosbag's default is
+    768 KiB) or at flush(); compression none, bz2 or lz4; no index records."""
 
-    def __init__(self, path, compression="none"):
+    def __init__(self, path, compression="none", chunk_threshold=768 * 1024):
         self.fh = open(path, "wb")
         self.compression = compression
+        self.chunk_threshold, self.chunk_bytes = chunk_threshold, 0
         self.conns, self.chunk, self.nchunks = {}, [], 0
         self.fh.write(_BAG_MAGIC)
         hdr = self._header({"op": bytes([OP_BAG_HEADER]), "index_pos": struct.pack("<Q", 0), "conn_count": struct.pack("<I", 0), "chunk_count": struct.pack("<I", 0)})
@@ -301,12 +438,16 @@ class BagWriter:
             self.chunk.append(self._record({"op": bytes([OP_CONNECTION]), "conn": struct.pack("<I", cid), "topic": topic.encode()}, info))
         sec, nsec = divmod(int(time_ns), 1000000000)
         self.chunk.append(self._record({"op": bytes([OP_MSG]), "conn": struct.pack("<I", self.conns[topic]), "time": struct.pack("<II", sec, nsec)}, data))
+        self.chunk_bytes += len(self.chunk[-1])
+        if self.chunk_bytes >= self.chunk_threshold:
+            self.flush()
 
     def flush(self):
         if not self.chunk:
             return
         body = b"".join(self.chunk)
-        comp = bz2.compress(body) if self.compression == "bz2" else body
+        comp = bz2.compress(body) if self.compression == "bz2" else (lz4_frame_compress(body) if self.compression == "lz4" else body)
+        self.chunk_bytes = 0
         self.fh.write(self._record({"op": bytes([OP_CHUNK]), "compression": self.compression.encode(), "size": struct.pack("<I", len(body))}, comp))
         self.chunk, self.nchunks = [], self.nchunks + 1
 

@@ -55,11 +55,13 @@ def main(argv=None):
     ap.add_argument("--disable_compensate", type=int, default=0)
     ap.add_argument("--registered_min_keyframe_dist", type=float, default=1.5)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--trace", action="store_true",
+                    help="keep per-sweep poses, Register summaries (outer / inner iteration counts, residuals), keyframe and cell counts in the result")
     args = ap.parse_args(argv)
     cost = {"P2P": 0, "P2L": 1, "P2D": 2}[args.cost_type]
     loss = {"None": 0, "Huber": 1, "Cauchy": 2, "SoftLOne": 3, "Combined": 4, "Tukey": 5}[args.loss_type]
     ctx = odo = None
-    est, gts, n = [], [], 0
+    est, gts, n, trace = [], [], 0, []
     first_gt = None
     for kind, t, payload in sweeps(args):
         if kind == "gt":
@@ -79,6 +81,11 @@ def main(argv=None):
             odo = ctx.odometry(1)
         odo.step_host(img[None])
         est.append(odo.poses()[0].copy())
+        if args.trace:
+            S, nc, nk = odo.summary(0)
+            no = min(max(S.outer_iterations, 0), 64)
+            trace.append({"outer": int(S.outer_iterations), "inner": [int(v) for v in S.inner_iterations[:no]], "residuals": int(S.num_residuals),
+                          "final_cost": float(S.final_cost), "keyframes": int(nk), "cells": int(nc)})
         n += 1
         if args.max_frames and n >= args.max_frames:
             break
@@ -95,6 +102,9 @@ def main(argv=None):
         kitti.write_kitti(os.path.join(gdir, "gt_00.txt"), gts[:m])
         out["drift"] = kitti.drift(np.array(gts[:m]), est_T[:m])
     print(json.dumps(out))
+    if args.trace:
+        out["poses"] = np.array(est)
+        out["trace"] = trace
     odo.release()
     ctx.close()
     return out

@@ -122,55 +122,80 @@ def world_sequence(T, A=400, R=3360, range_res=np.float32(0.0595238), seed=0, wo
     return imgs, np.asarray(gts)
 
 
-def _stream_file(cache_dir, seed, T, A, R, range_res, ccw):
-    return "%s/cfear_world_s%d_T%d_%dx%d_r%08x_c%d.npy" % (cache_dir, seed, T, A, R, np.float32(range_res).view(np.uint32), int(ccw))
+def _stream_file(cache_dir, seed, T, A, R, range_res, ccw, t0=None):
+    tag = "" if t0 is None else "_t%d" % t0
+    return "%s/cfear_world_s%d%s_T%d_%dx%d_r%08x_c%d.npy" % (cache_dir, seed, tag, T, A, R, np.float32(range_res).view(np.uint32), int(ccw))
 
 
 def _stream_worker(job):
-    path, seed, T, A, R, range_res, ccw = job
-    imgs, _ = world_sequence(T, A, R, np.float32(range_res), seed=seed, world_seed=1234 + seed, ccw=bool(ccw), t0=17 * (seed % 64))
+    path, seed, T, A, R, range_res, ccw, t0, world_seed = job
+    imgs, _ = world_sequence(T, A, R, np.float32(range_res), seed=seed, world_seed=world_seed, ccw=bool(ccw), t0=t0)
     tmp = "%s.%d.tmp.npy" % (path, os.getpid())
     np.save(tmp, imgs)
     os.replace(tmp, path)  # atomic: several ranks may want the same stream
     return path
 
 
-def world_streams(seeds, T, A=400, R=3360, range_res=np.float32(0.0595238), ccw=True, procs=None, cache_dir=None):
-    """uint8 [len(seeds), T, A, R]: one world sequence per seed (own world, own start point on the path), generated by
-    worker processes (fresh interpreters: `python -m ...synth --gen`; one sweep costs ~50 ms of one core) and cached as
-    .npy files so that the next run maps them back in."""
+def _run_jobs(jobs, procs):
+    """jobs of _stream_worker in fresh interpreters (`python -m ...synth --gen`), at most `procs` at a time"""
     import subprocess
     import sys
-    cache_dir = cache_dir or os.environ.get("CFEAR_SYNTH_CACHE", "/tmp/cfear_synth_cache")
-    os.makedirs(cache_dir, exist_ok=True)
-    files = [_stream_file(cache_dir, s, T, A, R, range_res, ccw) for s in seeds]
-    jobs = [(f, s, T, A, R, float(range_res), int(ccw)) for f, s in zip(files, seeds) if not os.path.exists(f)]
     n = max(1, min(len(jobs), procs or len(os.sched_getaffinity(0))))
     if len(jobs) == 1 or n == 1:
         for j in jobs:
             _stream_worker(j)
-    elif jobs:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-        running, todo = [], list(jobs)
-        while todo or running:
-            while todo and len(running) < n:
-                j = todo.pop()
-                running.append(subprocess.Popen([sys.executable, "-m", "cfear_radarodometry_code_public_amd.synth", "--gen"] + [str(x) for x in j],
-                                                cwd=root, env=env))
-            p = running.pop(0)
-            if p.wait(timeout=3600) != 0:
-                for q in running:
-                    q.kill()
-                raise RuntimeError("synthetic stream worker failed")
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    running, todo = [], list(jobs)
+    while todo or running:
+        while todo and len(running) < n:
+            j = todo.pop()
+            running.append(subprocess.Popen([sys.executable, "-m", "cfear_radarodometry_code_public_amd.synth", "--gen"] + [str(x) for x in j],
+                                            cwd=root, env=env))
+        p = running.pop(0)
+        if p.wait(timeout=3600) != 0:
+            for q in running:
+                q.kill()
+            raise RuntimeError("synthetic stream worker failed")
+
+
+def world_streams(seeds, T, A=400, R=3360, range_res=np.float32(0.0595238), ccw=True, procs=None, cache_dir=None):
+    """uint8 [len(seeds), T, A, R]: one world sequence per seed (own world, own start point on the path), generated by
+    worker processes (one sweep costs ~50 ms of one core) and cached as .npy files so that the next run maps them back in."""
+    cache_dir = cache_dir or os.environ.get("CFEAR_SYNTH_CACHE", "/tmp/cfear_synth_cache")
+    os.makedirs(cache_dir, exist_ok=True)
+    files = [_stream_file(cache_dir, s, T, A, R, range_res, ccw) for s in seeds]
+    jobs = [(f, s, T, A, R, float(range_res), int(ccw), 17 * (s % 64), 1234 + s) for f, s in zip(files, seeds) if not os.path.exists(f)]
+    _run_jobs(jobs, procs)
     out = np.empty((len(seeds), T, A, R), dtype=np.uint8)
     for i, f in enumerate(files):
         out[i] = np.load(f, mmap_mode="r")
     return out
 
 
+def world_sequence_long(T, A=400, R=3360, range_res=np.float32(0.0595238), seed=0, world_seed=1234, ccw=False, t0=0, chunk=25,
+                        procs=None, cache_dir=None):
+    """world_sequence for long runs: the same sweeps and ground truth, generated in chunks of frames by worker processes.
+    Returns (list of read-only [<=chunk, A, R] arrays, ground-truth poses [T, 3])."""
+    cache_dir = cache_dir or os.environ.get("CFEAR_SYNTH_CACHE", "/tmp/cfear_synth_cache")
+    os.makedirs(cache_dir, exist_ok=True)
+    starts = list(range(0, T, chunk))
+    files = [_stream_file(cache_dir, seed * 100003 + world_seed, min(chunk, T - a), A, R, range_res, ccw, t0=t0 + a) for a in starts]
+    jobs = [(f, seed, min(chunk, T - a), A, R, float(range_res), int(ccw), t0 + a, world_seed) for f, a in zip(files, starts) if not os.path.exists(f)]
+    _run_jobs(jobs, procs)
+    g0 = gt_pose(t0)
+    c, s = np.cos(g0[2]), np.sin(g0[2])
+    gts = []
+    for t in range(T):
+        g = gt_pose(t0 + t)
+        d = g[:2] - g0[:2]
+        gts.append([c * d[0] + s * d[1], -s * d[0] + c * d[1], g[2] - g0[2]])
+    return [np.load(f, mmap_mode="r") for f in files], np.asarray(gts)
+
+
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) == 9 and sys.argv[1] == "--gen":
+    if len(sys.argv) == 11 and sys.argv[1] == "--gen":
         a = sys.argv[2:]
-        _stream_worker((a[0], int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]), int(a[6])))
+        _stream_worker((a[0], int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]), int(a[6]), int(a[7]), int(a[8])))

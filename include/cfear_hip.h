@@ -78,8 +78,8 @@ int cfear_synchronize(cfear_ctx* ctx);
 /* Launch-shape knobs of a context (tuning; an integration never needs them, tools/ and bench.py do). Results do not depend on
  * them. FILTER_OCCUPANCY: 5..7 filter waves per SIMD (default 7); FILTER_ROWS_PER_WAVE: consecutive azimuths walked by one
  * filter wave (default 4); ODOMETRY_OVERLAP: batched odometry objects created afterwards run the filter of a sweep on a stream
- * of their own, one sweep ahead of the features / registration kernels (default 1; 0 = the three kernels strictly in turn on
- * the context stream). */
+ * of their own, one sweep ahead of the features / registration kernels (1; default 0 = the three kernels strictly in turn on
+ * the context stream, which measured faster: DESIGN.md). */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
@@ -216,11 +216,11 @@ typedef struct cfear_odometry cfear_odometry;
 int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** odo);
 void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* odo);
 int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* odo);
-/* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous: the sweeps must be ready at this
- * point of the context stream; the work itself runs on two internal streams (the filter of sweep t+1 may run beside
- * the features / registration kernels of sweep t) that the context stream joins only in the reading calls below
- * (poses / summary / profile_read / reset) and in cfear_synchronize(). Keep d_polar valid and unmodified until one
- * of those has returned. */
+/* d_polar: n_sequences contiguous A*R uint8 sweeps on the device. Asynchronous and stream-ordered for the input: the sweeps
+ * must be ready at this point of the context stream, and work given to the context stream afterwards (the next write into
+ * d_polar) runs after the filter has read it. With CFEAR_TUNE_ODOMETRY_OVERLAP the kernels run on two internal streams (the
+ * filter of sweep t+1 beside the features / registration kernels of sweep t) that the context stream joins for the results only
+ * in the reading calls below (poses / summary / profile_read / reset) and in cfear_synchronize(). */
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_polar);
 /* Same from a host buffer (n_sequences * A * R bytes): the sweeps are copied to a staging buffer on the device; the call
  * returns when that copy has completed (h_polar may be reused or freed at once), the kernels run asynchronously as above. */
