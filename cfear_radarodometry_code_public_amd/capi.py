@@ -62,7 +62,7 @@ EXPORTS = [
     "cfear_set_params", "cfear_synchronize", "cfear_tune", "cfear_kstrongest_device", "cfear_kstrongest_host",
     "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
-    "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
+    "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
@@ -111,6 +111,7 @@ def lib():
         "cfear_cloud_release": (None, [vp, vp]),
         "cfear_compensate": (C.c_int, [vp, vp, f64p, C.c_int]),
         "cfear_scan_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+        "cfear_scan_from_cells": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
         "cfear_scan_release": (None, [vp, vp]),
         "cfear_scan_size": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
         "cfear_scan_download_cells": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(C.c_int)]),
@@ -276,6 +277,13 @@ class Context:
     def scan_create(self, cloud):
         s = C.c_void_p()
         self._check(self._L.cfear_scan_create(self._h, cloud._h, C.byref(s)), "cfear_scan_create")
+        return Scan(self, s)
+
+    def scan_from_cells(self, cells):
+        """cells: numpy array of CELL_DTYPE (raw = true identity cells, transformed copies) -> Scan"""
+        cells = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+        s = C.c_void_p()
+        self._check(self._L.cfear_scan_from_cells(self._h, cells.ctypes.data, len(cells), C.byref(s)), "cfear_scan_from_cells")
         return Scan(self, s)
 
     # ---- stage 3 (n_scan_normal_reg::Register) ----

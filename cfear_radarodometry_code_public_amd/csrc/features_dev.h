@@ -343,6 +343,127 @@ __device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, i
   }
 }
 
+// ComputeSearchTreeFromCells (pointnormal.cpp:151-162): uniform grid over the float cell means of the nc cells already in
+// S (cells / mean_f / rsrc / rtar written by the caller). Block-collective; lm_ok: the float means also sit in the LDS copy
+// the feature epilogue left in W.vlist.
+__device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc, const FeatureParams& P, const FeatureScratch& W,
+                                                bool lm_ok, PhaseTimer* pt) {
+  typedef __attribute__((address_space(1))) float g_f32;
+  typedef __attribute__((address_space(1))) int g_i32;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
+  // the cell means come from the LDS copy the epilogue left in the voxel-list array when they fit (no read-back from memory)
+  const auto* lmr = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  g_f32* const g_mean = (g_f32*)S->mean_f;
+  g_i32* const g_gstart = (g_i32*)S->gstart;
+  __attribute__((address_space(1))) f32x4* const g_gpts = (__attribute__((address_space(1))) f32x4*)S->gpts;
+  __attribute__((address_space(1))) u32x2* const g_rows3 = (__attribute__((address_space(1))) u32x2*)grid_rows3(S->gstart);
+  float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
+  for (int i = tid; i < nc; i += nt) {
+    const float x = lm_ok ? lmr[2 * i] : g_mean[2 * i], y = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
+    gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
+  }
+  { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
+  if (nc == 0) {
+    if (tid == 0) { S->gw = 0; S->gh = 0; S->gcell = 1.f; S->gminx = 0.f; S->gminy = 0.f; }
+    __syncthreads();
+    return;
+  }
+  float gcell = (float)(2.0 * P.assoc_radius);
+  int gw, gh;
+  for (;;) {
+    gw = (int)floorf((gx1 - gx0) / gcell) + 1;
+    gh = (int)floorf((gy1 - gy0) / gcell) + 1;
+    if ((long long)gw * gh <= S->cap_grid) break;
+    gcell *= 2.f;
+  }
+  const int G = gw * gh;
+  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets, grid_rows3): the association reads
+  // the bounds of its whole window with two loads
+  bool rows3_done = false;
+  if (W.lds && G + 1 <= W.tab_voxels / 2) {
+    // bucket counters / cursors in LDS (the key region: the staged points are not needed any more)
+    int* gc = reinterpret_cast<int*>(W.keys);
+    for (int g = tid; g <= G; g += nt) gc[g] = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += nt) {
+      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
+      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
+      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+      atomicAdd(&gc[cy * gw + cx + 1], 1);
+    }
+    __syncthreads();
+    {
+      const int ipt = (G + nt - 1) / nt;
+      const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
+      int cnt = 0;
+      for (int g = i0; g < i1; g++) cnt += gc[g + 1];
+      int tot;
+      int o = block_exclusive_scan(cnt, W.red_i, &tot);
+      // a copy of the offsets stays in LDS for the three-row records below when the key region has room for it
+      int* gl = gc + (G + 1);
+      rows3_done = 2 * (G + 1) <= W.tab_voxels / 2;
+      for (int g = i0; g < i1; g++) {  // cursor / end offset
+        const int c = gc[g + 1]; gc[g + 1] = o; g_gstart[g + 1] = o + c; o += c;
+        if (rows3_done) gl[g + 1] = o;
+      }
+      if (tid == 0) { g_gstart[0] = 0; if (rows3_done) gl[0] = 0; }
+      __syncthreads();
+      if (rows3_done) {
+        for (int g = tid; g <= G; g += nt) {
+          const unsigned a = (unsigned)gl[g], b = (unsigned)gl[min(g + gw, G)], c = (unsigned)gl[min(g + 2 * gw, G)];
+          g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
+        }
+      }
+    }
+    for (int i = tid; i < nc; i += nt) {
+      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
+      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
+      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+      const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
+      g_gpts[pos] = f32x4{mx, my, __int_as_float(i), 0.f};
+    }
+  } else {
+  for (int g = tid; g <= G; g += nt) g_gstart[g] = 0;
+  __syncthreads();
+  for (int i = tid; i < nc; i += nt) {
+    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
+    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+    atomicAdd(&S->gstart[cy * gw + cx + 1], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan of the bucket counts (gstart[g+1] holds count of bucket g)
+    const int ipt = (G + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
+    int cnt = 0;
+    for (int g = i0; g < i1; g++) cnt += g_gstart[g + 1];
+    int tot;
+    int o = block_exclusive_scan(cnt, W.red_i, &tot);
+    for (int g = i0; g < i1; g++) { const int c = g_gstart[g + 1]; W.vcur[g] = o; g_gstart[g + 1] = o + c; o += c; }
+    __syncthreads();
+  }
+  // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query breaks
+  // exact ties by cell index)
+  for (int i = tid; i < nc; i += nt) {
+    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
+    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
+    const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
+    g_gpts[pos] = f32x4{g_mean[2 * i], g_mean[2 * i + 1], __int_as_float(i), 0.f};
+  }
+  }
+  if (!rows3_done) {  // from the offsets in global memory (final at the barrier before the scatter)
+    for (int g = tid; g <= G; g += nt) {
+      const unsigned a = (unsigned)g_gstart[g], b = (unsigned)g_gstart[min(g + gw, G)], c = (unsigned)g_gstart[min(g + 2 * gw, G)];
+      g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
+    }
+  }
+  if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
+  __syncthreads();
+  if (pt) pt->mark();
+}
+
 // MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi.
 // p2 = power of two >= n with p2 <= capacity of W.keys.
 __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2,
@@ -726,119 +847,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   if (pt) pt->mark();
   if (pt) pt->mark();
-  // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
-  const int nc = n_cells_out;
-  // the cell means come from the LDS copy the epilogue left in the voxel-list array when they fit (no read-back from memory)
-  const bool lm_ok = W.lds && nc <= CFEAR_LDS_POINT_CAP / 2;  // block-uniform
-  const auto* lmr = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  g_f32* const g_mean = (g_f32*)S->mean_f;
-  g_i32* const g_gstart = (g_i32*)S->gstart;
-  __attribute__((address_space(1))) f32x4* const g_gpts = (__attribute__((address_space(1))) f32x4*)S->gpts;
-  __attribute__((address_space(1))) u32x2* const g_rows3 = (__attribute__((address_space(1))) u32x2*)grid_rows3(S->gstart);
-  float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
-  for (int i = tid; i < nc; i += nt) {
-    const float x = lm_ok ? lmr[2 * i] : g_mean[2 * i], y = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
-    gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
-  }
-  { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
-  if (nc == 0) {
-    if (tid == 0) { S->gw = 0; S->gh = 0; S->gcell = 1.f; S->gminx = 0.f; S->gminy = 0.f; }
-    __syncthreads();
-    return;
-  }
-  float gcell = (float)(2.0 * P.assoc_radius);
-  int gw, gh;
-  for (;;) {
-    gw = (int)floorf((gx1 - gx0) / gcell) + 1;
-    gh = (int)floorf((gy1 - gy0) / gcell) + 1;
-    if ((long long)gw * gh <= S->cap_grid) break;
-    gcell *= 2.f;
-  }
-  const int G = gw * gh;
-  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets, grid_rows3): the association reads
-  // the bounds of its whole window with two loads
-  bool rows3_done = false;
-  if (W.lds && G + 1 <= W.tab_voxels / 2) {
-    // bucket counters / cursors in LDS (the key region: the staged points are not needed any more)
-    int* gc = reinterpret_cast<int*>(W.keys);
-    for (int g = tid; g <= G; g += nt) gc[g] = 0;
-    __syncthreads();
-    for (int i = tid; i < nc; i += nt) {
-      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
-      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
-      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-      atomicAdd(&gc[cy * gw + cx + 1], 1);
-    }
-    __syncthreads();
-    {
-      const int ipt = (G + nt - 1) / nt;
-      const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
-      int cnt = 0;
-      for (int g = i0; g < i1; g++) cnt += gc[g + 1];
-      int tot;
-      int o = block_exclusive_scan(cnt, W.red_i, &tot);
-      // a copy of the offsets stays in LDS for the three-row records below when the key region has room for it
-      int* gl = gc + (G + 1);
-      rows3_done = 2 * (G + 1) <= W.tab_voxels / 2;
-      for (int g = i0; g < i1; g++) {  // cursor / end offset
-        const int c = gc[g + 1]; gc[g + 1] = o; g_gstart[g + 1] = o + c; o += c;
-        if (rows3_done) gl[g + 1] = o;
-      }
-      if (tid == 0) { g_gstart[0] = 0; if (rows3_done) gl[0] = 0; }
-      __syncthreads();
-      if (rows3_done) {
-        for (int g = tid; g <= G; g += nt) {
-          const unsigned a = (unsigned)gl[g], b = (unsigned)gl[min(g + gw, G)], c = (unsigned)gl[min(g + 2 * gw, G)];
-          g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
-        }
-      }
-    }
-    for (int i = tid; i < nc; i += nt) {
-      const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
-      int cx = (int)floorf((mx - gx0) / gcell), cy = (int)floorf((my - gy0) / gcell);
-      cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-      const int pos = atomicAdd(&gc[cy * gw + cx + 1], 1);
-      g_gpts[pos] = f32x4{mx, my, __int_as_float(i), 0.f};
-    }
-  } else {
-  for (int g = tid; g <= G; g += nt) g_gstart[g] = 0;
-  __syncthreads();
-  for (int i = tid; i < nc; i += nt) {
-    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
-    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-    atomicAdd(&S->gstart[cy * gw + cx + 1], 1);
-  }
-  __syncthreads();
-  {  // exclusive scan of the bucket counts (gstart[g+1] holds count of bucket g)
-    const int ipt = (G + nt - 1) / nt;
-    const int i0 = tid * ipt, i1 = min(G, i0 + ipt);
-    int cnt = 0;
-    for (int g = i0; g < i1; g++) cnt += g_gstart[g + 1];
-    int tot;
-    int o = block_exclusive_scan(cnt, W.red_i, &tot);
-    for (int g = i0; g < i1; g++) { const int c = g_gstart[g + 1]; W.vcur[g] = o; g_gstart[g + 1] = o + c; o += c; }
-    __syncthreads();
-  }
-  // scatter cell indices into their buckets (order inside a bucket is irrelevant: the query breaks
-  // exact ties by cell index)
-  for (int i = tid; i < nc; i += nt) {
-    int cx = (int)floorf((g_mean[2 * i] - gx0) / gcell), cy = (int)floorf((g_mean[2 * i + 1] - gy0) / gcell);
-    cx = min(max(cx, 0), gw - 1); cy = min(max(cy, 0), gh - 1);
-    const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
-    g_gpts[pos] = f32x4{g_mean[2 * i], g_mean[2 * i + 1], __int_as_float(i), 0.f};
-  }
-  }
-  if (!rows3_done) {  // from the offsets in global memory (final at the barrier before the scatter)
-    for (int g = tid; g <= G; g += nt) {
-      const unsigned a = (unsigned)g_gstart[g], b = (unsigned)g_gstart[min(g + gw, G)], c = (unsigned)g_gstart[min(g + 2 * gw, G)];
-      g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
-    }
-  }
-  if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
-  __syncthreads();
-  if (pt) pt->mark();
+  cell_grid_block(S, n_cells_out, P, W, W.lds && n_cells_out <= CFEAR_LDS_POINT_CAP / 2, pt);
 }
 
 // GetClosestIdx (pointnormal.cpp:238-254): 1-NN over the float cell means, accepted iff d2 < d*d.

@@ -151,6 +151,25 @@ __global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const flo
   features_dispatch(S, n, P, B, lds, nullptr);
 }
 
+// MapPointNormal from given cells (raw = true identity cells, pointnormal.cpp:76-82; the transformed-copy constructor
+// :91-110): the cells are already in S->cells; this writes their float means, the registration views and the search grid
+__global__ __launch_bounds__(BLOCK_F) void scan_from_cells_kernel(ScanDev* S, int n, FeatureParams P, BlockScratch B) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::keys];  // the two reduction arrays
+  const FeatureScratch W = make_fscratch<false>(B, lds);
+  const size_t cc = (size_t)S->cap_cells;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const cfear_cell c = S->cells[i];
+    S->mean_f[2 * i] = (float)c.mean[0]; S->mean_f[2 * i + 1] = (float)c.mean[1];
+    double* rs = S->rsrc + i;
+    rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1]; rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
+    double* rt = S->rtar + 8 * (size_t)i;
+    rt[0] = c.mean[0]; rt[1] = c.mean[1]; rt[2] = c.normal[0]; rt[3] = c.normal[1]; rt[4] = (double)c.nsamples; rt[5] = c.scale;
+  }
+  if (threadIdx.x == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = n; S->status = n > 0 ? 0 : CFEAR_ERR_EMPTY; }
+  __syncthreads();
+  cell_grid_block(S, n, P, W, false, nullptr);
+}
+
 __global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nq) idx[i] = scan_closest(grid_view(S), q[2 * i], q[2 * i + 1], d);
@@ -644,6 +663,34 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
     delete s;
     return cfear_fail(ctx, CFEAR_ERR_EMPTY, "scan_create: empty cloud (reference: 'error, cloud empty' + exit)");
   }
+  *scan = s;
+  return CFEAR_OK;
+}
+
+int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_scan** scan) {
+  if (!ctx || !scan || n < 0 || (n > 0 && !cells)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_from_cells: bad argument");
+  if (n >= (1 << 24)) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "scan_from_cells: more than 2^24 cells");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *scan = nullptr;
+  if (n == 0) return cfear_fail(ctx, CFEAR_ERR_EMPTY, "scan_from_cells: no cells (reference: 'error, cloud empty' + exit)");
+  const int base = ctx->A * ctx->par.k_strongest, capmax = n > base ? n : base;
+  int rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
+  if (rc != CFEAR_OK) return rc;
+  cfear_scan* s = new (std::nothrow) cfear_scan();
+  if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
+  s->cap_points = n;
+  const ScanLayout L = scan_layout(n);
+  if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
+  const ScanDev h = scan_header(s->d_block, n);
+  hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(s->d_block + L.cells, cells, sizeof(cfear_cell) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
+    hipLaunchKernelGGL(scan_from_cells_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), n, feature_params(ctx), B);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h and the caller's cells are read until here
+  if (e != hipSuccess) { (void)hipFree(s->d_block); delete s; return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_from_cells", e); }
   *scan = s;
   return CFEAR_OK;
 }

@@ -19,33 +19,44 @@ int main(int argc, char** argv) {
   for (;;) { std::vector<uint8_t> img((size_t)A * R); if (!in.read(reinterpret_cast<char*>(img.data()), (std::streamsize)img.size())) break; imgs.push_back(img); }
   if (imgs.size() < 3) { std::fprintf(stderr, "need three sweeps\n"); return 2; }
   try {
-    cfear_params p; cfear_default_params(&p);
-    DevicePtr dev(new Device(p, A, R, 0));
+    // reference-signature constructors throughout (radar_driver.h:86, pointnormal.h:118, n_scan_normal.h:35): the device
+    // context is the process-wide default, created when the driver sees its first image
     radarDriver::Parameters rp; rp.range_res = rr; rp.z_min = 60; rp.k_strongest = 12; rp.min_distance = 2.5f;
-    radarDriver driver(dev, rp, true);
+    radarDriver driver(rp, true);
     std::vector<MapNormalPtr> scans; std::vector<size_t> npts;
     for (int t = 0; t < 3; t++) {
       PolarImage pi; pi.rows = A; pi.cols = R; pi.data = imgs[t].data(); pi.stamp = (uint64_t)t;
       CloudPtr cloud, peaks;
       driver.CallbackOffline(pi, cloud, peaks);
       npts.push_back(cloud->size());
-      scans.push_back(MapNormalPtr(new MapPointNormal(dev, *driver.device_cloud(), 3.0f, Vector2d(), true, false)));
+      scans.push_back(MapNormalPtr(new MapPointNormal(cloud, 3.0f, Vector2d(0, 0), true, false)));
     }
     // CA-CFAR through the same driver class (filter_type switch, radar_driver.cpp:52-56)
     radarDriver::Parameters rc = rp; rc.filter_type_ = Str2filter("CA-CFAR");
-    radarDriver cfar_driver(dev, rc, true);
+    radarDriver cfar_driver(rc, true);
     PolarImage pi0; pi0.rows = A; pi0.cols = R; pi0.data = imgs[0].data();
     CloudPtr ccloud, cpeaks;
     cfar_driver.CallbackOffline(pi0, ccloud, cpeaks);
     MapNormalPtr m = scans[2];
     const cell& c0 = m->GetCell(0);
     const std::vector<int> nn = m->GetClosestIdx(c0.u_, 1.0);
-    Affine3d Tt = Affine3d::FromXYT(1.0, -2.0, 0.3);
+    Affine3d Tt = cfear_from_xyt(1.0, -2.0, 0.3);
     std::vector<cell> tc = m->TransformCells(Tt);
-    n_scan_normal_reg reg(dev, P2L, Huber, 0.1, Combined_weights);
-    std::vector<Affine3d> T = {Affine3d::Identity(), Affine3d::FromXYT(1.0, 0.02, 0.02), Affine3d::FromXYT(2.2, 0.1, 0.05)};
+    n_scan_normal_reg reg(P2L, Huber, 0.1, Combined_weights);
+    // a second registration object with other settings on the same device, and a map built with other settings after
+    // the first ones: neither may change what `reg` and `scans` compute (per-object parameter snapshots)
+    n_scan_normal_reg other(P2P, None, 0.5, Uniform);
+    other.SetD2dPar(3.0, 0.7);
+    MapNormalPtr coarse(new MapPointNormal(driver.device_cloud()->dev, *driver.device_cloud(), 5.0f, Vector2d(0, 0), false, false));
+    MapNormalPtr raw(new MapPointNormal(driver.device_cloud()->dev, *driver.device_cloud(), 3.0f, Vector2d(0, 0), false, true));  // identity cells
+    std::vector<cell> raw_cells = raw->GetCells();
+    const std::vector<int> raw_nn = raw->GetClosestIdx(raw_cells[5].u_, 0.5);
+    MapNormalPtr moved = m->TransformMap(Tt);  // the transformed-copy constructor (pointnormal.h:120)
+    const std::vector<int> moved_nn = moved->GetClosestIdx(tc[0].u_, 0.5);
+    std::vector<Affine3d> T = {cfear_from_xyt(0, 0, 0), cfear_from_xyt(1.0, 0.02, 0.02), cfear_from_xyt(2.2, 0.1, 0.05)};
     std::vector<Matrix6d> cov(3);
-    std::vector<Affine3d> T1 = T;
+    std::vector<Affine3d> T1 = T, To = T; std::vector<Matrix6d> covo(3);
+    const bool ok_other = other.Register(scans, To, covo, false);
     const bool ok = reg.Register(scans, T1, cov, false);
     double cov_scale = 0; const bool has_scale = reg.GetCovarianceScaler(cov_scale);
     double score = 0; std::vector<double> residuals;
@@ -53,20 +64,24 @@ int main(int argc, char** argv) {
     const bool cost_ok = reg.GetCost(scans, Tq, score, residuals);
     const double score_after_get_cost = reg.getScore();
     std::vector<Affine3d> T2 = T; std::vector<Matrix6d> cov2(3);
-    for (int a = 0; a < 6; a++) cov2[2].m[a][a] = 0.05 * 0.05;
+    for (int a = 0; a < 6; a++) cov2[2](a, a) = 0.05 * 0.05;
     const bool ok_soft = reg.Register(scans, T2, cov2, true);
     std::printf("{\"points\": [%zu, %zu, %zu], \"cfar_points\": %zu, \"cfar_peaks\": %zu, \"cells\": [%zu, %zu, %zu], "
                 "\"cell0\": [%.12g, %.12g, %.12g, %.12g], \"closest_self\": %d, \"rel_time0\": %.12g, "
                 "\"tcell0\": [%.12g, %.12g, %.12g, %.12g, %.12g], "
                 "\"register\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"itr\": %zu, \"score\": %.12g, \"cov00\": %.12g, \"cov_scale\": %.12g, \"has_scale\": %d}, "
                 "\"get_cost\": {\"ok\": %d, \"score\": %.12g, \"n\": %zu, \"r0\": %.12g, \"getScore\": %.12g}, "
-                "\"register_soft\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"residuals\": %d}}\n",
+                "\"register_soft\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"residuals\": %d}, "
+                "\"other\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"residuals\": %d}, \"coarse_cells\": %zu, "
+                "\"raw\": {\"cells\": %zu, \"points\": %zu, \"nn5\": %d, \"scale\": %.12g, \"cov00\": %.12g}, \"moved\": {\"cells\": %zu, \"nn0\": %d}}\n",
                 npts[0], npts[1], npts[2], ccloud->size(), cpeaks->size(), scans[0]->GetSize(), scans[1]->GetSize(), scans[2]->GetSize(),
-                c0.u_.x, c0.u_.y, c0.snormal_.x, c0.snormal_.y, nn.empty() ? -1 : nn[0], m->GetCellRelTimeStamp(0, false),
-                tc[0].u_.x, tc[0].u_.y, tc[0].snormal_.x, tc[0].cov_.m[0][0], tc[0].cov_.m[0][1],
-                ok ? 1 : 0, T1[2].t[0], T1[2].t[1], T1[2].yaw(), reg.itr_ ? reg.itr_ : 0, 0.0, cov[2].m[0][0], cov_scale, has_scale ? 1 : 0,
+                c0.u_(0), c0.u_(1), c0.snormal_(0), c0.snormal_(1), nn.empty() ? -1 : nn[0], m->GetCellRelTimeStamp(0, false),
+                tc[0].u_(0), tc[0].u_(1), tc[0].snormal_(0), tc[0].cov_(0, 0), tc[0].cov_(0, 1),
+                ok ? 1 : 0, cfear_tx(T1[2]), cfear_ty(T1[2]), cfear_yaw(T1[2]), reg.itr_ ? reg.itr_ : 0, 0.0, cov[2](0, 0), cov_scale, has_scale ? 1 : 0,
                 cost_ok ? 1 : 0, score, residuals.size(), residuals.empty() ? 0.0 : residuals[0], score_after_get_cost,
-                ok_soft ? 1 : 0, T2[2].t[0], T2[2].t[1], T2[2].yaw(), reg.summary_.num_residuals);
+                ok_soft ? 1 : 0, cfear_tx(T2[2]), cfear_ty(T2[2]), cfear_yaw(T2[2]), reg.summary_.num_residuals,
+                ok_other ? 1 : 0, cfear_tx(To[2]), cfear_ty(To[2]), cfear_yaw(To[2]), other.summary_.num_residuals, coarse->GetSize(),
+                raw->GetSize(), npts[2], raw_nn.empty() ? -1 : raw_nn[0], raw_cells[5].scale_, raw_cells[5].cov_(0, 0), moved->GetSize(), moved_nn.empty() ? -1 : moved_nn[0]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 3;

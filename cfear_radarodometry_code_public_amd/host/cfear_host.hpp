@@ -5,8 +5,12 @@
 //   MapPointNormal         (pointnormal.h:110-243,   pointnormal.cpp:65-90, 238-254)
 //   n_scan_normal_reg      (n_scan_normal.h:27-85,   n_scan_normal.cpp:82-187)
 //   OdometryKeyframeFuser  (odometrykeyframefuser.h:67-260, odometrykeyframefuser.cpp:143-259)
-// with POD stand-ins where the reference uses ROS / PCL / Eigen / OpenCV types (none of those are in
-// this image; INTEGRATION.md shows the two-line adapters for a tree that has them).
+// written against a handful of adapter functions over the ROS / PCL / Eigen / OpenCV types of those interfaces: POD stand-ins
+// here (cfear_types_pod.hpp; none of those libraries are in this image), the real types in a tree that has them
+// (include/cfear_radarodometry/*.h, the drop-in headers). Constructors have the reference's signatures: the device context
+// is a process-wide default created on first use (Device::Default) unless one is passed explicitly, and every object keeps
+// its own parameter snapshot, applied for the duration of its calls only (two objects with different settings on one
+// device do not see each other).
 // Error behaviour: where the reference prints and calls exit(0) this layer throws std::runtime_error
 // carrying cfear_last_error(); bool returns are kept.
 #pragma once
@@ -19,31 +23,17 @@
 #include <vector>
 
 #include "../../include/cfear_hip.h"
+// The ROS / PCL / Eigen / OpenCV types crossing these interfaces come from one of two headers defining the same names and
+// adapter functions: include/cfear_radarodometry/cfear_types_ros.h (real types; included first by the drop-in headers of
+// that directory) or, in this image, the POD stand-ins:
+#ifndef CFEAR_HOST_TYPES_DEFINED
+#include "cfear_types_pod.hpp"
+#endif
 
 namespace CFEAR_Radarodometry {
 
-// ---- POD stand-ins ---------------------------------------------------------------------------
-struct PointXYZI { float x = 0, y = 0, z = 0, intensity = 0; };                 // pcl::PointXYZI
-struct PointCloudXYZI { std::vector<PointXYZI> points; uint64_t stamp = 0;       // pcl::PointCloud<pcl::PointXYZI>
-  size_t size() const { return points.size(); } };
-typedef std::shared_ptr<PointCloudXYZI> CloudPtr;                                // ...::Ptr
-struct PolarImage { int rows = 0, cols = 0; const uint8_t* data = nullptr; uint64_t stamp = 0; };  // sensor_msgs::Image 8UC1 (rows = azimuth)
-struct Vector2d { double x = 0, y = 0; double operator()(int i) const { return i ? y : x; } };
-struct Matrix2d { double m[2][2] = {{0, 0}, {0, 0}}; double operator()(int r, int c) const { return m[r][c]; } };
-typedef struct Matrix6dT { double m[6][6]; Matrix6dT() { for (auto& r : m) for (double& v : r) v = 0; for (int i = 0; i < 6; i++) m[i][i] = 1; } } Matrix6d;
-
-// Eigen::Affine3d restricted to what the path uses: planar rigid motions (vectorToAffine3d, registration.cpp:130-136)
-struct Affine3d {
-  double l[2][2] = {{1, 0}, {0, 1}}, t[2] = {0, 0};
-  static Affine3d Identity() { return Affine3d(); }
-  static Affine3d FromXYT(double x, double y, double th) { Affine3d T; const double c = std::cos(th), s = std::sin(th); T.l[0][0] = c; T.l[0][1] = -s; T.l[1][0] = s; T.l[1][1] = c; T.t[0] = x; T.t[1] = y; return T; }
-  Affine3d operator*(const Affine3d& B) const { Affine3d C; for (int i = 0; i < 2; i++) { for (int j = 0; j < 2; j++) C.l[i][j] = l[i][0] * B.l[0][j] + l[i][1] * B.l[1][j]; C.t[i] = (l[i][0] * B.t[0] + l[i][1] * B.t[1]) + t[i]; } return C; }
-  Affine3d inverse() const { Affine3d I; const double det = l[0][0] * l[1][1] - l[0][1] * l[1][0], id = 1.0 / det; I.l[0][0] = l[1][1] * id; I.l[0][1] = -l[0][1] * id; I.l[1][0] = -l[1][0] * id; I.l[1][1] = l[0][0] * id; I.t[0] = -(I.l[0][0] * t[0] + I.l[0][1] * t[1]); I.t[1] = -(I.l[1][0] * t[0] + I.l[1][1] * t[1]); return I; }
-  double translation_norm() const { return std::sqrt(t[0] * t[0] + t[1] * t[1]); }
-  double yaw() const { return std::atan2(l[1][0], l[1][1]); }  // eulerAngles(0,1,2)[2] of a pure yaw rotation
-};
-inline void Affine3dToVectorXYeZ(const Affine3d& T, std::vector<double>& par) { par.resize(3); par[0] = T.t[0]; par[1] = T.t[1]; par[2] = T.yaw(); }  // utils.cpp:115-122
-inline Affine3d vectorToAffine3d(const std::vector<double>& v) { return Affine3d::FromXYT(v[0], v[1], v[2]); }
+inline void Affine3dToVectorXYeZ(const Affine3d& T, std::vector<double>& par) { par.resize(3); par[0] = cfear_tx(T); par[1] = cfear_ty(T); par[2] = cfear_yaw(T); }  // utils.cpp:115-122
+inline Affine3d vectorToAffine3d(const std::vector<double>& v) { return cfear_from_xyt(v[0], v[1], v[2]); }
 
 typedef enum costmetric { P2P, P2L, P2D } cost_metric;                                        // registration.h:55
 typedef enum losstype { None, Huber, Cauchy, SoftLOne, Combined, Tukey } loss_type;          // registration.h:60
@@ -54,6 +44,7 @@ inline loss_type Str2loss(const std::string& s) {                               
   if (s == "Tukey") return Tukey; if (s == "None") return None; return Huber; }
 
 // ---- timing (statistics.h / statistics.cpp:10-51): same stage names as the reference ------------
+#ifndef CFEAR_TIMING  // (a tree with the reference's statistics.h uses its global `timing` object: cfear_types_ros.h)
 struct statistics {
   std::map<std::string, std::vector<double>> executionTimes;
   void Document(const std::string& name, double value) { executionTimes[name].push_back(value); }
@@ -61,8 +52,11 @@ struct statistics {
 };
 inline statistics& timing_instance() { static statistics t; return t; }
 #define CFEAR_TIMING CFEAR_Radarodometry::timing_instance()
+#endif
 
-// ---- one device context shared by the mirrored classes (one per thread / sequence) -------------
+// ---- device context shared by the mirrored classes (one per thread / sequence) ------------------
+class Device;
+typedef std::shared_ptr<Device> DevicePtr;
 class Device {
  public:
   Device(const cfear_params& p, int A, int R, int device = 0) : par_(p), A_(A), R_(R) {
@@ -75,10 +69,36 @@ class Device {
   void set_params(const cfear_params& p) { check(cfear_set_params(ctx_, &p), "cfear_set_params"); par_ = p; }
   void check(int rc, const char* what) const { if (rc != CFEAR_OK) throw std::runtime_error(std::string(what) + ": " + cfear_last_error(ctx_)); }
   int A() const { return A_; } int R() const { return R_; }
+  // Process-wide default context of the reference-signature constructors: created on first use for the polar image shape
+  // first seen (A x R; 400 x 3768 when a cloud arrives before any image), on HIP device CFEAR_DEVICE (environment, default 0).
+  static DevicePtr& default_slot() { static DevicePtr d; return d; }
+  static void SetDefault(const DevicePtr& d) { default_slot() = d; }
+  static DevicePtr Default(int A = 400, int R = 3768) {
+    DevicePtr& d = default_slot();
+    if (!d || (A > 0 && R > 0 && (A != d->A() || R != d->R()) && !d->shape_seen_)) {
+      cfear_params p; cfear_default_params(&p);
+      const char* e = getenv("CFEAR_DEVICE");
+      d.reset(new Device(p, A, R, e ? atoi(e) : 0));
+    }
+    return d;
+  }
+  static DevicePtr DefaultForImage(int A, int R) {  // the first image fixes the shape of the default context
+    DevicePtr d = Default(A, R);
+    if (d->A() != A || d->R() != R) throw std::runtime_error("polar image shape differs from the device context");
+    d->shape_seen_ = true;
+    return d;
+  }
  private:
-  cfear_ctx* ctx_ = nullptr; cfear_params par_; int A_, R_;
+  cfear_ctx* ctx_ = nullptr; cfear_params par_; int A_, R_; bool shape_seen_ = false;
 };
-typedef std::shared_ptr<Device> DevicePtr;
+// an object's parameter snapshot applied to the context for the duration of one call
+class ScopedParams {
+ public:
+  ScopedParams(const DevicePtr& d, const cfear_params& p) : d_(d), saved_(d->params()) { d_->set_params(p); }
+  ~ScopedParams() { try { d_->set_params(saved_); } catch (...) {} }
+ private:
+  DevicePtr d_; cfear_params saved_;
+};
 
 // device-resident cloud handle travelling with the host cloud (keeps the data on the GPU between stages)
 struct DeviceCloud { DevicePtr dev; cfear_cloud* h = nullptr; ~DeviceCloud() { if (h) cfear_cloud_release(dev->ctx(), h); } };
@@ -88,15 +108,15 @@ inline CloudPtr DownloadCloud(const DevicePtr& dev, cfear_cloud* h) {
   int n = 0; dev->check(cfear_cloud_size(dev->ctx(), h, &n), "cfear_cloud_size");
   std::vector<float> xyi(3 * (size_t)(n > 0 ? n : 1));
   dev->check(cfear_cloud_download(dev->ctx(), h, xyi.data(), n, &n), "cfear_cloud_download");
-  CloudPtr c(new PointCloudXYZI()); c->points.resize(n);
-  for (int i = 0; i < n; i++) { c->points[i].x = xyi[3 * i]; c->points[i].y = xyi[3 * i + 1]; c->points[i].intensity = xyi[3 * i + 2]; }
+  CloudPtr c = cfear_make_cloud();
+  cfear_cloud_from_xyi(*c, xyi.data(), (size_t)n);
   return c;
 }
 inline DeviceCloudPtr UploadCloud(const DevicePtr& dev, const PointCloudXYZI& c) {
-  std::vector<float> xyi(3 * c.size() + 3);
-  for (size_t i = 0; i < c.size(); i++) { xyi[3 * i] = c.points[i].x; xyi[3 * i + 1] = c.points[i].y; xyi[3 * i + 2] = c.points[i].intensity; }
+  std::vector<float> xyi;
+  cfear_cloud_to_xyi(c, xyi);
   DeviceCloudPtr d(new DeviceCloud()); d->dev = dev;
-  dev->check(cfear_cloud_upload(dev->ctx(), xyi.data(), (int)c.size(), &d->h), "cfear_cloud_upload");
+  dev->check(cfear_cloud_upload(dev->ctx(), xyi.data(), (int)cfear_cloud_size(c), &d->h), "cfear_cloud_upload");
   return d;
 }
 
@@ -108,21 +128,25 @@ inline std::string Filter2str(const filtertype& filter) { return filter == filte
 // ---- AzimuthCACFAR (cfar.h:31-46, cfar.cpp:27-87) -------------------------------------------------------
 class AzimuthCACFAR {
  public:
+  AzimuthCACFAR(int window_size = 40, double false_alarm_rate = 0.01, int nb_guard_cells = 5, double range_resolution = 0.0438,
+                double static_threshold = 60.0, double min_distance = 2.5, double max_distance = 200.0)
+      : window_size_(window_size), nb_guard_cells_(nb_guard_cells), false_alarm_rate_(false_alarm_rate), max_distance_(max_distance),
+        range_res_((float)range_resolution), z_min_((float)static_threshold), min_distance_((float)min_distance) {}
   AzimuthCACFAR(const DevicePtr& dev, int window_size = 40, double false_alarm_rate = 0.01, int nb_guard_cells = 5, double range_resolution = 0.0438,
                 double static_threshold = 60.0, double min_distance = 2.5, double max_distance = 200.0)
-      : dev_(dev), window_size_(window_size), nb_guard_cells_(nb_guard_cells), false_alarm_rate_(false_alarm_rate), max_distance_(max_distance) {
-    cfear_params p = dev_->params(); p.range_res = (float)range_resolution; p.z_min = (float)static_threshold; p.min_distance = (float)min_distance;
-    dev_->set_params(p);
-  }
+      : AzimuthCACFAR(window_size, false_alarm_rate, nb_guard_cells, range_resolution, static_threshold, min_distance, max_distance) { dev_ = dev; }
   // void getFilteredPointCloud(const cv_bridge::CvImagePtr&, PointCloud::Ptr& output) const (cfar.cpp:35)
-  DeviceCloudPtr getFilteredPointCloud(const PolarImage& img, CloudPtr& output_pointcloud) const {
-    DeviceCloudPtr d(new DeviceCloud()); d->dev = dev_;
-    dev_->check(cfear_filter_cfar(dev_->ctx(), img.data, window_size_, nb_guard_cells_, (float)false_alarm_rate_, max_distance_, &d->h), "cfear_filter_cfar");
-    output_pointcloud = DownloadCloud(dev_, d->h);
+  DeviceCloudPtr getFilteredPointCloud(const CvImagePtr& img, CloudPtr& output_pointcloud) const {
+    const DevicePtr dev = dev_ ? dev_ : Device::DefaultForImage(cfear_cv_rows(img), cfear_cv_cols(img));
+    cfear_params p = dev->params(); p.range_res = range_res_; p.z_min = z_min_; p.min_distance = min_distance_;
+    ScopedParams sp(dev, p);
+    DeviceCloudPtr d(new DeviceCloud()); d->dev = dev;
+    dev->check(cfear_filter_cfar(dev->ctx(), cfear_cv_data(img), window_size_, nb_guard_cells_, (float)false_alarm_rate_, max_distance_, &d->h), "cfear_filter_cfar");
+    output_pointcloud = DownloadCloud(dev, d->h);
     return d;
   }
  private:
-  DevicePtr dev_; int window_size_, nb_guard_cells_; double false_alarm_rate_, max_distance_;
+  DevicePtr dev_; int window_size_, nb_guard_cells_; double false_alarm_rate_, max_distance_; float range_res_, z_min_, min_distance_;
 };
 
 class radarDriver {
@@ -134,111 +158,198 @@ class radarDriver {
     int nb_guard_cells = 20, window_size = 10; float false_alarm_rate = 0.01f;  // :43-44
     filtertype filter_type_ = filtertype::kstrong;                               // :48
   };
-  radarDriver(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) {
-    (void)disable_callback;
-    cfear_params p = dev_->params(); p.z_min = par.z_min; p.range_res = par.range_res; p.min_distance = par.min_distance; p.k_strongest = par.k_strongest;
-    dev_->set_params(p);
+  radarDriver(const Parameters& pars, bool disable_callback = false) : par(pars) { (void)disable_callback; }  // radar_driver.h:86
+  radarDriver(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) { (void)disable_callback; }
+  // void CallbackOffline(const sensor_msgs::ImageConstPtr&, PointCloud::Ptr& cloud, PointCloud::Ptr& cloud_peaks) (radar_driver.h:90,
+  // radar_driver.cpp:163-176) -> Process() (:48-73). Oxford images are rows = azimuth x cols = range; the other datasets arrive
+  // range-major and go through cv::rotate first (CallbackOffline dispatches on par.dataset like the reference, :165-170).
+  void CallbackOffline(const ImageConstPtr& radar_image_polar, CloudPtr& cloud, CloudPtr& cloud_peaks) {
+    if (cfear_image_null(radar_image_polar)) throw std::runtime_error("Radar image NULL");  // radar_driver.cpp:75-78
+    cv_polar_image = cfear_image_to_cv(radar_image_polar);
+    if (par.dataset != "oxford") Rotate();
+    Process(cloud, cloud_peaks);
   }
-  // void CallbackOffline(const sensor_msgs::ImageConstPtr&, PointCloud::Ptr& cloud, PointCloud::Ptr& cloud_peaks) (radar_driver.cpp:163-176)
-  // -> Process() (:48-73). The image is rows = azimuth x cols = range (the reference rotates non-Oxford input first, :84).
-  void CallbackOffline(const PolarImage& img, CloudPtr& cloud, CloudPtr& cloud_peaks) {
-    if (!img.data) throw std::runtime_error("Radar image NULL");  // radar_driver.cpp:75-78
-    if (img.rows != dev_->A() || img.cols != dev_->R()) throw std::runtime_error("polar image shape differs from the device context");
-    cv_polar_image = img;
-    if (par.filter_type_ == filtertype::CACFAR) {  // :52-56: max_distance 400.0, the peaks cloud stays empty
-      AzimuthCACFAR filter(dev_, par.window_size, par.false_alarm_rate, par.nb_guard_cells, par.range_res, par.z_min, par.min_distance, 400.0);
-      last_cloud_ = filter.getFilteredPointCloud(img, cloud);
-      last_peaks_.reset(new DeviceCloud()); last_peaks_->dev = dev_;
-      cloud_peaks.reset(new PointCloudXYZI());
-    } else {
-      last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
-      last_cloud_->dev = dev_; last_peaks_->dev = dev_;
-      dev_->check(cfear_filter_polar(dev_->ctx(), img.data, &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
-      cloud = DownloadCloud(dev_, last_cloud_->h); cloud_peaks = DownloadCloud(dev_, last_peaks_->h);
-    }
-    cloud->stamp = cloud_peaks->stamp = img.stamp;
-  }
-  // void Callback(const sensor_msgs::ImageConstPtr&) for the non-Oxford datasets (radar_driver.cpp:74-90): the image arrives with
-  // rows = range bins; cv::rotate(ROTATE_90_COUNTERCLOCKWISE) (:84) runs on the device, then Process()
-  void Callback(const PolarImage& range_major, CloudPtr& cloud, CloudPtr& cloud_peaks) {
-    if (!range_major.data) throw std::runtime_error("Radar image NULL");
-    rotated_.resize((size_t)range_major.rows * range_major.cols);
-    dev_->check(cfear_rotate_polar(dev_->ctx(), range_major.data, range_major.rows, range_major.cols, rotated_.data()), "cfear_rotate_polar");
-    PolarImage az; az.rows = range_major.cols; az.cols = range_major.rows; az.data = rotated_.data(); az.stamp = range_major.stamp;
-    CallbackOffline(az, cloud, cloud_peaks);
+  // void Callback(const sensor_msgs::ImageConstPtr&) for the non-Oxford datasets (radar_driver.cpp:74-90): rows = range bins in;
+  // cv::rotate(ROTATE_90_COUNTERCLOCKWISE) (:84) runs on the device, then Process()
+  void Callback(const ImageConstPtr& range_major, CloudPtr& cloud, CloudPtr& cloud_peaks) {
+    if (cfear_image_null(range_major)) throw std::runtime_error("Radar image NULL");
+    cv_polar_image = cfear_image_to_cv(range_major);
+    Rotate();
+    Process(cloud, cloud_peaks);
   }
   DeviceCloudPtr device_cloud() const { return last_cloud_; }  // avoids a round trip when the fuser runs on the same device
-  PolarImage cv_polar_image;  // latest radar image (radar_driver.h:92)
+  CvImagePtr cv_polar_image;  // latest radar image (radar_driver.h:92)
  private:
-  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_; std::vector<uint8_t> rotated_;
+  DevicePtr device(int A, int R) {
+    if (!dev_) dev_ = Device::DefaultForImage(A, R);
+    if (A != dev_->A() || R != dev_->R()) throw std::runtime_error("polar image shape differs from the device context");
+    return dev_;
+  }
+  void Rotate() {
+    const int rows = cfear_cv_rows(cv_polar_image), cols = cfear_cv_cols(cv_polar_image);
+    const DevicePtr dev = device(cols, rows);
+    std::vector<uint8_t> out((size_t)rows * cols);
+    dev->check(cfear_rotate_polar(dev->ctx(), cfear_cv_data(cv_polar_image), rows, cols, out.data()), "cfear_rotate_polar");
+    cv_polar_image = cfear_cv_from_buffer(cols, rows, std::move(out), cv_polar_image);
+  }
+  void Process(CloudPtr& cloud, CloudPtr& cloud_peaks) {  // radar_driver.cpp:48-73
+    const DevicePtr dev = device(cfear_cv_rows(cv_polar_image), cfear_cv_cols(cv_polar_image));
+    if (par.filter_type_ == filtertype::CACFAR) {  // :52-56: max_distance 400.0, the peaks cloud stays empty
+      AzimuthCACFAR filter(dev, par.window_size, par.false_alarm_rate, par.nb_guard_cells, par.range_res, par.z_min, par.min_distance, 400.0);
+      last_cloud_ = filter.getFilteredPointCloud(cv_polar_image, cloud);
+      last_peaks_.reset(new DeviceCloud()); last_peaks_->dev = dev;
+      cloud_peaks = cfear_make_cloud();
+    } else {
+      cfear_params p = dev->params(); p.z_min = par.z_min; p.range_res = par.range_res; p.min_distance = par.min_distance; p.k_strongest = par.k_strongest;
+      ScopedParams sp(dev, p);
+      last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
+      last_cloud_->dev = dev; last_peaks_->dev = dev;
+      dev->check(cfear_filter_polar(dev->ctx(), cfear_cv_data(cv_polar_image), &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
+      cloud = DownloadCloud(dev, last_cloud_->h); cloud_peaks = DownloadCloud(dev, last_peaks_->h);
+    }
+    cfear_cloud_stamp_from_cv(*cloud, cv_polar_image); cfear_cloud_stamp_from_cv(*cloud_peaks, cv_polar_image);  // :66-67
+  }
+  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_;
 };
 
-// ---- Compensate (utils.h:49) -------------------------------------------------------------------------
+// ---- Compensate (utils.h:47-49, utils.cpp:96-113) -----------------------------------------------------
 inline void Compensate(const DevicePtr& dev, DeviceCloud& cloud, const Affine3d& Tmotion, bool ccw) {
-  const double mot[3] = {Tmotion.t[0], Tmotion.t[1], Tmotion.yaw()};
+  const double mot[3] = {cfear_tx(Tmotion), cfear_ty(Tmotion), cfear_yaw(Tmotion)};
   dev->check(cfear_compensate(dev->ctx(), cloud.h, mot, ccw ? 1 : 0), "cfear_compensate");
 }
+// void Compensate(pcl::PointCloud<pcl::PointXYZI>& cloud, const Eigen::Affine3d& Tmotion, bool ccw) (utils.h:49): in place
+inline void Compensate(PointCloudXYZI& cloud, const Affine3d& Tmotion, bool ccw) {
+  if (cfear_cloud_size(cloud) == 0) return;
+  const DevicePtr dev = Device::Default();
+  DeviceCloudPtr d = UploadCloud(dev, cloud);
+  Compensate(dev, *d, Tmotion, ccw);
+  CloudPtr back = DownloadCloud(dev, d->h);
+  std::vector<float> xyi; cfear_cloud_to_xyi(*back, xyi);
+  cfear_cloud_from_xyi(cloud, xyi.data(), cfear_cloud_size(*back));
+}
+inline void Compensate(PointCloudXYZI& cloud, const std::vector<double>& mot, bool ccw) { Compensate(cloud, vectorToAffine3d(mot), ccw); }  // utils.h:47
 
 // ---- cell / MapPointNormal (pointnormal.h:45-243) -----------------------------------------------------
 struct cell {
   Vector2d u_; Matrix2d cov_; double scale_ = 0; Vector2d snormal_, orth_normal; double lambda_min = 0, lambda_max = 0;
   double sum_intensity_ = 0, avg_intensity_ = 0; size_t Nsamples_ = 0; bool valid_ = false;
   double GetPlanarity() const { return scale_; }
+  // static cell GetIdentityCell(u, intensity) (pointnormal.h:58, private ctor :80-82); cov_ keeps its default Identity * 0.1 (:63)
+  static cell GetIdentityCell(const Vector2d& u, const double intensity) {
+    (void)intensity;
+    cell c; c.u_ = u; c.cov_ = cfear_mat2(0.1, 0, 0, 0.1); c.scale_ = 1.0; c.snormal_ = cfear_vec2(1, 0); c.orth_normal = cfear_vec2(0, 1);
+    c.lambda_min = 1; c.lambda_max = 1; c.sum_intensity_ = 1.0; c.avg_intensity_ = 1.0; c.Nsamples_ = 1; c.valid_ = true;
+    return c;
+  }
+  // cell TransformCopy(T) (pointnormal.cpp:515-527), arithmetic as written there: C = R * T * cov * R^T with the affine T
+  // applied to the columns of cov (so the translation enters the product)
+  cell TransformCopy(const Affine3d& T) const {
+    double R[2][2]; cfear_linear2(T, R);
+    const double t[2] = {cfear_tx(T), cfear_ty(T)};
+    cell ct = *this;
+    double M[2][2], RT[2][2], rt[2];  // R*T: linear R*R, translation R*t
+    for (int i = 0; i < 2; i++) { for (int j = 0; j < 2; j++) RT[i][j] = R[i][0] * R[0][j] + R[i][1] * R[1][j]; rt[i] = R[i][0] * t[0] + R[i][1] * t[1]; }
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) M[i][j] = RT[i][0] * cov_(0, j) + RT[i][1] * cov_(1, j) + rt[i];
+    ct.cov_ = cfear_mat2(M[0][0] * R[0][0] + M[0][1] * R[0][1], M[0][0] * R[1][0] + M[0][1] * R[1][1],
+                         M[1][0] * R[0][0] + M[1][1] * R[0][1], M[1][0] * R[1][0] + M[1][1] * R[1][1]);
+    ct.snormal_ = cfear_vec2(R[0][0] * snormal_(0) + R[0][1] * snormal_(1), R[1][0] * snormal_(0) + R[1][1] * snormal_(1));
+    ct.orth_normal = cfear_vec2(R[0][0] * orth_normal(0) + R[0][1] * orth_normal(1), R[1][0] * orth_normal(0) + R[1][1] * orth_normal(1));
+    ct.u_ = cfear_vec2(R[0][0] * u_(0) + R[0][1] * u_(1) + t[0], R[1][0] * u_(0) + R[1][1] * u_(1) + t[1]);
+    return ct;
+  }
 };
 class MapPointNormal;
-typedef std::shared_ptr<MapPointNormal> MapNormalPtr;
+typedef CFEAR_SHARED_PTR<MapPointNormal> MapNormalPtr;
 class MapPointNormal {
  public:
-  // MapPointNormal(cld, radius, origin = (0,0), weight_intensity = false, raw = false) (pointnormal.h:118)
-  MapPointNormal(const DevicePtr& dev, const DeviceCloud& cld, float radius, const Vector2d& origin = Vector2d(), bool weight_intensity = false, bool raw = false) : dev_(dev) {
-    if (raw) throw std::runtime_error("MapPointNormal: raw=true (identity cells) is not on the accelerated path");
-    if (origin.x != 0 || origin.y != 0) throw std::runtime_error("MapPointNormal: origin must be (0,0) as in odometrykeyframefuser.cpp:161");
-    cfear_params p = dev_->params(); p.res = radius; p.weight_intensity = weight_intensity ? 1 : 0; dev_->set_params(p);
+  // MapPointNormal(cld, radius, origin = (0,0), weight_intensity = false, raw = false) (pointnormal.h:118, pointnormal.cpp:65-90)
+  MapPointNormal(const CloudPtr& cld, float radius, const Vector2d& origin = Vector2d(0, 0), const bool weight_intensity = false, const bool raw = false)
+      : dev_(Device::Default()), input_(cld) {
+    if (!cld || cfear_cloud_size(*cld) == 0) throw std::runtime_error("error, cloud empty");  // pointnormal.cpp:72-75 (exit(0) there)
+    if (raw) { BuildRaw(*cld); return; }
+    DeviceCloudPtr d = UploadCloud(dev_, *cld);
+    Build(*d, radius, origin, weight_intensity);
+  }
+  // MapPointNormal(cld, radius, cell_orig, T) (pointnormal.h:120, pointnormal.cpp:91-110): transformed copy of existing cells
+  MapPointNormal(const CloudPtr& cld, float radius, std::vector<cell>& cell_orig, const Affine3d& T) : dev_(Device::Default()), input_(cld) {
+    (void)radius;
+    std::vector<cell> cs;
+    for (const cell& c : cell_orig) cs.push_back(c.TransformCopy(T));
+    FromCells(cs);
+  }
+  // the same from a cloud that is already on the device (radarDriver::device_cloud(): no upload)
+  MapPointNormal(const DevicePtr& dev, const DeviceCloud& cld, float radius, const Vector2d& origin = Vector2d(0, 0), bool weight_intensity = false, bool raw = false) : dev_(dev) {
+    if (raw) { CloudPtr host = DownloadCloud(dev_, cld.h); if (cfear_cloud_size(*host) == 0) throw std::runtime_error("error, cloud empty"); BuildRaw(*host); return; }
+    Build(cld, radius, origin, weight_intensity);
+  }
+  ~MapPointNormal() { if (scan_) cfear_scan_release(dev_->ctx(), scan_); }
+  MapPointNormal(const MapPointNormal&) = delete;
+  size_t GetSize() { int n = 0; dev_->check(cfear_scan_size(dev_->ctx(), scan_, &n), "cfear_scan_size"); return (size_t)n; }
+  std::vector<cell> GetCells() { fetch(); return cells_; }
+  cell& GetCell(const size_t i) { fetch(); return cells_[i]; }
+  Vector2d GetMean2d(const size_t i) { fetch(); return cells_[i].u_; }
+  Matrix2d GetCov2d(const size_t i) { fetch(); return cells_[i].cov_; }
+  Vector2d GetNormal2d(const size_t i) { fetch(); return cells_[i].snormal_; }
+  CloudPtr GetScan() { return input_; }  // pointnormal.h:172 (null when built from a device cloud)
+  std::vector<int> GetClosestIdx(const Vector2d& p, double d) {  // pointnormal.cpp:238-254
+    const double q[2] = {p(0), p(1)}; int32_t idx = -1;
+    dev_->check(cfear_scan_closest(dev_->ctx(), scan_, q, 1, d, &idx), "cfear_scan_closest");
+    return idx >= 0 ? std::vector<int>{idx} : std::vector<int>();
+  }
+  std::vector<cell*> GetClosest(Vector2d& p, double d) {  // pointnormal.cpp:225-236
+    fetch();
+    std::vector<cell*> out;
+    for (int i : GetClosestIdx(p, d)) out.push_back(&cells_[(size_t)i]);
+    return out;
+  }
+  // double GetCellRelTimeStamp(index, ccw) (pointnormal.cpp:139-143) with GetRelTimeStamp (utils.h:28-32)
+  double GetCellRelTimeStamp(const size_t index, const bool ccw) {
+    fetch();
+    const double a = std::atan2(cells_[index].u_(1), cells_[index].u_(0));
+    const double d = (a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI);
+    return ccw ? -(d - 0.5) : (d - 0.5);
+  }
+  // std::vector<cell> TransformCells(T) (pointnormal.cpp:352-361) -> cell::TransformCopy (:515-527)
+  std::vector<cell> TransformCells(const Affine3d& T) {
+    fetch();
+    std::vector<cell> out;
+    for (const cell& c : cells_) out.push_back(c.TransformCopy(T));
+    return out;
+  }
+  // MapNormalPtr TransformMap(T) (pointnormal.cpp:135-137): new map of transformed cells
+  MapNormalPtr TransformMap(const Affine3d& T) { fetch(); return MapNormalPtr(new MapPointNormal(input_, 0.f, cells_, T)); }
+  cfear_scan* handle() const { return scan_; }
+  const DevicePtr& device() const { return dev_; }
+  static double downsample_factor;  // pointnormal.h:241 (read when a map is built)
+ private:
+  void Build(const DeviceCloud& cld, float radius, const Vector2d& origin, bool weight_intensity) {
+    if (origin(0) != 0 || origin(1) != 0) throw std::runtime_error("MapPointNormal: origin must be (0,0) as in odometrykeyframefuser.cpp:161");
+    cfear_params p = dev_->params(); p.res = radius; p.weight_intensity = weight_intensity ? 1 : 0; p.downsample_factor = downsample_factor;
+    ScopedParams sp(dev_, p);  // this map's settings, for this call only
     const int rc = cfear_scan_create(dev_->ctx(), cld.h, &scan_);
     if (rc == CFEAR_ERR_EMPTY) throw std::runtime_error("error, cloud empty");  // pointnormal.cpp:72-75 (exit(0) there)
     dev_->check(rc, "cfear_scan_create");
   }
-  ~MapPointNormal() { if (scan_) cfear_scan_release(dev_->ctx(), scan_); }
-  size_t GetSize() { int n = 0; dev_->check(cfear_scan_size(dev_->ctx(), scan_, &n), "cfear_scan_size"); return (size_t)n; }
-  const std::vector<cell>& GetCells() { fetch(); return cells_; }
-  cell& GetCell(size_t i) { fetch(); return cells_[i]; }
-  Vector2d GetMean2d(size_t i) { fetch(); return cells_[i].u_; }
-  Matrix2d GetCov2d(size_t i) { fetch(); return cells_[i].cov_; }
-  Vector2d GetNormal2d(size_t i) { fetch(); return cells_[i].snormal_; }
-  std::vector<int> GetClosestIdx(const Vector2d& p, double d) {  // pointnormal.cpp:238-254
-    const double q[2] = {p.x, p.y}; int32_t idx = -1;
-    dev_->check(cfear_scan_closest(dev_->ctx(), scan_, q, 1, d, &idx), "cfear_scan_closest");
-    return idx >= 0 ? std::vector<int>{idx} : std::vector<int>();
+  void BuildRaw(const PointCloudXYZI& cld) {  // pointnormal.cpp:76-82: one identity cell per point
+    std::vector<float> xyi; cfear_cloud_to_xyi(cld, xyi);
+    std::vector<cell> cs;
+    for (size_t i = 0; i < cfear_cloud_size(cld); i++) cs.push_back(cell::GetIdentityCell(cfear_vec2(xyi[3 * i], xyi[3 * i + 1]), xyi[3 * i + 2]));
+    FromCells(cs);
   }
-  // double GetCellRelTimeStamp(index, ccw) (pointnormal.cpp:139-143) with GetRelTimeStamp (utils.h:28-32)
-  double GetCellRelTimeStamp(size_t index, bool ccw) {
-    fetch();
-    const double a = std::atan2(cells_[index].u_.y, cells_[index].u_.x);
-    const double d = (a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI);
-    return ccw ? -(d - 0.5) : (d - 0.5);
-  }
-  // std::vector<cell> TransformCells(T) (pointnormal.cpp:352-361) -> cell::TransformCopy (:515-527), arithmetic as written
-  // there: C = R * T * cov * R^T with the affine T applied to the columns of cov (so the translation enters the product)
-  std::vector<cell> TransformCells(const Affine3d& T) {
-    fetch();
-    std::vector<cell> out;
-    const double (*R)[2] = T.l;
-    for (const cell& c : cells_) {
-      cell ct = c;
-      double M[2][2], RT[2][2], rt[2];  // R*T: linear R*R, translation R*t
-      for (int i = 0; i < 2; i++) { for (int j = 0; j < 2; j++) RT[i][j] = R[i][0] * R[0][j] + R[i][1] * R[1][j]; rt[i] = R[i][0] * T.t[0] + R[i][1] * T.t[1]; }
-      for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) M[i][j] = RT[i][0] * c.cov_.m[0][j] + RT[i][1] * c.cov_.m[1][j] + rt[i];
-      for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) ct.cov_.m[i][j] = M[i][0] * R[j][0] + M[i][1] * R[j][1];
-      ct.snormal_.x = R[0][0] * c.snormal_.x + R[0][1] * c.snormal_.y; ct.snormal_.y = R[1][0] * c.snormal_.x + R[1][1] * c.snormal_.y;
-      ct.orth_normal.x = R[0][0] * c.orth_normal.x + R[0][1] * c.orth_normal.y; ct.orth_normal.y = R[1][0] * c.orth_normal.x + R[1][1] * c.orth_normal.y;
-      ct.u_.x = R[0][0] * c.u_.x + R[0][1] * c.u_.y + T.t[0]; ct.u_.y = R[1][0] * c.u_.x + R[1][1] * c.u_.y + T.t[1];
-      out.push_back(ct);
+  void FromCells(const std::vector<cell>& cs) {
+    std::vector<cfear_cell> raw(cs.size() ? cs.size() : 1);
+    for (size_t i = 0; i < cs.size(); i++) {
+      const cell& c = cs[i]; cfear_cell& r = raw[i];
+      r.mean[0] = c.u_(0); r.mean[1] = c.u_(1); r.cov[0] = c.cov_(0, 0); r.cov[1] = c.cov_(0, 1); r.cov[2] = c.cov_(1, 1);
+      r.normal[0] = c.snormal_(0); r.normal[1] = c.snormal_(1); r.orth[0] = c.orth_normal(0); r.orth[1] = c.orth_normal(1);
+      r.lambda_min = c.lambda_min; r.lambda_max = c.lambda_max; r.scale = c.scale_; r.sum_intensity = c.sum_intensity_; r.avg_intensity = c.avg_intensity_;
+      r.nsamples = (int32_t)c.Nsamples_; r.valid = c.valid_ ? 1 : 0;
     }
-    return out;
+    const int rc = cfear_scan_from_cells(dev_->ctx(), raw.data(), (int)cs.size(), &scan_);
+    if (rc == CFEAR_ERR_EMPTY) throw std::runtime_error("error, cloud empty");
+    dev_->check(rc, "cfear_scan_from_cells");
+    cells_ = cs; fetched_ = true;
   }
-  cfear_scan* handle() const { return scan_; }
-  static double downsample_factor;  // pointnormal.h:241 (set through cfear_params.downsample_factor)
- private:
   void fetch() {
     if (fetched_) return;
     int n = 0; dev_->check(cfear_scan_size(dev_->ctx(), scan_, &n), "cfear_scan_size");
@@ -247,20 +358,23 @@ class MapPointNormal {
     cells_.resize(n);
     for (int i = 0; i < n; i++) {
       cell& c = cells_[i]; const cfear_cell& r = raw[i];
-      c.u_.x = r.mean[0]; c.u_.y = r.mean[1]; c.cov_.m[0][0] = r.cov[0]; c.cov_.m[0][1] = c.cov_.m[1][0] = r.cov[1]; c.cov_.m[1][1] = r.cov[2];
-      c.snormal_.x = r.normal[0]; c.snormal_.y = r.normal[1]; c.orth_normal.x = r.orth[0]; c.orth_normal.y = r.orth[1];
+      c.u_ = cfear_vec2(r.mean[0], r.mean[1]); c.cov_ = cfear_mat2(r.cov[0], r.cov[1], r.cov[1], r.cov[2]);
+      c.snormal_ = cfear_vec2(r.normal[0], r.normal[1]); c.orth_normal = cfear_vec2(r.orth[0], r.orth[1]);
       c.lambda_min = r.lambda_min; c.lambda_max = r.lambda_max; c.scale_ = r.scale; c.sum_intensity_ = r.sum_intensity; c.avg_intensity_ = r.avg_intensity;
       c.Nsamples_ = (size_t)r.nsamples; c.valid_ = r.valid != 0;
     }
     fetched_ = true;
   }
-  DevicePtr dev_; cfear_scan* scan_ = nullptr; std::vector<cell> cells_; bool fetched_ = false;
+  DevicePtr dev_; CloudPtr input_; cfear_scan* scan_ = nullptr; std::vector<cell> cells_; bool fetched_ = false;
 };
 inline double MapPointNormal::downsample_factor = 1;
 
 // ---- n_scan_normal_reg (n_scan_normal.h:27-85) ----------------------------------------------------------
 class n_scan_normal_reg {
  public:
+  n_scan_normal_reg() {}                                                                                   // n_scan_normal.h:33
+  n_scan_normal_reg(const cost_metric& cost, loss_type loss = Huber, double loss_limit = 0.1, const weightoption opt = weightoption::Uniform)  // :35
+      : cost_(cost), loss_(loss), loss_limit_(loss_limit), weight_opt_(opt) {}
   n_scan_normal_reg(const DevicePtr& dev, const cost_metric& cost, loss_type loss = Huber, double loss_limit = 0.1, const weightoption opt = Uniform)
       : dev_(dev), cost_(cost), loss_(loss), loss_limit_(loss_limit), weight_opt_(opt) {}
   void SetD2dPar(const double cov_scale, const double regularization) { cov_scale_ = cov_scale; regularization_ = regularization; }  // n_scan_normal.h:53
@@ -269,26 +383,23 @@ class n_scan_normal_reg {
   bool Register(std::vector<MapNormalPtr>& scans, std::vector<Affine3d>& Tsrc, std::vector<Matrix6d>& reg_cov, bool soft_constraints = false) {
     const size_t n = scans.size();
     if (Tsrc.size() != n || reg_cov.size() != n || n < 2) throw std::runtime_error("Register: scans/Tsrc/reg_cov size mismatch");  // assert at n_scan_normal.cpp:84
-    cfear_params p = dev_->params();
-    p.cost = cost_ == P2L ? CFEAR_COST_P2L : (cost_ == P2D ? CFEAR_COST_P2D : CFEAR_COST_P2P); p.loss = (int)loss_; p.loss_limit = loss_limit_;
-    p.weight_opt = (int)weight_opt_; p.covar_scale = cov_scale_; p.regularization = regularization_;
-    p.max_itr_association = max_itr_association_; p.max_solver_iterations = max_itr_solver_;
-    dev_->set_params(p);
+    const DevicePtr dev = device(scans);
+    ScopedParams sp(dev, my_params(dev));  // this object's cost / loss / weights, for this call only
     std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
-    for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = Tsrc[i].t[0]; poses[3 * i + 1] = Tsrc[i].t[1]; poses[3 * i + 2] = Tsrc[i].yaw(); }
+    for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = cfear_tx(Tsrc[i]); poses[3 * i + 1] = cfear_ty(Tsrc[i]); poses[3 * i + 2] = cfear_yaw(Tsrc[i]); }
     double cov[36];
     if (soft_constraints) {  // :373-377: prior from reg_cov.back() as passed in
       double prior[36];
-      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) prior[6 * a + b] = reg_cov.back().m[a][b];
-      dev_->check(cfear_register_soft(dev_->ctx(), h.data(), (int)n, poses.data(), prior, cov, &summary_), "cfear_register_soft");
+      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) prior[6 * a + b] = reg_cov.back()(a, b);
+      dev->check(cfear_register_soft(dev->ctx(), h.data(), (int)n, poses.data(), prior, cov, &summary_), "cfear_register_soft");
     } else {
-      dev_->check(cfear_register(dev_->ctx(), h.data(), (int)n, poses.data(), cov, &summary_), "cfear_register");
+      dev->check(cfear_register(dev->ctx(), h.data(), (int)n, poses.data(), cov, &summary_), "cfear_register");
     }
-    Tsrc.back() = Affine3d::FromXYT(poses[3 * (n - 1)], poses[3 * (n - 1) + 1], poses[3 * (n - 1) + 2]);
+    Tsrc.back() = cfear_from_xyt(poses[3 * (n - 1)], poses[3 * (n - 1) + 1], poses[3 * (n - 1) + 2]);
     if (summary_.usable) {  // :164-178: every pose passes through vectorToAffine3d(parameters), covariances get the default diagonal
-      for (size_t i = 0; i + 1 < n; i++) Tsrc[i] = Affine3d::FromXYT(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
-      for (size_t i = 0; i < n; i++) { Matrix6d m; for (int a = 0; a < 6; a++) m.m[a][a] = 0; m.m[0][0] = m.m[1][1] = 0.1 * 0.1; m.m[5][5] = 0.01 * 0.01; reg_cov[i] = m; }
-      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) reg_cov.back().m[a][b] = cov[6 * a + b];
+      for (size_t i = 0; i + 1 < n; i++) Tsrc[i] = cfear_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
+      for (size_t i = 0; i < n; i++) { Matrix6d m = cfear_mat6_identity(); for (int a = 0; a < 6; a++) m(a, a) = 0; m(0, 0) = m(1, 1) = 0.1 * 0.1; m(5, 5) = 0.01 * 0.01; reg_cov[i] = m; }
+      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) reg_cov.back()(a, b) = cov[6 * a + b];
       score_ = summary_.score;
     }
     itr_ = (size_t)summary_.outer_iterations;
@@ -299,30 +410,38 @@ class n_scan_normal_reg {
   bool GetCost(std::vector<MapNormalPtr>& scans, std::vector<Affine3d>& Tsrc, double& score, std::vector<double>& residuals) {
     const size_t n = scans.size();
     if (Tsrc.size() != n || n < 2) throw std::runtime_error("GetCost: scans/Tsrc size mismatch");  // assert at :190
-    cfear_params p = dev_->params();
-    p.cost = cost_ == P2L ? CFEAR_COST_P2L : (cost_ == P2D ? CFEAR_COST_P2D : CFEAR_COST_P2P); p.loss = (int)loss_; p.loss_limit = loss_limit_;
-    p.weight_opt = (int)weight_opt_; p.covar_scale = cov_scale_; p.regularization = regularization_;
-    dev_->set_params(p);
+    const DevicePtr dev = device(scans);
+    ScopedParams sp(dev, my_params(dev));
     std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
-    for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = Tsrc[i].t[0]; poses[3 * i + 1] = Tsrc[i].t[1]; poses[3 * i + 2] = Tsrc[i].yaw(); }
-    int cap = 0; dev_->check(cfear_scan_size(dev_->ctx(), h.back(), &cap), "cfear_scan_size");
+    for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = cfear_tx(Tsrc[i]); poses[3 * i + 1] = cfear_ty(Tsrc[i]); poses[3 * i + 2] = cfear_yaw(Tsrc[i]); }
+    int cap = 0; dev->check(cfear_scan_size(dev->ctx(), h.back(), &cap), "cfear_scan_size");
     cap = 2 * (int)(n - 1) * (cap > 0 ? cap : 1);
     residuals.assign((size_t)cap, 0.0);
     int nres = -1;
-    const int rc = cfear_get_cost(dev_->ctx(), h.data(), (int)n, poses.data(), (int)itr_, &score, residuals.data(), cap, &nres);
+    const int rc = cfear_get_cost(dev->ctx(), h.data(), (int)n, poses.data(), (int)itr_, &score, residuals.data(), cap, &nres);
     if (rc == CFEAR_ERR_EMPTY) { residuals.clear(); return false; }  // "too few residuals" (:205-208)
-    dev_->check(rc, "cfear_get_cost");
+    dev->check(rc, "cfear_get_cost");
     residuals.resize((size_t)nres);
     score_ = score / (double)(nres > 1 ? nres : 1);  // :211
     return true;
   }
-  double getScore() const { return score_; }
-  bool GetCovarianceScaler(double& cov_scale) const {  // n_scan_normal.cpp:435-441
+  double getScore() { return score_; }
+  void getScore(double& score, int& num_residuals) { score = score_; num_residuals = summary_.num_residuals; }  // n_scan_normal.h:51
+  bool GetCovarianceScaler(double& cov_scale) {  // n_scan_normal.cpp:435-441
     if (summary_.num_residuals - 3 == 0) return false; cov_scale = summary_.final_cost / (summary_.num_residuals - 3); return true; }
   cfear_reg_summary summary_ {};  // stands in for ceres::Solver::Summary (registration.h:110)
   size_t itr_ = 0;
+  // device and parameter snapshot of this object (cfear_cov_by_sampling runs under them as well)
+  DevicePtr device(const std::vector<MapNormalPtr>& scans) { if (!dev_) dev_ = scans.empty() ? Device::Default() : scans.back()->device(); return dev_; }
+  cfear_params my_params(const DevicePtr& dev) const {
+    cfear_params p = dev->params();
+    p.cost = cost_ == P2L ? CFEAR_COST_P2L : (cost_ == P2D ? CFEAR_COST_P2D : CFEAR_COST_P2P); p.loss = (int)loss_; p.loss_limit = loss_limit_;
+    p.weight_opt = (int)weight_opt_; p.covar_scale = cov_scale_; p.regularization = regularization_;
+    p.max_itr_association = max_itr_association_; p.max_solver_iterations = max_itr_solver_;
+    return p;
+  }
  private:
-  DevicePtr dev_; cost_metric cost_; loss_type loss_; double loss_limit_; weightoption weight_opt_;
+  DevicePtr dev_; cost_metric cost_ = P2L; loss_type loss_ = Huber; double loss_limit_ = 0.1; weightoption weight_opt_ = weightoption::Uniform;  // registration.h:117-120
   double cov_scale_ = 1, regularization_ = 0.01, score_ = 0; int max_itr_association_ = 8, max_itr_solver_ = 20;
 };
 
@@ -333,18 +452,15 @@ class OdometryKeyframeFuser {
    public:
     std::string cost_type = "P2L"; weightoption weight_opt = Uniform; int submap_scan_size = 3; bool weight_intensity_ = false;
     bool use_guess = true, disable_registration = false, soft_constraint = false, compensate = true, radar_ccw = false, use_keyframe = true;
+    bool use_raw_pointcloud = false;  // odometrykeyframefuser.h:96
     double res = 3.5, min_keyframe_dist_ = 1.5, min_keyframe_rot_deg_ = 5; std::string loss_type_ = "Huber"; double loss_limit_ = 0.1;
     double covar_scale_ = 1.0, regularization_ = 0.0;
     // cost-sampling covariance (odometrykeyframefuser.h:104-110; the samples-to-file switch is not mirrored)
     bool estimate_cov_by_sampling = false; double cov_sampling_xy_range = 0.4, cov_sampling_yaw_range = 0.0043625;
     unsigned int cov_sampling_samples_per_axis = 3; double cov_sampling_covariance_scaler = 4.0;
   };
-  OdometryKeyframeFuser(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) {
-    (void)disable_callback;
-    if (!(par.res > 0.05 && par.submap_scan_size >= 1)) throw std::runtime_error("assert(par.res>0.05 && par.submap_scan_size>=1)");  // odometrykeyframefuser.cpp:25
-    radar_reg.reset(new n_scan_normal_reg(dev_, Str2Cost(par.cost_type), Str2loss(par.loss_type_), par.loss_limit_, par.weight_opt));  // :27-30
-    radar_reg->SetD2dPar(par.covar_scale_, par.regularization_);                                                                    // :32
-  }
+  OdometryKeyframeFuser(const Parameters& pars, bool disable_callback = false) : par(pars) { Init(disable_callback); }  // odometrykeyframefuser.h:187
+  OdometryKeyframeFuser(const DevicePtr& dev, const Parameters& pars, bool disable_callback = true) : dev_(dev), par(pars) { Init(disable_callback); }
   // void pointcloudCallback(cloud_filtered, cloud_filtered_peaks, Tcurr, t [, cov]) (odometrykeyframefuser.cpp:397-411).
   // cloud / cloud_peaks are compensated in place like the reference does (:147-150).
   void pointcloudCallback(CloudPtr& cloud_filtered, CloudPtr& cloud_filtered_peaks, Affine3d& Tcurr, uint64_t t, Matrix6d* cov_curr = nullptr) {
@@ -354,20 +470,30 @@ class OdometryKeyframeFuser {
     Tcurr = Tcurrent;
     if (cov_curr) *cov_curr = cov_current;
   }
+  void pointcloudCallback(CloudPtr& cloud_filtered, CloudPtr& cloud_filtered_peaks, Affine3d& Tcurr, uint64_t t, Matrix6d& cov_curr) {  // :409-411
+    pointcloudCallback(cloud_filtered, cloud_filtered_peaks, Tcurr, t, &cov_curr);
+  }
   Affine3d GetCurrentPose() const { return Tcurrent; }
   size_t NumKeyframes() const { return keyframes_.size(); }
   bool updated = false;
   std::shared_ptr<n_scan_normal_reg> radar_reg;
  private:
   struct Keyframe { MapNormalPtr cloud_normal_; Affine3d pose; };
+  void Init(bool disable_callback) {
+    (void)disable_callback;
+    if (!(par.res > 0.05 && par.submap_scan_size >= 1)) throw std::runtime_error("assert(par.res>0.05 && par.submap_scan_size>=1)");  // odometrykeyframefuser.cpp:25
+    if (!dev_) dev_ = Device::Default();
+    radar_reg.reset(new n_scan_normal_reg(dev_, Str2Cost(par.cost_type), Str2loss(par.loss_type_), par.loss_limit_, par.weight_opt));  // :27-30
+    radar_reg->SetD2dPar(par.covar_scale_, par.regularization_);                                                                    // :32
+  }
   static bool KeyFrameBasedFuse(const Affine3d& diff, bool use_keyframe, double min_keyframe_dist, double min_keyframe_rot_deg) {  // :62-73
     if (!use_keyframe) return true;
-    return diff.translation_norm() > min_keyframe_dist || std::fabs(diff.yaw()) > (min_keyframe_rot_deg * M_PI / 180.0);
+    return cfear_tnorm(diff) > min_keyframe_dist || std::fabs(cfear_yaw(diff)) > (min_keyframe_rot_deg * M_PI / 180.0);
   }
   static bool AccelerationVelocitySanityCheck(const Affine3d& Tmot_prev, const Affine3d& Tmot_curr) {  // :76-94
     const double dt = 0.25, vel_limit = 200, acc_limit = 200;
-    const double vel = Tmot_curr.translation_norm() / dt;
-    const double ax = (Tmot_curr.t[0] - Tmot_prev.t[0]) / (dt * dt), ay = (Tmot_curr.t[1] - Tmot_prev.t[1]) / (dt * dt);
+    const double vel = cfear_tnorm(Tmot_curr) / dt;
+    const double ax = (cfear_tx(Tmot_curr) - cfear_tx(Tmot_prev)) / (dt * dt), ay = (cfear_ty(Tmot_curr) - cfear_ty(Tmot_prev)) / (dt * dt);
     return !(std::sqrt(ax * ax + ay * ay) > acc_limit) && !(vel > vel_limit);
   }
   void processFrame(CloudPtr& cloud, CloudPtr& cloud_peaks, uint64_t) {  // :143-259
@@ -377,27 +503,27 @@ class OdometryKeyframeFuser {
       Compensate(dev_, *dcloud, TprevMot, par.radar_ccw); Compensate(dev_, *dpeaks, TprevMot, par.radar_ccw);
       cloud = DownloadCloud(dev_, dcloud->h); cloud_peaks = DownloadCloud(dev_, dpeaks->h);
     }
-    MapNormalPtr Pcurrent(new MapPointNormal(dev_, *dcloud, (float)par.res, Vector2d(), par.weight_intensity_, false));  // :161
+    MapNormalPtr Pcurrent(new MapPointNormal(dev_, *dcloud, (float)par.res, Vector2d(0, 0), par.weight_intensity_, par.use_raw_pointcloud));  // :161
     CFEAR_TIMING.Document("Surface points", (double)Pcurrent->GetSize());  // pointnormal.cpp:87
     const Affine3d Tguess = par.use_guess ? T_prev * TprevMot : T_prev;  // :164-168
     if (keyframes_.empty()) {  // :171-177
-      keyframes_.push_back({Pcurrent, Affine3d::Identity()}); updated = true; return;
+      keyframes_.push_back({Pcurrent, cfear_from_xyt(0, 0, 0)}); updated = true; return;
     }
     std::vector<Matrix6d> cov_vek; std::vector<MapNormalPtr> scans_vek; std::vector<Affine3d> T_vek;  // FormatScans :478-494
-    for (auto& k : keyframes_) { cov_vek.push_back(Matrix6d()); scans_vek.push_back(k.cloud_normal_); T_vek.push_back(k.pose); }
-    cov_vek.push_back(Matrix6d()); scans_vek.push_back(Pcurrent); T_vek.push_back(Tguess);
+    for (auto& k : keyframes_) { cov_vek.push_back(cfear_mat6_identity()); scans_vek.push_back(k.cloud_normal_); T_vek.push_back(k.pose); }
+    cov_vek.push_back(cfear_mat6_identity()); scans_vek.push_back(Pcurrent); T_vek.push_back(Tguess);
     if (!par.disable_registration) (void)radar_reg->Register(scans_vek, T_vek, cov_vek, par.soft_constraint);  // :184-186: the result lands in a shadowed variable
     Tcurrent = T_vek.back(); cov_current = cov_vek.back();  // :195-196
     const Affine3d Tmot_current = T_prev.inverse() * Tcurrent;
     if (!AccelerationVelocitySanityCheck(Tmot, Tmot_current)) Tcurrent = Tguess;  // :198-199
     Tmot = T_prev.inverse() * Tcurrent;  // :200
     if (par.estimate_cov_by_sampling) {  // :203-208
-      Matrix6d cov_sampled;
+      Matrix6d cov_sampled = cfear_mat6_identity();
       if (approximateCovarianceBySampling(scans_vek, T_vek, cov_sampled)) { cov_current = cov_sampled; cov_vek.back() = cov_sampled; }
     }
     const Affine3d Tkeydiff = keyframes_.back().pose.inverse() * Tcurrent;  // :227
     const bool fuse = KeyFrameBasedFuse(Tkeydiff, par.use_keyframe, par.min_keyframe_dist_, par.min_keyframe_rot_deg_);
-    CFEAR_TIMING.Document("velocity", Tmot.translation_norm() / 0.25);  // :231
+    CFEAR_TIMING.Document("velocity", cfear_tnorm(Tmot) / 0.25);  // :231
     if (fuse) {  // :234-249, AddToReference :470-476
       keyframes_.push_back({Pcurrent, Tcurrent});
       if (keyframes_.size() > (size_t)par.submap_scan_size) keyframes_.erase(keyframes_.begin());
@@ -409,17 +535,19 @@ class OdometryKeyframeFuser {
   bool approximateCovarianceBySampling(std::vector<MapNormalPtr>& scans_vek, const std::vector<Affine3d>& T_vek, Matrix6d& cov_sampled) {
     const size_t n = scans_vek.size();
     std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
-    for (size_t i = 0; i < n; i++) { h[i] = scans_vek[i]->handle(); poses[3 * i] = T_vek[i].t[0]; poses[3 * i + 1] = T_vek[i].t[1]; poses[3 * i + 2] = T_vek[i].yaw(); }
+    for (size_t i = 0; i < n; i++) { h[i] = scans_vek[i]->handle(); poses[3 * i] = cfear_tx(T_vek[i]); poses[3 * i + 1] = cfear_ty(T_vek[i]); poses[3 * i + 2] = cfear_yaw(T_vek[i]); }
+    ScopedParams sp(dev_, radar_reg->my_params(dev_));  // the samples are GetCost calls of radar_reg (:305)
     double cov[36]; int ok = 0;
     dev_->check(cfear_cov_by_sampling(dev_->ctx(), h.data(), (int)n, poses.data(), (int)radar_reg->itr_, par.cov_sampling_xy_range, par.cov_sampling_yaw_range,
                                       (int)par.cov_sampling_samples_per_axis, par.cov_sampling_covariance_scaler, radar_reg->summary_.final_cost,
                                       radar_reg->summary_.num_residuals, cov, &ok, nullptr), "cfear_cov_by_sampling");
     if (!ok) return false;
-    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) cov_sampled.m[a][b] = cov[6 * a + b];
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) cov_sampled(a, b) = cov[6 * a + b];
     return true;
   }
   DevicePtr dev_; Parameters par;
-  Affine3d Tcurrent, T_prev, Tmot; Matrix6d cov_current; std::vector<Keyframe> keyframes_; size_t nr_callbacks_ = 0;
+  Affine3d Tcurrent = cfear_from_xyt(0, 0, 0), T_prev = cfear_from_xyt(0, 0, 0), Tmot = cfear_from_xyt(0, 0, 0);  // odometrykeyframefuser.cpp:34-38
+  Matrix6d cov_current = cfear_mat6_identity(); std::vector<Keyframe> keyframes_; size_t nr_callbacks_ = 0;
 };
 
 }  // namespace CFEAR_Radarodometry

@@ -85,12 +85,13 @@ int main(int argc, char** argv) {
       const auto t1 = std::chrono::steady_clock::now();
       CFEAR_TIMING.Document("Filtering", std::chrono::duration<double, std::milli>(t1 - t0).count());  // radar_driver.cpp:111
       CFEAR_TIMING.Document("Filtered points", (double)cloud->size());    // :104
-      Affine3d Tcurrent;
+      Affine3d Tcurrent = cfear_from_xyt(0, 0, 0);
       fuser.pointcloudCallback(cloud, cloud_peaks, Tcurrent, pi.stamp);   // :108
       const auto t2 = std::chrono::steady_clock::now();
       CFEAR_TIMING.Document("Registration", std::chrono::duration<double, std::milli>(t2 - t1).count());  // odometrykeyframefuser.cpp:404
-      est << Tcurrent.l[0][0] << " " << Tcurrent.l[0][1] << " 0.000000 " << Tcurrent.t[0] << " "
-          << Tcurrent.l[1][0] << " " << Tcurrent.l[1][1] << " 0.000000 " << Tcurrent.t[1] << " "
+      double Rm[2][2]; cfear_linear2(Tcurrent, Rm);
+      est << Rm[0][0] << " " << Rm[0][1] << " 0.000000 " << cfear_tx(Tcurrent) << " "
+          << Rm[1][0] << " " << Rm[1][1] << " 0.000000 " << cfear_ty(Tcurrent) << " "
           << "0.000000 0.000000 1.000000 0.000000\n";
       n++;
       const double tot = std::chrono::duration<double>(t2 - t_start).count();

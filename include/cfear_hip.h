@@ -150,6 +150,11 @@ typedef struct cfear_cell {
 /* MapPointNormal(cld, radius = params.res, origin = (0,0), weight_intensity, raw = false)
  * (pointnormal.cpp:65-90 -> ComputeNormals :265-297 -> ComputeSearchTreeFromCells :151-162). */
 int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** scan);
+/* MapPointNormal over given cells: raw = true (one identity cell per point, pointnormal.cpp:76-82, cell::GetIdentityCell
+ * pointnormal.h:58,80-82) and the transformed-copy constructor (pointnormal.cpp:91-110) build the cell list on the host and
+ * hand it over here; the device builds the search structure (ComputeSearchTreeFromCells :151-162) and the registration
+ * views. Synchronous. */
+int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_scan** scan);
 void cfear_scan_release(cfear_ctx* ctx, cfear_scan* scan);
 int cfear_scan_size(cfear_ctx* ctx, const cfear_scan* scan, int* n_cells);          /* GetSize() */
 int cfear_scan_download_cells(cfear_ctx* ctx, const cfear_scan* scan, cfear_cell* cells, int capacity, int* n);

@@ -128,3 +128,18 @@ def test_cpp_mirror_classes_against_oracle(oracle, tmp_path):
     rs = oracle.register_soft(scans, poses, prior, p)
     assert out["register_soft"]["ok"] == rs[0] and out["register_soft"]["residuals"] == rs[3].num_residuals
     assert np.all(np.abs(np.array(out["register_soft"]["pose"]) - rs[1][2]) < [1e-4, 1e-4, 1e-5])
+    # per-object parameter snapshots: a second registration object (P2P, no loss, uniform weights) and a coarser map on the same device
+    po = oracle.default_params(range_res=RR, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=0, cost=0, loss=0, loss_limit=0.5, covar_scale=3.0,
+                               regularization=0.7)
+    ro = oracle.register(scans, poses, po)
+    assert out["other"]["ok"] == ro[0] and out["other"]["residuals"] == ro[3].num_residuals
+    assert np.all(np.abs(np.array(out["other"]["pose"]) - ro[1][2]) < [1e-4, 1e-4, 1e-5])
+    pc = oracle.default_params(range_res=RR, z_min=60.0, res=5.0, weight_intensity=0)
+    assert out["coarse_cells"] == oracle.Scan(clouds[2], pc).size
+    # raw = true: one identity cell per point (pointnormal.cpp:76-82, pointnormal.h:63,80-82)
+    assert out["raw"]["cells"] == out["raw"]["points"] == len(clouds[2])
+    assert out["raw"]["scale"] == 1.0 and out["raw"]["cov00"] == 0.1
+    d5 = np.linalg.norm(clouds[2][:, :2] - clouds[2][5, :2], axis=1)
+    assert out["raw"]["nn5"] == int(np.argmin(d5))
+    # the transformed-copy constructor: same number of cells, the moved cell 0 is its own nearest neighbour
+    assert out["moved"]["cells"] == scans[2].size and out["moved"]["nn0"] == 0
