@@ -42,9 +42,9 @@ def test_cloud_and_cells_golden(gold):
     ctx.close()
 
 
-def test_registration_golden_trajectory(gold):
-    """Replays the golden clouds through the per-call API with the reference's caller logic
-    (odometrykeyframefuser.cpp:143-259) written out in the test."""
+def replay_clouds(clouds, cost):
+    """The reference's caller logic (odometrykeyframefuser.cpp:143-259) written out over the per-call API:
+    -> (trajectory [T, 3], per-sweep [outer, inner...] iteration counts, per-sweep cell counts)."""
     kw = dict(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4)
 
     def T(p):
@@ -54,31 +54,43 @@ def test_registration_golden_trajectory(gold):
     def xyt(M):
         return np.array([M[0, 2], M[1, 2], np.arctan2(M[1, 0], M[1, 1])])
 
+    ctx = capi.Context(capi.default_params(cost=cost, **kw), 400, 3360)
+    T_prev, Tmot = np.eye(3), np.eye(3)
+    ring, traj, iters, ncells = [], [], [], []
+    for cl in clouds:
+        c = ctx.cloud_upload(cl)
+        ctx.compensate(c, xyt(Tmot), 0)
+        cur = ctx.scan_create(c)
+        Tguess = T_prev @ Tmot
+        if not ring:
+            ring.append((cur, np.eye(3)))
+            pose = np.zeros(3)
+            iters.append([0] * 9)
+        else:
+            poses = np.array([xyt(M) for _, M in ring] + [xyt(Tguess)])
+            ok, P, cov, S = ctx.register([s for s, _ in ring] + [cur], poses)
+            iters.append([S.outer_iterations] + list(S.inner_iterations[:8]))
+            Tcur = T(P[-1])
+            Tmot = np.linalg.inv(T_prev) @ Tcur
+            Tkd = np.linalg.inv(ring[-1][1]) @ Tcur
+            if np.hypot(Tkd[0, 2], Tkd[1, 2]) > 1.5 or abs(np.arctan2(Tkd[1, 0], Tkd[1, 1])) > np.deg2rad(5):
+                ring.append((cur, Tcur))
+                ring = ring[-4:]
+            T_prev = Tcur
+            pose = xyt(Tcur)
+        traj.append(pose)
+        ncells.append(cur.size)
+    ctx.close()
+    return np.array(traj), iters, ncells
+
+
+def test_registration_golden_trajectory(gold):
+    """Replays the golden clouds through the per-call API with the reference's caller logic."""
     for cost, tag in ((1, "p2l"), (2, "p2d")):
-        ctx = capi.Context(capi.default_params(cost=cost, **kw), 400, 3360)
-        T_prev, Tmot = np.eye(3), np.eye(3)
-        ring = []
+        traj, iters, ncells = replay_clouds([gold["world_cloud_%d" % t] for t in range(8)], cost)
         for t in range(8):
-            c = ctx.cloud_upload(gold["world_cloud_%d" % t])
-            ctx.compensate(c, xyt(Tmot), 0)
-            cur = ctx.scan_create(c)
-            Tguess = T_prev @ Tmot
-            if not ring:
-                ring.append((cur, np.eye(3)))
-                pose = np.zeros(3)
-            else:
-                poses = np.array([xyt(M) for _, M in ring] + [xyt(Tguess)])
-                ok, P, cov, S = ctx.register([s for s, _ in ring] + [cur], poses)
-                assert [S.outer_iterations] + list(S.inner_iterations[:8]) == list(gold["iters_" + tag][t])
-                Tcur = T(P[-1])
-                Tmot = np.linalg.inv(T_prev) @ Tcur
-                Tkd = np.linalg.inv(ring[-1][1]) @ Tcur
-                if np.hypot(Tkd[0, 2], Tkd[1, 2]) > 1.5 or abs(np.arctan2(Tkd[1, 0], Tkd[1, 1])) > np.deg2rad(5):
-                    ring.append((cur, Tcur))
-                    ring = ring[-4:]
-                T_prev = Tcur
-                pose = xyt(Tcur)
-            assert cur.size == gold["ncells_" + tag][t]
-            assert np.all(np.abs(pose[:2] - gold["traj_" + tag][t][:2]) < 1e-4), (tag, t)
-            assert abs(pose[2] - gold["traj_" + tag][t][2]) < 1e-5
-        ctx.close()
+            if t > 0:
+                assert iters[t] == list(gold["iters_" + tag][t]), (tag, t)
+            assert ncells[t] == gold["ncells_" + tag][t]
+            assert np.all(np.abs(traj[t][:2] - gold["traj_" + tag][t][:2]) < 1e-4), (tag, t)
+            assert abs(traj[t][2] - gold["traj_" + tag][t][2]) < 1e-5
