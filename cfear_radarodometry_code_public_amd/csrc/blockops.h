@@ -164,6 +164,57 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// ---- wave64 sums of TEN doubles at once, transposed: instead of ten full reductions (six exchange steps each) the lanes
+// first split the work - after the exchange with lane ^ 1 a lane carries five of the ten sums, after lane ^ 2 three -
+// and only those are carried through the remaining four steps (rotations by 4 and 8 inside the 16-lane rows, then gfx950's
+// row and half swaps across the rows): 13 additions per lane instead of 60. On return every lane holds the wave totals of
+// its residue class lane % 4; lanes 60..63 are the ones that store them:
+//   lane 60: out[0..2] = sums 0, 1, 2   lane 62: out[0..1] = sums 3, 4   lane 61: out[0..2] = sums 5, 6, 7   lane 63: out[0..1] = sums 8, 9
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+  return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ void wave_sum10_transposed(const double (&v)[10], double (&out)[3]) {
+  const int lane = lane_id();
+  const bool odd = (lane & 1) != 0, hi2 = (lane & 2) != 0;
+  double u[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {  // lane ^ 1: even lanes keep sums 0..4, odd lanes 5..9
+    const double keep = odd ? v[k + 5] : v[k], give = odd ? v[k] : v[k + 5];
+    u[k] = keep + dpp_get<0xB1, 0xF>(give);  // quad_perm [1,0,3,2]
+  }
+  double w[3];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {  // lane ^ 2: of a lane's five sums, entries 0, 1 stay where bit 1 is clear, 3, 4 where it is set
+    const double keep = hi2 ? u[k + 3] : u[k], give = hi2 ? u[k] : u[k + 3];
+    w[k] = keep + dpp_get<0x4E, 0xF>(give);  // quad_perm [2,3,0,1]
+  }
+  w[2] = u[2] + dpp_get<0x4E, 0xF>(u[2]);    // entry 2 is carried by both
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    w[k] += dpp_get<0x124, 0xF>(w[k]);  // row_ror:4: lanes of equal lane % 4 inside a row
+    w[k] += dpp_get<0x128, 0xF>(w[k]);  // row_ror:8: every lane holds the row sum of its residue class
+    // across the four rows with the lane position kept (a row broadcast would hand every lane the value of lane 15, a
+    // different residue class): gfx950's row / half swaps. permlane16_swap(x, x) = {(r0, r0, r2, r2), (r1, r1, r3, r3)}
+    {
+      const unsigned long long b = __double_as_longlong(w[k]);
+      const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+      w[k] = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+    {  // permlane32_swap(y, y) = {(y.lo, y.lo), (y.hi, y.hi)}
+      const unsigned long long b = __double_as_longlong(w[k]);
+      const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+      w[k] = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+    out[k] = w[k];  // every lane: the wave total of the sums of its residue class
+  }
+}
+
 // In-place ascending bitonic sort of keys[0..p2) (p2 = power of two, padded by the caller).
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int p2) {
   for (int k = 2; k <= p2; k <<= 1) {

@@ -1,0 +1,364 @@
+// features_compact_dev.h -- MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells (pointnormal.cpp:265-297, :7-63,
+// :151-162) for clouds of up to CFEAR_CPT_CAP points with a working set of < 80 KB of LDS, so that TWO feature workgroups
+// share a compute unit (the path is a chain of short phases separated by barriers: a second workgroup works while the
+// first one waits). Same results as features_block (features_dev.h), which stays as the path for bigger clouds.
+//
+// What makes it small:
+//  * the dense voxel grid is a BITMAP (one bit per voxel, <= 32768 voxels = 4 KB) plus a popcount prefix per word: the rank
+//    of a voxel among the occupied ones is one word, one prefix and a popcount. The counting sort runs over the occupied
+//    voxels only (16-bit counters), and the first occupied voxel >= k of a voxel row - what the radius search needs - is
+//    the same rank query instead of a binary search in a voxel list;
+//  * sorted points are float2 + one intensity byte (9 bytes instead of 12), every index array is 16-bit;
+//  * a sample's centroid and candidate row ranges are recomputed by whoever needs them (a few LDS reads) instead of being
+//    stored per sample.
+#pragma once
+#include "features_dev.h"
+
+namespace cfear_dev {
+
+#define CFEAR_CPT_CAP 4864      // points (the reference configuration has at most A * k = 4800)
+#define CFEAR_CPT_VOXELS 32768  // voxels of the dense grid the bitmap covers
+
+struct FeatLdsC {  // byte offsets into the LDS segment
+  static constexpr size_t red_i = 0;                                        // 64 ints
+  static constexpr size_t red_f = red_i + 64 * sizeof(int);                 // 64 floats
+  static constexpr size_t bm = red_f + 64 * sizeof(float);                  // bitmap words (+1: rank(G) looks one past)
+  static constexpr size_t bmp = bm + (CFEAR_CPT_VOXELS / 32 + 4) * 4;       // u16 prefix per bitmap word (+1)
+  static constexpr size_t vst = bmp + (CFEAR_CPT_VOXELS / 32 + 8) * 2;      // u16 [cap + 2]: counters, cursors, then voxel starts
+  static constexpr size_t ord = vst + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap + 2]: parked voxel ids, unordered slots, candidate totals, chunk starts
+  static constexpr size_t chk = ord + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap]: sample of every chunk; later the float cell means
+  static constexpr size_t pw = chk + CFEAR_CPT_CAP * 2;                     // u8 [cap] intensities in sorted order
+  static constexpr size_t pxy = (pw + CFEAR_CPT_CAP + 15) / 16 * 16;        // float2 [cap] points in sorted order; before that the bearing table of the cloud pass, afterwards the grid counters
+  static constexpr size_t total = pxy + CFEAR_CPT_CAP * 8;
+};
+static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit need <= 80,384 B each (LDS comes in 1,280-byte granules)");
+
+// Returns false (before touching anything but registers) when the cloud does not fit this path: more than CFEAR_CPT_CAP
+// points or a voxel grid beyond the bitmap. zeroed: the caller cleared bm / vst already (saves a barrier).
+__device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W,
+                                                 unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed) {
+  typedef __attribute__((address_space(1))) double g_f64;
+  typedef __attribute__((address_space(1))) float g_f32;
+  typedef __attribute__((address_space(3))) unsigned l_u32;
+  typedef __attribute__((address_space(3))) unsigned short l_u16;
+  typedef __attribute__((address_space(3))) unsigned char l_u8;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) f32x2 l_f32x2;
+  l_u32* const bm = (l_u32*)(lds + FeatLdsC::bm);
+  l_u16* const bmp = (l_u16*)(lds + FeatLdsC::bmp);
+  l_u32* const vstw = (l_u32*)(lds + FeatLdsC::vst);  // packed pairs for the atomics
+  l_u16* const vst = (l_u16*)(lds + FeatLdsC::vst);
+  l_u16* const ord = (l_u16*)(lds + FeatLdsC::ord);
+  l_u16* const chk = (l_u16*)(lds + FeatLdsC::chk);
+  l_u8* const pw = (l_u8*)(lds + FeatLdsC::pw);
+  l_f32x2* const pxy = (l_f32x2*)(lds + FeatLdsC::pxy);
+  g_f64* const g_part = (g_f64*)W.part;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const g_f32* const xyi = (const g_f32*)S->xyi;
+  const int ccap = min(CFEAR_CPT_CAP, W.cap);  // points / chunk records the arrays (LDS and the global partial sums) hold
+  if (n <= 0 || n > ccap) return false;
+  // ---- PCL VoxelGrid (pointnormal.cpp:277-280), leaf = radius_/downsample_factor ----
+  const float leaf = (float)((double)P.radius / P.downsample_factor);
+  const float inv = 1.0f / leaf;
+  float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+  if (bounds) {  // block-uniform: the caller already knows the bounding box
+    mnx = bounds[0]; mxx = bounds[1]; mny = bounds[2]; mxy = bounds[3];
+  } else {
+    for (int i = tid; i < n; i += nt) {
+      const float x = xyi[3 * i], y = xyi[3 * i + 1];
+      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    float bb[4] = {mnx, mxx, mny, mxy};
+    block_bounds(bb, W.red_f);
+    mnx = bb[0]; mxx = bb[1]; mny = bb[2]; mxy = bb[3];
+  }
+  const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
+  const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
+  const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
+  const long long Gll = (long long)div0 * (long long)div1;
+  if (Gll > CFEAR_CPT_VOXELS || Gll <= 0) return false;  // block-uniform
+  const int G = (int)Gll, NW = (G >> 5) + 1;  // bitmap words incl. the one rank(G) looks at
+  if (!zeroed) {
+    for (int i = tid; i < CFEAR_CPT_VOXELS / 32 + 4; i += nt) bm[i] = 0u;
+    for (int i = tid; i < (CFEAR_CPT_CAP + 8) / 2; i += nt) vstw[i] = 0u;
+    __syncthreads();
+  }
+  // points of this thread: i = tid + r * nt (at most PT of them)
+  constexpr int PT = 10;
+  if (n > PT * nt) return false;  // block-uniform (a launch with fewer than 487 threads)
+  // ---- occupied voxels: bitmap (a point's voxel index stays in its thread's registers) ----
+  int pv[PT];
+#pragma unroll
+  for (int r = 0; r < PT; r++) {
+    const int i = tid + r * nt;
+    pv[r] = 0;
+    if (i < n) {
+      const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
+      const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+      pv[r] = ijk0 + ijk1 * div0;
+      __hip_atomic_fetch_or(&bm[pv[r] >> 5], 1u << (pv[r] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  if (pt) pt->mark();
+  // ---- popcount prefix per bitmap word; nv = occupied voxels = sample points ----
+  int nv;
+  {
+    const int wpt = (NW + nt - 1) / nt;
+    const int w0 = tid * wpt, w1 = min(NW, w0 + wpt);
+    int cnt = 0;
+    for (int w = w0; w < w1; w++) cnt += __popc(bm[w]);
+    int ex = block_exclusive_scan(cnt, W.red_i, &nv);
+    for (int w = w0; w < w1; w++) { bmp[w] = (unsigned short)ex; ex += __popc(bm[w]); }
+  }
+  __syncthreads();
+  // rank of voxel index k among the occupied voxels = number of occupied voxels below k (k in 0..G)
+  auto rank = [&](int k) -> int { return (int)bmp[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u)); };
+  // ---- stable counting sort over the occupied voxels ([3P] std::sort on the voxel index, pinned as stable): counters of
+  // voxel c at vst[c + 1] (16 bits, two per word), so that after the scatter vst[c] is the start of voxel c ----
+#pragma unroll
+  for (int r = 0; r < PT; r++) {
+    if (tid + r * nt < n) {
+      pv[r] = rank(pv[r]);  // compact voxel index from here on
+      const int c1 = pv[r] + 1;
+      __hip_atomic_fetch_add(&vstw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of the counters: entry c + 1 becomes the cursor (start) of voxel c; entry 0 stays 0
+    const int ipt = (((nv + 1) + nt - 1) / nt + 1) & ~1;  // even: a thread owns whole words
+    const int g0 = tid * ipt, g1 = min(nv + 1, g0 + ipt);
+    int cnt = 0;
+    for (int g = g0; g < g1; g++) cnt += (int)vst[g];
+    int tot;
+    int o = block_exclusive_scan(cnt, W.red_i, &tot);
+    for (int g = g0; g < g1; g++) { const int c = (int)vst[g]; vst[g] = (unsigned short)o; o += c; }
+    if (tid == 0) { S->n_samples = nv; S->n_points = n; S->status = 0; }
+    __syncthreads();
+  }
+  // scatter: the slot order inside a voxel is whatever the atomics gave; the final slot of a point is the voxel start plus
+  // the number of voxel members with a smaller point index (rank by counting)
+  int pos[PT];
+#pragma unroll
+  for (int r = 0; r < PT; r++) {
+    pos[r] = 0;
+    if (tid + r * nt < n) {
+      const int c1 = pv[r] + 1;
+      const unsigned old = __hip_atomic_fetch_add(&vstw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pos[r] = (int)((old >> (16 * (c1 & 1))) & 0xFFFFu);
+    }
+  }
+  __syncthreads();  // vst[c + 1] = end of voxel c = start of voxel c + 1 from here on; vst[0] = 0
+#pragma unroll
+  for (int r = 0; r < PT; r++)
+    if (tid + r * nt < n) ord[pos[r]] = (unsigned short)(tid + r * nt);
+  __syncthreads();
+  // final position; the point goes straight to its place in the sorted arrays (x, y as floats, the intensity - an integer
+  // 0..255 from the filter's slots - as a byte)
+#pragma unroll
+  for (int r = 0; r < PT; r++) {
+    const int i = tid + r * nt;
+    if (i < n) {
+      const int a = (int)vst[pv[r]], b = (int)vst[pv[r] + 1];
+      int c = 0;
+      for (int q = a; q < b; q++) c += (int)ord[q] < i ? 1 : 0;
+      const float x = xyi[3 * i], y = xyi[3 * i + 1], w = xyi[3 * i + 2];
+      pxy[a + c] = f32x2{x, y};
+      pw[a + c] = (unsigned char)(int)w;
+    }
+  }
+  __syncthreads();
+  if (pt) { pt->mark(); pt->mark(); pt->mark(); }
+  // ---- radius search + cell statistics per sample point (pointnormal.cpp:286-296, :7-63) ----
+  // One pass over the candidates with moments shifted by the sample point c:
+  //   mean = c + S1/S0,  cov = S2/S0 - (S1/S0)(S1/S0)^T   (== sum w_i (x_i-u)(x_i-u)^T with sum w_i = 1)
+  const float r2 = (float)((double)P.radius * (double)P.radius);
+  const float rq = P.radius * 1.0001f;
+  // centroid of sample v: float sums in ascending (voxel, point) order, divided by float(count) ([3P] PCL CentroidPoint)
+  auto centroid = [&](int v, float& cx, float& cy) {
+    const int a = (int)vst[v], b = (int)vst[v + 1];
+    float sx = 0.f, sy = 0.f;
+    for (int q = a; q < b; q++) { const f32x2 p = pxy[q]; sx += p.x; sy += p.y; }
+    const float cnt = (float)(b - a);
+    cx = sx / cnt; cy = sy / cnt;
+  };
+  struct Win { int gx0, gx1, gy0, gy1; };
+  auto window = [&](float cx, float cy) -> Win {
+    Win w;
+    w.gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0); w.gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
+    w.gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1); w.gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
+    w.gx0 = max(w.gx0, 0); w.gy0 = max(w.gy0, 0); w.gx1 = min(w.gx1, div0 - 1); w.gy1 = min(w.gy1, div1 - 1);
+    return w;
+  };
+  // candidates of voxel row gy of the window: voxels gx0..gx1 are contiguous in the sorted order
+  auto row_range = [&](const Win& w, int gy, int& a, int& b) {
+    const int k0 = w.gx0 + gy * div0, k1 = w.gx1 + gy * div0 + 1;
+    a = (int)vst[rank(k0)]; b = (int)vst[rank(k1)];
+  };
+  // Candidate counts range from 1 to ~1000 per sample point, so the work is cut into chunks of at most C candidates:
+  // (1) per sample the candidate total, (2) a scan turns the totals into a chunk list, (3) one lane per chunk accumulates
+  // partial moments, (4) the epilogue adds a sample's partials in chunk order (deterministic).
+  int C = 32, NC;
+  {
+    const int ipt = (nv + nt - 1) / nt;
+    const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
+    for (int v = i0; v < i1; v++) {
+      float cx, cy;
+      centroid(v, cx, cy);
+      const Win w = window(cx, cy);
+      int tot = 0;
+      for (int gy = w.gy0; gy <= w.gy1 && w.gx0 <= w.gx1; gy++) { int a, b; row_range(w, gy, a, b); tot += b - a; }
+      ord[v] = (unsigned short)(tot >= 6 ? tot : 0);  // fewer than six candidates can never make a cell (pointnormal.cpp:291)
+    }
+    if (pt) pt->mark();
+    int o;
+    for (;;) {  // block-uniform: double the chunk size until the chunk list fits
+      int cnt = 0;
+      for (int i = i0; i < i1; i++) cnt += ((int)ord[i] + C - 1) / C;
+      o = block_exclusive_scan(cnt, W.red_i, &NC);
+      if (NC <= ccap) break;
+      C <<= 1;
+    }
+    for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk
+      const int c = ((int)ord[i] + C - 1) / C;
+      ord[i] = (unsigned short)o;
+      for (int j = 0; j < c; j++) chk[o + j] = (unsigned short)i;
+      o += c;
+    }
+    if (tid == 0) ord[nv] = (unsigned short)NC;
+    __syncthreads();
+  }
+  if (pt) pt->mark();
+  const size_t cs = (size_t)W.cap;
+  const double wfloor = 60.0;
+  for (int wq = tid; wq < NC; wq += nt) {
+    const int v = (int)chk[wq];
+    const int j = wq - (int)ord[v];
+    float cx, cy;
+    centroid(v, cx, cy);
+    const Win win = window(cx, cy);
+    int skip = j * C, left = C;
+    int m = 0;
+    double s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
+    const double cxd = (double)cx, cyd = (double)cy;
+    for (int gy = win.gy0; gy <= win.gy1 && left > 0; gy++) {
+      int a, b;
+      row_range(win, gy, a, b);
+      const int len = b - a;
+      if (skip >= len) { skip -= len; continue; }
+      const int s = a + skip, e = min(b, s + left);
+      for (int q = s; q < e; q += 4) {
+        f32x2 p[4]; int iw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int qq = min(q + u, e - 1); p[u] = pxy[qq]; iw[u] = (int)pw[qq]; }  // independent LDS loads first
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float dx = cx - p[u].x, dy = cy - p[u].y;
+          float d2 = dx * dx; d2 += dy * dy;
+          if (q + u < e && d2 < r2) {  // pointnormal.cpp:291 radius test (float, strict)
+            const double w = P.weight_intensity ? fmax((double)iw[u] - wfloor, 0.0) : 1.0;  // :15
+            const double ex = (double)p[u].x - cxd, ey = (double)p[u].y - cyd;
+            m++; s0 += w; s1x += w * ex; s1y += w * ey;
+            sxx += w * (ex * ex); sxy += w * (ex * ey); syy += w * (ey * ey);
+          }
+        }
+      }
+      left -= e - s; skip = 0;
+    }
+    g_part[wq] = (double)m; g_part[cs + wq] = s0; g_part[2 * cs + wq] = s1x; g_part[3 * cs + wq] = s1y;
+    g_part[4 * cs + wq] = sxx; g_part[5 * cs + wq] = sxy; g_part[6 * cs + wq] = syy;
+  }
+  __syncthreads();
+  if (pt) pt->mark();
+  // ---- cell epilogue + compaction: a cell is built in registers and, if it is valid, written straight to its final
+  // slot; one block scan per round of blockDim samples keeps the sample order (pointnormal.cpp:292-294)
+  int n_cells_out;
+  // float cell means for the grid build go over the bitmap and its prefix (the rank queries are done): no read-back from memory
+  constexpr int LM_CAP = (int)((FeatLdsC::vst - FeatLdsC::bm) / 8);
+  typedef __attribute__((address_space(3))) float l_f32;
+  l_f32* const lmw = (l_f32*)(lds + FeatLdsC::bm);
+  {
+    int base = 0;
+    const int cap_cells = S->cap_cells;
+    for (int v0 = 0; v0 < nv; v0 += nt) {
+      const int v = v0 + tid;
+      cfear_cell c;
+      int valid = 0;
+      if (v < nv) {
+        double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
+        const int w0 = (int)ord[v], w1 = (int)ord[v + 1];
+        for (int w = w0; w < w1; w += 2) {  // two chunks per trip: fourteen loads in flight together, added in chunk order
+          const int wb = min(w + 1, w1 - 1);
+          double pa[7], pb[7];
+#pragma unroll
+          for (int q = 0; q < 7; q++) { pa[q] = g_part[q * cs + w]; pb[q] = g_part[q * cs + wb]; }
+          md += pa[0]; s0 += pa[1]; s1x += pa[2]; s1y += pa[3]; sxx += pa[4]; sxy += pa[5]; syy += pa[6];
+          if (w + 1 < w1) { md += pb[0]; s0 += pb[1]; s1x += pb[2]; s1y += pb[3]; sxx += pb[4]; sxy += pb[5]; syy += pb[6]; }
+        }
+        const int m = (int)md;
+        if (m >= 6) {  // :291
+          float cx, cy;
+          centroid(v, cx, cy);
+          const double m1x = s1x / s0, m1y = s1y / s0;
+          const double ux = (double)cx + m1x, uy = (double)cy + m1y;
+          const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
+          double lmin, lmax, vmin[2], vmax[2];
+          eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
+          const double cond = fabs(lmax / lmin);  // :53
+          const double det = lmax * lmin;         // :54
+          valid = ((cond <= 10000) && (det > 0.00001) && lmin > 0 && lmax > 0) ? 1 : 0;  // :56
+          if (valid) {
+            if (vmin[0] * (0.0 - ux) + vmin[1] * (0.0 - uy) < 0) { vmin[0] = -vmin[0]; vmin[1] = -vmin[1]; }  // :59-61
+            c.mean[0] = ux; c.mean[1] = uy;
+            c.cov[0] = cxx; c.cov[1] = cyx; c.cov[2] = cyy;
+            c.normal[0] = vmin[0]; c.normal[1] = vmin[1];
+            c.orth[0] = vmax[0]; c.orth[1] = vmax[1];
+            c.lambda_min = lmin; c.lambda_max = lmax;
+            c.scale = log(1.0 + cond / 2);  // :57
+            c.sum_intensity = s0; c.avg_intensity = s0 / m;
+            c.nsamples = m; c.valid = 1;
+          }
+        }
+      }
+      int round_total;
+      const int o = base + block_exclusive_scan(valid, W.red_i, &round_total);
+      if (valid && o < cap_cells) {
+        typedef __attribute__((address_space(1))) cfear_cell g_cell;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) f64x2 g_f64x2;
+        g_cell* gc = (g_cell*)S->cells + o;
+        gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
+        gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
+        gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
+        gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        g_f32* mf = (g_f32*)S->mean_f;
+        mf[2 * o] = (float)c.mean[0];
+        mf[2 * o + 1] = (float)c.mean[1];
+        if (o < LM_CAP) { lmw[2 * o] = (float)c.mean[0]; lmw[2 * o + 1] = (float)c.mean[1]; }
+        const size_t cc = (size_t)cap_cells;
+        g_f64* rs = (g_f64*)S->rsrc + o;
+        rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
+        rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
+        g_f64x2* rt = (g_f64x2*)(S->rtar + 8 * (size_t)o);
+        rt[0] = f64x2{c.mean[0], c.mean[1]}; rt[1] = f64x2{c.normal[0], c.normal[1]};
+        rt[2] = f64x2{(double)c.nsamples, c.scale};
+      }
+      base += round_total;
+    }
+    n_cells_out = base < cap_cells ? base : cap_cells;
+    if (tid == 0) S->n_cells = n_cells_out;
+    __syncthreads();
+  }
+  if (pt) { pt->mark(); pt->mark(); }
+  // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162): counters and offsets go over
+  // the staged points (consumed)
+  FeatureScratch Wg = W;
+  Wg.keys = reinterpret_cast<uint64_t*>(lds + FeatLdsC::pxy);
+  Wg.tab_voxels = (int)(CFEAR_CPT_CAP * 8 / 2);  // ints that fit the region x 2 (cell_grid_block's unit: 16-bit counters)
+  Wg.vlist = reinterpret_cast<int*>(lds + FeatLdsC::bm);
+  Wg.lds = true;
+  cell_grid_block(S, n_cells_out, P, Wg, n_cells_out <= LM_CAP, pt);
+  return true;
+}
+
+}  // namespace cfear_dev

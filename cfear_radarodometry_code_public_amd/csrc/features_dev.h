@@ -187,7 +187,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
     }
   }
   // the thread's slots in registers (one batch of loads) when there are few of them, as in every reference configuration
-  constexpr int SV = 8;
+  constexpr int SV = 10;  // A * k / blockDim slots: 4800 / 512
   const bool few = ipt <= SV;  // block-uniform
   uint32_t sv[SV];
 #pragma unroll

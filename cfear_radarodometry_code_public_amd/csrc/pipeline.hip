@@ -17,28 +17,17 @@
 
 #include "common.h"
 #include "registration_dev.h"
+#include "features_compact_dev.h"
 
 using namespace cfear_dev;
 
 namespace {
 
-constexpr int BLOCK_F = 1024;  // features / cloud kernels
+constexpr int BLOCK_F = 512;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
 constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
 static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
 constexpr int MAX_SCANS = 64;  // keyframes + current
-constexpr int LDS_P2 = 8192;   // sort keys held in LDS (clouds up to CFEAR_LDS_POINT_CAP points)
-
-struct FeatLds {  // byte offsets into the static LDS segment of the features kernels
-  static constexpr size_t red_i = 0;                                   // 64 ints
-  static constexpr size_t red_f = red_i + 64 * sizeof(int);           // 64 floats
-  static constexpr size_t keys = red_f + 64 * sizeof(float);          // LDS_P2 u64, later the sorted points
-  static constexpr size_t order = keys + LDS_P2 * sizeof(uint64_t);   // CFEAR_LDS_POINT_CAP ints
-  static constexpr size_t vstart = order + CFEAR_LDS_POINT_CAP * sizeof(int);      // +1 (padded)
-  static constexpr size_t vlist = vstart + (CFEAR_LDS_POINT_CAP + 8) * sizeof(int);
-  static constexpr size_t srng = vlist + CFEAR_LDS_POINT_CAP * sizeof(int);  // per sample: 8 x u16 candidate ranges + centroid xy
-  static constexpr size_t total = srng + CFEAR_LDS_SAMPLE_CAP * 24;
-};
-static_assert(FeatLds::total <= 160 * 1024, "a workgroup can have 160 KB of LDS");
+static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit");
 struct RegLds {  // registration kernels
   static constexpr size_t red_d = 0;                                  // 10 sums x CFEAR_RED_STRIDE waves
   static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*MAX_SCANS doubles
@@ -82,41 +71,27 @@ struct OdoParams {
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
-// LDS = true: keys/order/vstart/vlist and the staged points are LDS arrays (ds_* instructions after
-// inlining); LDS = false: their global twins for clouds above CFEAR_LDS_POINT_CAP points.
-template <bool LDS>
-__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds, bool tab_zeroed = false) {
+// working memory of one feature build: global arrays of the general path (clouds beyond the compact path's limits) + the two
+// LDS reduction arrays
+__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds) {
   FeatureScratch W;
-  if (LDS) {
-    W.keys = reinterpret_cast<uint64_t*>(lds + FeatLds::keys);
-    W.spts = reinterpret_cast<float*>(lds + FeatLds::keys);
-    W.order = reinterpret_cast<int*>(lds + FeatLds::order);
-    W.vstart = reinterpret_cast<int*>(lds + FeatLds::vstart);
-    W.vlist = reinterpret_cast<int*>(lds + FeatLds::vlist);
-    W.srng = lds + FeatLds::srng;
-  } else {
-    W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
-    W.srng = nullptr;
-  }
-  W.vcur = B.vcur; W.lds = LDS; W.tab_zeroed = LDS && tab_zeroed;
-  W.tab_voxels = LDS ? (LDS_P2 * 4 < 32768 ? LDS_P2 * 4 - 2 : 32768) : 0;  // 16-bit counters over the key region, values < 65536
+  W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
+  W.srng = nullptr;
+  W.vcur = B.vcur; W.lds = false; W.tab_zeroed = false; W.tab_voxels = 0;
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
-  W.cap = (LDS && B.cap_points > CFEAR_LDS_POINT_CAP) ? CFEAR_LDS_POINT_CAP : B.cap_points;
+  W.cap = B.cap_points;
   W.samples = B.samples;
-  W.red_i = reinterpret_cast<int*>(lds + FeatLds::red_i);
-  W.red_f = reinterpret_cast<float*>(lds + FeatLds::red_f);
+  W.red_i = reinterpret_cast<int*>(lds + FeatLdsC::red_i);
+  W.red_f = reinterpret_cast<float*>(lds + FeatLdsC::red_f);
   return W;
 }
+// byte_intensities: every intensity of the cloud is an integer in 0..255 (block-uniform; always true for clouds made from
+// the filter's slots) - the compact path keeps them as bytes
 __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
-                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds = nullptr,
-                                                  bool tab_zeroed = false) {
-  if (n <= CFEAR_LDS_POINT_CAP) {  // block-uniform
-    const FeatureScratch W = make_fscratch<true>(B, lds, tab_zeroed);
-    features_block(S, n, P, W, next_pow2(n), pt, bounds);
-  } else {
-    const FeatureScratch W = make_fscratch<false>(B, lds);
-    features_block(S, n, P, W, next_pow2(n), pt, bounds);
-  }
+                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities) {
+  const FeatureScratch W = make_fscratch(B, lds);
+  if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed)) return;
+  features_block(S, n, P, W, next_pow2(n), pt, bounds);
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
   RegScratch W;
@@ -143,19 +118,24 @@ __global__ __launch_bounds__(BLOCK_F) void compensate_kernel(float* xyi, const i
 
 __global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const float* src_xyi, const int* d_n, FeatureParams P,
                                                            BlockScratch B) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::total];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   int n = *d_n;
   if (n > S->cap_points) n = S->cap_points;
-  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) S->xyi[i] = src_xyi[i];
-  __syncthreads();
-  features_dispatch(S, n, P, B, lds, nullptr);
+  int bytes = 1;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = src_xyi[3 * i], y = src_xyi[3 * i + 1], w = src_xyi[3 * i + 2];
+    S->xyi[3 * i] = x; S->xyi[3 * i + 1] = y; S->xyi[3 * i + 2] = w;
+    bytes &= (w >= 0.f && w <= 255.f && w == (float)(int)w) ? 1 : 0;
+  }
+  const bool byte_intensities = __syncthreads_and(bytes) != 0;
+  features_dispatch(S, n, P, B, lds, nullptr, nullptr, false, byte_intensities);
 }
 
 // MapPointNormal from given cells (raw = true identity cells, pointnormal.cpp:76-82; the transformed-copy constructor
 // :91-110): the cells are already in S->cells; this writes their float means, the registration views and the search grid
 __global__ __launch_bounds__(BLOCK_F) void scan_from_cells_kernel(ScanDev* S, int n, FeatureParams P, BlockScratch B) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::keys];  // the two reduction arrays
-  const FeatureScratch W = make_fscratch<false>(B, lds);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::bm];  // the two reduction arrays
+  const FeatureScratch W = make_fscratch(B, lds);
   const size_t cc = (size_t)S->cap_cells;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const cfear_cell c = S->cells[i];
@@ -225,10 +205,10 @@ __global__ __launch_bounds__(BLOCK_R, 3) void get_cost_samples_kernel(ScanDev* c
 // state on the device, split after the feature build (:161) ------------------------------------------
 // TIMED: per-phase timestamps (tools/); the production instantiation carries no timer at all
 template <bool TIMED>
-__global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
-                                                                const SeqState* states, ScanDev* const* scan_slots,
-                                                                const BlockScratch* scratch) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLds::total];
+__global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
+                                                                   const SeqState* states, ScanDev* const* scan_slots,
+                                                                   const BlockScratch* scratch) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   const int q = OP.seq0 + blockIdx.x;
   const SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
@@ -236,21 +216,21 @@ __global__ __launch_bounds__(BLOCK_F) void features_step_kernel(const uint32_t* 
   const Aff2 TprevMot = st->Tmot;  // :146
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   if (TIMED) pt.mark();
-  // the dense voxel table of the counting sort starts all-zero (cleared here: the barriers of the cloud pass publish it)
+  // the voxel bitmap and the counting-sort counters start all-zero (cleared here: the barriers of the cloud pass publish it)
   {
-    uint4* kz = reinterpret_cast<uint4*>(lds + FeatLds::keys);
-    for (int i = threadIdx.x; i < (int)(LDS_P2 * sizeof(uint64_t) / sizeof(uint4)); i += BLOCK_F) kz[i] = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds + FeatLdsC::bm);
+    for (int i = threadIdx.x; i < (int)((FeatLdsC::ord - FeatLdsC::bm) / 4); i += BLOCK_F) z[i] = 0u;
   }
   // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
   double mot[3]; aff_to_xyt(TprevMot, mot);
   float bounds[4];
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
-                                 reinterpret_cast<int*>(lds + FeatLds::red_i), reinterpret_cast<float*>(lds + FeatLds::red_f),
-                                 reinterpret_cast<double*>(lds + FeatLds::order),  // 6 doubles per bearing in the (still unused) order array
-                                 (int)(CFEAR_LDS_POINT_CAP * sizeof(int) / (6 * sizeof(double))), bounds);
+                                 reinterpret_cast<int*>(lds + FeatLdsC::red_i), reinterpret_cast<float*>(lds + FeatLdsC::red_f),
+                                 reinterpret_cast<double*>(lds + FeatLdsC::pxy),  // 6 doubles per bearing where the sorted points go later
+                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds);
   if (TIMED) { pt.mark(); pt.mark(); }
-  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true);  // :161
+  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true);  // :161
 }
 
 template <bool TIMED>
@@ -404,8 +384,8 @@ ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   ScratchLayout L;
   int p2 = 1; while (p2 < cap_points) p2 <<= 1;
   L.p2cap = p2;
-  L.big = cap_points > CFEAR_LDS_POINT_CAP;  // the LDS arrays need global twins only for big clouds
-  const size_t cp = L.big ? (size_t)cap_points : 1, kp = L.big ? (size_t)p2 : 1;
+  L.big = true;  // the general feature path (clouds beyond the compact path's limits) works in these global arrays
+  const size_t cp = (size_t)cap_points, kp = (size_t)p2;
   size_t o = 0;
   L.keys = o; o = align_up(o + sizeof(uint64_t) * kp, 256);
   L.spts = o; o = align_up(o + sizeof(float) * 3 * cp, 256);

@@ -254,13 +254,16 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
       a.h11 += j1 * j1; a.h12 += j1 * j2; a.h22 += j2 * j2;
     }
   }
-  double v[10] = {a.cost, a.g0, a.g1, a.g2, a.h00, a.h01, a.h02, a.h11, a.h12, a.h22};
-#pragma unroll
-  for (int i = 0; i < 10; i++) v[i] = wave_sum_dpp(v[i]);
-  if (lane_id() == 0) {
+  const double v[10] = {a.cost, a.g0, a.g1, a.g2, a.h00, a.h01, a.h02, a.h11, a.h12, a.h22};
+  double t[3];
+  wave_sum10_transposed(v, t);  // lanes 60..63 end up with the ten wave totals between them (blockops.h)
+  const int lane = lane_id();
+  if (lane >= 60) {
     auto* red = CFEAR_LDS_PTR(double, ls->rw.red);  // ds_write, not flat stores
-#pragma unroll
-    for (int i = 0; i < 10; i++) red[i * CFEAR_RED_STRIDE + wave] = v[i];
+    const int first = lane == 60 ? 0 : (lane == 62 ? 3 : (lane == 61 ? 5 : 8));  // index of the lane's first sum
+    red[first * CFEAR_RED_STRIDE + wave] = t[0];
+    red[(first + 1) * CFEAR_RED_STRIDE + wave] = t[1];
+    if ((lane & 2) == 0) red[(first + 2) * CFEAR_RED_STRIDE + wave] = t[2];
   }
 }
 template <int COST, bool HUBER>

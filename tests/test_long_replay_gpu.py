@@ -69,5 +69,5 @@ def test_1000_sweep_bag_replay_matches_oracle_at_every_sweep(oracle, tmp_path):
     d_dev_full = kitti.drift(gtk, kitti.poses_from_xyt(out["poses"]))  # full precision poses: 1e-6
     assert abs(d_dev_full["translation_percent"] - d_cpu["translation_percent"]) < 1e-6
     assert abs(d_dev_full["rotation_deg_per_100m"] - d_cpu["rotation_deg_per_100m"]) < 1e-6
-    assert abs(out["drift"]["translation_percent"] - d_dev_full["translation_percent"]) < 1e-9  # replay.py reports the full-precision drift
+    assert abs(out["drift"]["translation_percent"] - d_dev_full["translation_percent"]) < 1e-5  # replay.py: full-precision poses and ground truth (gtk above was read back from 6-decimal text)
     assert d_cpu["translation_percent"] < 5.0  # known answer: the odometry follows the synthetic ground truth

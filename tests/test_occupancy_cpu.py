@@ -1,5 +1,5 @@
 """Occupancy guard: the step kernels are tuned to a number of resident wavefronts that a few extra registers or LDS bytes
-silently take away (registration: 168 VGPRs incl. AGPRs and 53,760 B of LDS for three workgroups per CU; filter: 72 VGPRs for
+silently take away (features: 128 VGPRs and 80,384 B of LDS for two 512-thread workgroups per CU; registration: 168 VGPRs incl. AGPRs and 53,760 B of LDS for three workgroups per CU; filter: 72 VGPRs for
 seven waves per SIMD). Reads the compiler's kernel-resource remarks for gfx950 - no GPU needed."""
 import os
 import re
@@ -33,7 +33,7 @@ def test_step_kernels_keep_their_occupancy(tmp_path):
     reg = [v for n, v in k.items() if "register_step_kernelILb0" in n][0]
     feat = [v for n, v in k.items() if "features_step_kernelILb0" in n][0]
     assert reg["Occupancy"] >= 3 and reg["LDS"] <= 53760, reg      # three 256-thread workgroups per CU
-    assert feat["Occupancy"] >= 4 and feat["ScratchSize"] == 0, feat  # one 1024-thread workgroup per CU, no scratch
+    assert feat["Occupancy"] >= 4 and feat["LDS"] <= 80384 and feat["ScratchSize"] == 0, feat  # two 512-thread workgroups per CU, no scratch
     k = remarks("kstrongest.hip", tmp_path)
     flt = [v for n, v in k.items() if "kstrongest_kernelILi4ELi7" in n][0]
     assert flt["Occupancy"] >= 7 and flt["ScratchSize"] == 0, flt   # seven waves per SIMD, no spills
