@@ -27,7 +27,7 @@ struct FeatLdsC {  // byte offsets into the LDS segment
   static constexpr size_t vst = bmp + (CFEAR_CPT_VOXELS / 32 + 8) * 2;      // u16 [cap + 2]: counters, cursors, then voxel starts
   static constexpr size_t ord = vst + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap + 2]: parked voxel ids, unordered slots, candidate totals, chunk starts
   static constexpr size_t chk = ord + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap]: sample of every chunk; later the float cell means
-  static constexpr size_t pw = chk + CFEAR_CPT_CAP * 2;                     // u8 [cap] intensities in sorted order
+  static constexpr size_t pw = chk + CFEAR_CPT_CAP * 2;                     // u8 [cap] moment weights (from the intensities) in sorted order
   static constexpr size_t pxy = (pw + CFEAR_CPT_CAP + 15) / 16 * 16;        // float2 [cap] points in sorted order; before that the bearing table of the cloud pass, afterwards the grid counters
   static constexpr size_t total = pxy + CFEAR_CPT_CAP * 8;
 };
@@ -164,7 +164,9 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       for (int q = a; q < b; q++) c += (int)ord[q] < i ? 1 : 0;
       const float x = xyi[3 * i], y = xyi[3 * i + 1], w = xyi[3 * i + 2];
       pxy[a + c] = f32x2{x, y};
-      pw[a + c] = (unsigned char)(int)w;
+      // what the moments need of the intensity: the weight max(I - 60, 0) (pointnormal.cpp:15), an integer 0..195, or 1
+      const int iw = (int)w;
+      pw[a + c] = (unsigned char)(P.weight_intensity ? (iw > 60 ? iw - 60 : 0) : 1);
     }
   }
   __syncthreads();
@@ -198,7 +200,9 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   // Candidate counts range from 1 to ~1000 per sample point, so the work is cut into chunks of at most C candidates:
   // (1) per sample the candidate total, (2) a scan turns the totals into a chunk list, (3) one lane per chunk accumulates
   // partial moments, (4) the epilogue adds a sample's partials in chunk order (deterministic).
-  int C = 32, NC;
+  // (chunks of 16: with 512 lanes and some 300-1500 samples of 6..300 candidates each, shorter chunks spread the work more
+  // evenly over the lanes than chunks of 32 - fewer lanes wait for the longest chunk of their wave)
+  int C = 16, NC, NA;  // chunk size, chunks, samples that have chunks ("active": only they can become cells)
   {
     const int ipt = (nv + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
@@ -211,26 +215,29 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       ord[v] = (unsigned short)(tot >= 6 ? tot : 0);  // fewer than six candidates can never make a cell (pointnormal.cpp:291)
     }
     if (pt) pt->mark();
-    int o;
-    for (;;) {  // block-uniform: double the chunk size until the chunk list fits
-      int cnt = 0;
-      for (int i = i0; i < i1; i++) cnt += ((int)ord[i] + C - 1) / C;
-      o = block_exclusive_scan(cnt, W.red_i, &NC);
-      if (NC <= ccap) break;
+    int o, oa;
+    for (;;) {  // block-uniform: double the chunk size until the chunk list and the active-sample list fit side by side
+      int cnt = 0, act = 0;
+      for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) / C; act += t > 0 ? 1 : 0; }
+      int tot2;
+      const int ex = block_exclusive_scan(cnt | (act << 16), W.red_i, &tot2);  // both counts < 32768: one scan for the two
+      o = ex & 0xFFFF; oa = ex >> 16; NC = tot2 & 0xFFFF; NA = tot2 >> 16;
+      if (NC + NA <= ccap) break;
       C <<= 1;
     }
-    for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk
-      const int c = ((int)ord[i] + C - 1) / C;
+    for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk, active samples in order
+      const int t = (int)ord[i];
+      const int c = (t + C - 1) / C;
       ord[i] = (unsigned short)o;
       for (int j = 0; j < c; j++) chk[o + j] = (unsigned short)i;
       o += c;
+      if (t > 0) { chk[NC + oa] = (unsigned short)i; oa++; }
     }
     if (tid == 0) ord[nv] = (unsigned short)NC;
     __syncthreads();
   }
   if (pt) pt->mark();
   const size_t cs = (size_t)W.cap;
-  const double wfloor = 60.0;
   for (int wq = tid; wq < NC; wq += nt) {
     const int v = (int)chk[wq];
     const int j = wq - (int)ord[v];
@@ -256,7 +263,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
           const float dx = cx - p[u].x, dy = cy - p[u].y;
           float d2 = dx * dx; d2 += dy * dy;
           if (q + u < e && d2 < r2) {  // pointnormal.cpp:291 radius test (float, strict)
-            const double w = P.weight_intensity ? fmax((double)iw[u] - wfloor, 0.0) : 1.0;  // :15
+            const double w = (double)iw[u];  // the weight byte staged with the point (:15)
             const double ex = (double)p[u].x - cxd, ey = (double)p[u].y - cyd;
             m++; s0 += w; s1x += w * ex; s1y += w * ey;
             sxx += w * (ex * ex); sxy += w * (ex * ey); syy += w * (ey * ey);
@@ -280,11 +287,12 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
-    for (int v0 = 0; v0 < nv; v0 += nt) {
-      const int v = v0 + tid;
+    for (int a0 = 0; a0 < NA; a0 += nt) {  // rounds over the active samples, in sample order
+      const int ai = a0 + tid;
       cfear_cell c;
       int valid = 0;
-      if (v < nv) {
+      if (ai < NA) {
+        const int v = (int)chk[NC + ai];
         double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
         const int w0 = (int)ord[v], w1 = (int)ord[v + 1];
         for (int w = w0; w < w1; w += 2) {  // two chunks per trip: fourteen loads in flight together, added in chunk order

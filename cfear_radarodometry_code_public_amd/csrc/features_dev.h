@@ -78,6 +78,7 @@ struct FeatureScratch {
 #define CFEAR_LDS_SAMPLE_CAP 1365
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
+#define CFEAR_INV_TWO_PI 0.15915494309189533576888376337251
 
 // getPeaksFilteredPointCloud (radar_filters.cpp:309-337): row-major over (bearing, slot).
 // trig[b] = (cos, sin) of theta = (b+1)/A*2pi computed by the host libm. Returns the point count.
@@ -140,7 +141,9 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
 //   atan2(y, x) = theta_b + atan((y c_b - x s_b) / (x c_b + y s_b)),  argument ~1e-7 => atan(t) = t to f64 precision
 //   sin/cos(arg) around arg_b = d_b * m2 to second order in (arg - arg_b) ~ 1e-9
 // which agrees with evaluating the reference's expressions to within f64 rounding (the test tolerance on
-// compensated points stays one float ulp, as for any two libm implementations).
+// compensated points stays one float ulp, as for any two libm implementations). The sweep fraction a / (2 pi) is a
+// multiplication by the rounded reciprocal here (a double division costs some 35 instructions per point): one ulp of d,
+// 1e-16 of the point's coordinates before they are rounded to float.
 // Compensate (utils.cpp:96-107) of one point as written: atan2, sweep fraction, rotation by the scaled motion
 __device__ __noinline__ float2 compensate_point_plain(float x, float y, double m0, double m1, double m2, int ccw) {
   const double px = (double)x, py = (double)y;
@@ -150,6 +153,18 @@ __device__ __noinline__ float2 compensate_point_plain(float x, float y, double m
   double s1, c1;
   sincos(d * m2, &s1, &c1);
   return make_float2((float)((c1 * px + (-s1) * py) + d * m0), (float)((s1 * px + c1 * py) + d * m1));
+}
+
+// quotient of a small numerator by a well-scaled denominator (the ray-offset term of the compensation: |num| ~ 1e-7 den,
+// den = a range of 2.5 .. 400 m): hardware reciprocal, two Newton steps, one residual correction - the quotient without the
+// scaling / special-case handling of a full IEEE division (a third of its instructions); agrees with it to an ulp of a
+// term that is added to an angle 1e7 times its size.
+__device__ __forceinline__ double div_well_scaled(double num, double den) {
+  double r = __builtin_amdgcn_rcp(den);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  const double q = num * r;
+  return __builtin_fma(__builtin_fma(-den, q, num), r, q);
 }
 
 __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
@@ -219,8 +234,8 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       } else if (compensate) {
         const double px = (double)x, py = (double)y;
         const double ab = ltab[6 * b], s_b = ltab[6 * b + 1], c_b = ltab[6 * b + 2], d_b = ltab[6 * b + 3];
-        const double a = ab + (py * cb - px * sb) / (px * cb + py * sb);
-        const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+        const double a = ab + div_well_scaled(py * cb - px * sb, px * cb + py * sb);
+        const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;  // (one ulp of the quotient by 2 pi: see cloud_step_block)
         const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
         const double e = d * m2 - d_b * m2;
         const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
@@ -247,8 +262,8 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       const double px = (double)(float)(rad * cb), py = (double)(float)(rad * sb);  // :329-330 (float store, read back)
       const double ab = ltab[6 * bb], s_b = ltab[6 * bb + 1], c_b = ltab[6 * bb + 2], d_b = ltab[6 * bb + 3];
       const double den = px * cb + py * sb;
-      const double a = ab + (py * cb - px * sb) / (p.on ? den : 1.0);
-      const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
+      const double a = ab + div_well_scaled(py * cb - px * sb, p.on ? den : 1.0);
+      const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;
       const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
       const double e = d * m2 - d_b * m2;
       const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);

@@ -2,7 +2,7 @@
 # run on the GPU box: regenerates the files that get copied into profiles/ (prefix = $1, e.g. r01)
 P=${1:-r01}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  K1_N=1536 K1_REPS=2 K1_CONFIGS="7,4,0" timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_k1_$c -o k1 -- python $R/tools/gpu_time_k1.py > $O/${P}_pmc_k1_$c.log 2>&1
+  K1_N=1536 K1_REPS=2 K1_CONFIGS="7,4" timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_k1_$c -o k1 -- python $R/tools/gpu_time_k1.py > $O/${P}_pmc_k1_$c.log 2>&1
 done
 python $R/tools/pmc_k1_traffic_report.py $(find /tmp/pmc_k1_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_k1_WRITE_SIZE -name "*.db" | head -1) 1536 $O/${P}_k1_traffic.json
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $R/bench.py --no-cpu-baseline --stream-steps 0 > $O/${P}_bench_prof.log 2>&1
