@@ -101,9 +101,12 @@ __device__ __forceinline__ int block_sum(int v, int* scratch) {
 }
 
 // Exclusive prefix sum of one int per thread; *total = block sum. scratch: >= 32 ints in LDS.
+// NT: threads of the workgroup when the caller knows them at compile time (blockDim.x is a load from the dispatch packet:
+// a round trip to memory in every out-of-line function that asks for it)
+template <int NT = 0>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
   auto* sl = CFEAR_LDS_PTR(int, scratch);
-  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = NT ? (NT + 63) >> 6 : (blockDim.x + 63) >> 6;
   const int inc = wave_inclusive_scan(v);
   __syncthreads();
   if (lane == 63) sl[w] = inc;
@@ -120,10 +123,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
 
 // Exclusive prefix sum of one 64-bit value per thread (e.g. four 16-bit counters packed side by side);
 // *total = block sum. scratch: >= 32 unsigned long long in LDS.
+template <int NT = 0>
 __device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long* scratch,
                                                                       unsigned long long* total) {
   auto* sl = CFEAR_LDS_PTR(unsigned long long, scratch);
-  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = NT ? (NT + 63) >> 6 : (blockDim.x + 63) >> 6;
   unsigned long long inc = v;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int BLOCK_F = 512;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
 constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
+static_assert(BLOCK_R == CFEAR_REG_BLOCK, "registration_dev.h is compiled for this workgroup size");
 static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
 constexpr int MAX_SCANS = 64;  // keyframes + current
 static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit");

@@ -115,6 +115,9 @@ struct SolveSummary { int num_iterations; int termination; double final_cost; do
 #define CFEAR_REG_MAX_SCANS 64
 #define CFEAR_RED_STRIDE 8  // partial sums of up to 8 waves per quantity (W.red)
 #define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
+#define CFEAR_REG_BLOCK 256 // threads of every workgroup that runs this code (pipeline.hip BLOCK_R): a compile-time constant,
+                            // because blockDim.x is a load from the dispatch packet - a round trip to memory wherever an
+                            // out-of-line function asks for it (the evaluation did, thirteen times per registration)
 
 enum { REG_CMD_BUILD = 1, REG_CMD_EVAL = 2, REG_CMD_DONE = 3 };
 enum { REG_ST_BUILD = 0, REG_ST_LM_IT0 = 1, REG_ST_LM_CAND = 2, REG_ST_COV = 3 };
@@ -133,6 +136,7 @@ struct RegShared {
   double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
   double Trel[CFEAR_REG_MAX_SCANS][6];  // Ttar^-1 * Tsrc (n_scan_normal.cpp:224)
   GridView kf[CFEAR_REG_MAX_SCANS];      // 1-NN search view of every scan (filled once per Register call)
+  const double* srs; long long scc;      // source scan (the last one): its SoA cell view (ScanDev::rsrc) and that array's stride
   // parameter blocks the out-of-line functions take by reference: kept here so that they are LDS reads, not reads
   // of a per-thread stack copy
   RegParams rp; RegScratch rw; RegIo rio;
@@ -200,7 +204,7 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
   } rd;
   rd.l = (lds_cdouble*)lds_match_base(); rd.g = ls->rw.tmx; rd.cap = (size_t)ls->rw.cap;
   const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
-  const int nthr = min((int)blockDim.x, CFEAR_EVAL_WAVES * 64);
+  const int nthr = min(CFEAR_REG_BLOCK, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < M; i += nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
     const double sx = rd(5, i), sy = rd(6, i), tmx = rd(0, i), tmy = rd(1, i), wgt = rd(7, i);
@@ -431,52 +435,60 @@ __device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0
 // ti[u] = matched target cell of keyframe i0 + u or -1.
 template <int NI, int NC>
 __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegShared* sh, int nk, int i0, int j, double curr_radius, int* ti) {
+  // Branch-free with clamped addresses and global-typed pointers: every load of a phase is issued unconditionally (a
+  // keyframe that does not exist, an empty window or a candidate past the end reads a valid dummy address and is masked
+  // afterwards), so that the loads of the NI keyframes are in flight together - with the loads inside conditionals the
+  // compiler waited for one keyframe's data before it issued the next one's, and generic pointers made them flat loads
+  // that also wait for the LDS counter. Round trips per call: source cell, bucket bounds, candidates (NC per keyframe per
+  // trip), gate normals.
+  typedef __attribute__((address_space(1))) const double g_cf64;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) const u32x2 g_cu32x2;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) const f32x4 g_cf32x4;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) const f64x2 g_cf64x2;
+  (void)src;
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
-  const size_t cc = (size_t)src->cap_cells;
-  const double* rs = src->rsrc + j;
-  const double mx = rs[0], my = rs[cc];
+  const size_t cc = (size_t)sh->scc;
+  g_cf64* rs = (g_cf64*)sh->srs + j;
+  const double mx = rs[0], my = rs[cc], snx = rs[2 * cc], sny = rs[3 * cc];  // mean and normal of the source cell: one round trip
   const double m = curr_radius * (1.0 + 1e-6) + 1e-6;  // window padding of scan_closest
   float qx[NI], qy[NI];
-  int nrows[NI], wide = 0;
-  int lo[NI][3], hi[NI][3];
+  int nrows[NI], wide = 0, kf[NI];
+  u32x2 L[NI], H[NI];
 #pragma unroll
   for (int u = 0; u < NI; u++) {
-    const int i = i0 + u;
-    qx[u] = 0.f; qy[u] = 0.f; nrows[u] = 0;
-#pragma unroll
-    for (int r = 0; r < 3; r++) { lo[u][r] = 0; hi[u][r] = 0; }
-    if (i < nk) {
-      const auto* T = sh->Trel[i];
-      qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
-      qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
-      const int gw = sh->kf[i].gw, gh = sh->kf[i].gh;
-      int gx0 = 0, gy0 = 0, gxe = 0;
-      if (sh->kf[i].n_cells > 0 && gw > 0) {
-        const double igc = 1.0 / (double)sh->kf[i].gcell, gmx = (double)sh->kf[i].gminx, gmy = (double)sh->kf[i].gminy;
-        int ax0 = (int)floor(((double)qx[u] - m - gmx) * igc), ax1 = (int)floor(((double)qx[u] + m - gmx) * igc);
-        int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
-        ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
-        if (ax0 <= ax1 && ay0 <= ay1) {
-          if (ay1 - ay0 > 2 || sh->kf[i].n_cells > 0xFFFF) wide |= 1 << u;  // more than three rows of buckets (a query within rounding of a bucket edge), or offsets beyond 16 bits
-          else { gx0 = ax0; gy0 = ay0; gxe = ax1 + 1; nrows[u] = ay1 - ay0 + 1; }
-        }
-      }
-      if (nrows[u] > 0) {  // bucket bounds of the window's rows: two 8-byte records (features_dev.h, grid_rows3)
-        const uint2* g3 = grid_rows3(sh->kf[i].gs);
-        const uint2 L = g3[gy0 * gw + gx0], H = g3[gy0 * gw + gxe];
-        lo[u][0] = (int)(L.x & 0xFFFFu); lo[u][1] = (int)(L.x >> 16); lo[u][2] = (int)L.y;
-        hi[u][0] = (int)(H.x & 0xFFFFu); hi[u][1] = (int)(H.x >> 16); hi[u][2] = (int)H.y;
-      }
-    }
+    const int i = min(i0 + u, nk - 1);  // a keyframe past the last one repeats the last one and is dropped at the end
+    kf[u] = i;
+    const auto* T = sh->Trel[i];
+    qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
+    qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
+    const int gw = sh->kf[i].gw, gh = sh->kf[i].gh, nc = sh->kf[i].n_cells;
+    const double igc = 1.0 / (double)sh->kf[i].gcell, gmx = (double)sh->kf[i].gminx, gmy = (double)sh->kf[i].gminy;
+    int ax0 = (int)floor(((double)qx[u] - m - gmx) * igc), ax1 = (int)floor(((double)qx[u] + m - gmx) * igc);
+    int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
+    ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
+    const bool ok = (i0 + u < nk) && nc > 0 && gw > 0 && ax0 <= ax1 && ay0 <= ay1;
+    // more than three rows of buckets (a query within rounding of a bucket edge), or offsets beyond 16 bits: left to the caller
+    const bool wd = ok && (ay1 - ay0 > 2 || nc > 0xFFFF);
+    wide |= wd ? (1 << u) : 0;
+    const bool use = ok && !wd;
+    nrows[u] = use ? ay1 - ay0 + 1 : 0;
+    const int b0 = use ? ay0 * gw + ax0 : 0, b1 = use ? ay0 * gw + ax1 + 1 : 0;
+    g_cu32x2* g3 = (g_cu32x2*)grid_rows3(sh->kf[i].gs);  // bucket bounds of the window's rows: two 8-byte records (features_dev.h)
+    L[u] = g3[b0]; H[u] = g3[b1];
   }
-  int cnt[NI][2], tot[NI], kmax = 0;  // candidates of rows 0, 0..1 and of the whole window
+  int lo[NI][3], cnt[NI][2], tot[NI], kmax = 0;  // candidates of rows 0, 0..1 and of the whole window
 #pragma unroll
   for (int u = 0; u < NI; u++) {
-    const int c0 = (0 < nrows[u]) ? hi[u][0] - lo[u][0] : 0;
-    const int c1 = (1 < nrows[u]) ? hi[u][1] - lo[u][1] : 0;
-    const int c2 = (2 < nrows[u]) ? hi[u][2] - lo[u][2] : 0;
+    const int l0 = (int)(L[u].x & 0xFFFFu), l1 = (int)(L[u].x >> 16), l2 = (int)L[u].y;
+    const int h0 = (int)(H[u].x & 0xFFFFu), h1 = (int)(H[u].x >> 16), h2 = (int)H[u].y;
+    const int c0 = (0 < nrows[u]) ? h0 - l0 : 0;
+    const int c1 = (1 < nrows[u]) ? h1 - l1 : 0;
+    const int c2 = (2 < nrows[u]) ? h2 - l2 : 0;
     cnt[u][0] = c0; cnt[u][1] = c0 + c1; tot[u] = c0 + c1 + c2;
-    lo[u][1] -= c0; lo[u][2] -= c0 + c1;  // candidate kk of row r sits at lo[r] + kk
+    lo[u][0] = l0; lo[u][1] = l1 - c0; lo[u][2] = l2 - (c0 + c1);  // candidate kk of row r sits at lo[r] + kk
     kmax = max(kmax, tot[u]);
   }
   int best[NI];
@@ -484,16 +496,15 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegS
 #pragma unroll
   for (int u = 0; u < NI; u++) { best[u] = -1; bd[u] = 3.4e38f; }
   for (int k = 0; k < kmax; k += NC) {
-    float4 c[NI][NC];
+    f32x4 c[NI][NC];
 #pragma unroll
     for (int u = 0; u < NI; u++) {
-      const float4* gp = sh->kf[min(i0 + u, nk - 1)].gp;
+      g_cf32x4* gp = (g_cf32x4*)sh->kf[kf[u]].gp;
 #pragma unroll
       for (int v = 0; v < NC; v++) {
         const int kk = k + v;  // candidate kk of the window, rows in ascending order
         const int idx = kk + (kk < cnt[u][0] ? lo[u][0] : (kk < cnt[u][1] ? lo[u][1] : lo[u][2]));
-        c[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < tot[u]) c[u][v] = gp[idx];
+        c[u][v] = gp[kk < tot[u] ? idx : 0];
       }
     }
 #pragma unroll
@@ -503,29 +514,26 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegS
         const float dx = qx[u] - c[u][v].x, dy = qy[u] - c[u][v].y;
         float d2 = dx * dx; d2 += dy * dy;
         const int ci = __float_as_int(c[u][v].z);
-        if (k + v < tot[u] && (d2 < bd[u] || (d2 == bd[u] && ci < best[u]))) { bd[u] = d2; best[u] = ci; }
+        const bool take = (k + v < tot[u]) & ((d2 < bd[u]) | ((d2 == bd[u]) & (ci < best[u])));  // no short circuit, selects: a load whose
+        bd[u] = take ? d2 : bd[u];                                                          // only use sits in a conditional block
+        best[u] = take ? ci : best[u];                                                      // gets sunk into it and waited for alone
       }
     }
   }
-  const double snx = rs[2 * cc], sny = rs[3 * cc];
-  double2 tn[NI];
+  f64x2 tn[NI];
 #pragma unroll
   for (int u = 0; u < NI; u++) {
-    const int i = i0 + u;
     ti[u] = (best[u] >= 0 && (double)bd[u] < curr_radius * curr_radius) ? best[u] : -1;
-    if (i >= nk) ti[u] = -1;
-    tn[u] = make_double2(0.0, 0.0);
-    if (ti[u] >= 0) tn[u] = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti[u])[1];
+    if (i0 + u >= nk) ti[u] = -1;
+    tn[u] = ((g_cf64x2*)(sh->kf[kf[u]].rtar + 8 * (size_t)(ti[u] >= 0 ? ti[u] : 0)))[1];  // the gate normals of all keyframes in one round trip
   }
 #pragma unroll
   for (int u = 0; u < NI; u++) {
-    if (ti[u] >= 0) {
-      const auto* T = sh->Trel[i0 + u];
-      const double nx = T[0] * snx + T[1] * sny;
-      const double ny = T[2] * snx + T[3] * sny;
-      const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
-      if (!(sim > angle_outlier)) ti[u] = -1;  // :247
-    }
+    const auto* T = sh->Trel[kf[u]];
+    const double nx = T[0] * snx + T[1] * sny;
+    const double ny = T[2] * snx + T[3] * sny;
+    const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
+    if (ti[u] >= 0 && !(sim > angle_outlier)) ti[u] = -1;  // :247
     // a window of more than three bucket rows is left to the caller (-2): a call in here would make this function save and
     // restore a register through scratch at every exit
     if ((wide & (1 << u)) && i0 + u < nk) ti[u] = -2;
@@ -561,24 +569,45 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
   const int cost = sh->rp.cost, weight_opt = sh->rp.weight_opt;  // through the LDS-typed pointer
-  const RCell cs = rcell_src(src, j);
+  typedef __attribute__((address_space(1))) const double g_cf64;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) const f64x2 g_cf64x2;
+  RCell cs;
+  {  // the source cell through the pointer kept in LDS (no read of the scan header first), global_load instead of flat
+    const size_t cc = (size_t)sh->scc;
+    g_cf64* r = (g_cf64*)sh->srs + j;
+    cs.mx = r[0]; cs.my = r[cc]; cs.nx = r[2 * cc]; cs.ny = r[3 * cc]; cs.ns = r[4 * cc]; cs.scale = r[5 * cc];
+  }
+  (void)src;
   typedef __attribute__((address_space(3))) double lds_double;
-#pragma unroll 2
-  for (int i = 0; i < nk; i++) {  // two keyframes per trip, branch-free (stores predicated): their independent chains of
-                                  // double-precision arithmetic interleave instead of running one after the other
+  // the target records of two keyframes are fetched together (the first pair with the source cell): two round trips to
+  // memory for the emission (keyframe by keyframe it was one each plus the source's; all four at once needs the callee-saved
+  // registers, whose save / restore through scratch is a round trip of its own). Unmatched / missing keyframes read record 0.
+  f64x2 R0[2], R1[2], R2[2];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {  // branch-free (stores predicated): the pair's independent chains of double-precision arithmetic interleave
+    if ((i & 1) == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int tu = assoc_get(a, i + u);
+        g_cf64x2* r = (g_cf64x2*)(sh->kf[min(i + u, nk - 1)].rtar + 8 * (size_t)(tu >= 0 ? tu : 0));
+        R0[u] = r[0]; R1[u] = r[1]; R2[u] = r[2];  // mean, normal, (samples, scale)
+      }
+    }
     const int ti = assoc_get(a, i);
-    const bool on = ti >= 0;
+    const bool on = ti >= 0 && i < nk;
     const int tix = on ? ti : 0;
+    const int ki = min(i, nk - 1);
     const int o = (int)((pos >> (16 * i)) & 0xFFFF);
     lds_double* lm = (lds_double*)lds_match_base() + o;
     double* gm = sh->rw.tmx + o;
     const size_t gcap = (size_t)sh->rw.cap;
     // array q of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
     auto put = [&](int q, double val) { if (on) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; } };
-    const double2* r = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)tix);
-    const double2 r0 = r[0], r1 = r[1], r2 = r[2];  // mean, normal, (samples, scale)
-    const auto* T = sh->Trel[i];
-    const auto* Tt = sh->Ttar[i];
+    const f64x2 r0 = R0[i & 1], r1 = R1[i & 1], r2 = R2[i & 1];
+    const auto* T = sh->Trel[ki];
+    const auto* Tt = sh->Ttar[ki];
     const double tmx = (Tt[0] * r0.x + Tt[1] * r0.y) + Tt[4];
     const double tmy = (Tt[2] * r0.x + Tt[3] * r0.y) + Tt[5];
     const double nx = T[0] * cs.nx + T[1] * cs.ny;
@@ -587,7 +616,7 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
     const double wgt = get_weight(weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y);
     double a0, a1, a2;
     if (cost == CFEAR_COST_P2D) {  // :290-299
-      const cfear_cell* ctf = &scans[i]->cells[tix];
+      const cfear_cell* ctf = &scans[ki]->cells[tix];
       const double ca = ctf->cov[0], cb = ctf->cov[1], cc = ctf->cov[2];
       const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
       const double m00 = r00 * ca + r01 * cb, m01 = r00 * cb + r01 * cc;
@@ -621,26 +650,26 @@ __device__ __forceinline__ unsigned long long assoc_counts(const Assoc4& a) {
 __device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int itr, int b) {
   AssocBlock R;
   R.a.t0 = R.a.t1 = R.a.t2 = R.a.t3 = -1;
-  const int j = b * blockDim.x + threadIdx.x;
+  const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
   if (j < nsrc) {
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
     R.a = associate_cell(src, sh, nk, j, curr_radius);
   }
-  R.e = block_exclusive_scan64(assoc_counts(R.a), reinterpret_cast<unsigned long long*>(sh->rw.red), &R.tb);
+  R.e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(R.a), reinterpret_cast<unsigned long long*>(sh->rw.red), &R.tb);
   // more source cells than threads: the matches wait in W.assoc for the totals of all blocks
-  if (nsrc > (int)blockDim.x && j < nsrc) reinterpret_cast<int4*>(sh->rw.assoc)[j] = make_int4(R.a.t0, R.a.t1, R.a.t2, R.a.t3);
+  if (nsrc > CFEAR_REG_BLOCK && j < nsrc) reinterpret_cast<int4*>(sh->rw.assoc)[j] = make_int4(R.a.t0, R.a.t1, R.a.t2, R.a.t3);
   return R;
 }
 // residual blocks of block b of the source cells; before = matches in front of this block, per keyframe. Returns the
 // matches of the block per keyframe (0 when the block is the only one: nothing follows it).
 __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int b,
                                                       Assoc4 a, unsigned long long e, unsigned long long before, bool use_lds) {
-  const int j = b * blockDim.x + threadIdx.x;
+  const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
   unsigned long long tb = 0;
-  if (nsrc > (int)blockDim.x) {  // positions inside the block: the same scan again (cheaper than keeping them)
+  if (nsrc > CFEAR_REG_BLOCK) {  // positions inside the block: the same scan again (cheaper than keeping them)
     a.t0 = a.t1 = a.t2 = a.t3 = -1;
     if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
-    e = block_exclusive_scan64(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
+    e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
   }
   if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell(scans, src, sh, nsrc, nk, j, a, before + e, use_lds);
   return tb;
@@ -650,7 +679,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   const ScanDev* src = scans[n - 1];
   const int nsrc = src->n_cells;
   const int pairs = (n - 1) * nsrc;
-  const int nt = blockDim.x, tid = threadIdx.x;
+  const int nt = CFEAR_REG_BLOCK, tid = threadIdx.x;
   int M;
   bool use_lds;
   const int nk = n - 1;
@@ -683,7 +712,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       sh->rw.assoc[p] = ti;
       cnt += (ti >= 0) ? 1 : 0;
     }
-    int o = block_exclusive_scan(cnt, sh->rw.red_i, &M);
+    int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
     use_lds = M <= CFEAR_MATCH_LDS_CAP;
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];
@@ -987,18 +1016,19 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   const RegIo& io = sh->rio;
   const bool master = (tid >> 6) == 0;
   // Affine3dToVectorXYeZ(Tsrc[i]) (:88-92): theta -> atan2(sin, cos)
-  for (int i = tid; i < n; i += blockDim.x) {
+  for (int i = tid; i < n; i += CFEAR_REG_BLOCK) {
     const Aff2 T = aff_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
     double v[3]; aff_to_xyt(T, v);
     par_lds[3 * i] = v[0]; par_lds[3 * i + 1] = v[1]; par_lds[3 * i + 2] = v[2];
   }
-  for (int i = tid; i < n; i += blockDim.x) sh->kf[i] = grid_view(scans[i]);
+  for (int i = tid; i < n; i += CFEAR_REG_BLOCK) sh->kf[i] = grid_view(scans[i]);
+  if (tid == 64) { sh->srs = scans[n - 1]->rsrc; sh->scc = (long long)scans[n - 1]->cap_cells; }
   if (tid == 0 && out) {
     out->success = 0; out->usable = 0; out->outer_iterations = 0; out->num_residuals = 0; out->num_residual_blocks = 0;
     out->reserved = 0; out->final_cost = 0; out->score = 0;
   }
   if (out)  // one thread per outer iteration (448 stores by a single thread were a measurable part of the start-up)
-    for (int i = tid; i < CFEAR_MAX_OUTER; i += blockDim.x) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
+    for (int i = tid; i < CFEAR_MAX_OUTER; i += CFEAR_REG_BLOCK) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }
   __syncthreads();
   if (master) {
     const int L = 3 * (n - 1);
@@ -1065,12 +1095,13 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
     sh->rp = P_in; sh->rw = W_in;
     sh->rio.poses = nullptr; sh->rio.cov6 = nullptr; sh->rio.out = nullptr; sh->rio.par = par_lds; sh->rio.n = n;
   }
-  for (int i = tid; i < n; i += blockDim.x) {  // Affine3dToVectorXYeZ (:196)
+  for (int i = tid; i < n; i += CFEAR_REG_BLOCK) {  // Affine3dToVectorXYeZ (:196)
     const Aff2 T = aff_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
     double v[3]; aff_to_xyt(T, v);
     par_lds[3 * i] = v[0]; par_lds[3 * i + 1] = v[1]; par_lds[3 * i + 2] = v[2];
     sh->kf[i] = grid_view(scans[i]);
   }
+  if (tid == 64) { sh->srs = scans[n - 1]->rsrc; sh->scc = (long long)scans[n - 1]->cap_cells; }
   __syncthreads();
   const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
   const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
