@@ -50,14 +50,13 @@ struct PhaseTimer {
   __device__ inline void mark() { if (t && threadIdx.x == 0 && n < cap) t[n++] = (long long)wall_clock64(); }
 };
 
-// Working memory of one block. For clouds up to CFEAR_LDS_POINT_CAP points keys/order/vstart/vlist
-// live in LDS and the sorted points are staged over the key region after the sort; bigger clouds use
-// the global arrays of the same names.
-#define CFEAR_LDS_POINT_CAP 5120
+// Working memory of one block in global memory: the general feature path (features_block below; clouds of any size) works
+// in it, the compact path (features_compact_dev.h: two workgroups per compute unit, the one every reference configuration
+// takes) only uses the partial sums, the reduction arrays and - for the cell grid - an LDS region handed over in `keys`.
 struct FeatureScratch {
   uint64_t* keys;   // [p2] (voxel << 32 | point) sort keys. NB: a 24-bit packing with an '& 0xFFFFFF' extract is
                     // miscompiled by hipcc 7.2 (mask dropped in front of v_mad_u64_u32)
-  float* spts;      // [n][3] points in sorted order (LDS: aliases keys; global otherwise)
+  float* spts;      // [n][3] points in sorted order
   int* order;       // [n] point index of every sorted position
   int* vstart;      // [n + 1] start of each occupied voxel in the sorted order
   int* vlist;       // [n] voxel index of each occupied voxel, ascending
@@ -65,17 +64,13 @@ struct FeatureScratch {
   float* samples;   // global [cap_points][3] voxel centroids
   int* red_i;       // LDS, >= 64 ints
   float* red_f;     // LDS, >= 64 floats
-  bool lds;         // keys/order/vstart/vlist/spts are LDS arrays (enables the LDS counting sort)
+  bool lds;         // cell_grid_block only: `keys` is an LDS region of tab_voxels / 2 ints for its counters, `vlist` the float cell means
   int* rng;         // global [cap_points][8] candidate row ranges of every sample point
   double* part;     // global [7][cap_points] partial moments of the candidate chunks
   int* tmpi;        // global [2 * cap + 16] copies of vlist/vstart (only used when leaf < radius)
   int cap;          // capacity (entries) of order/vstart/vlist/rng/part
-  bool tab_zeroed;  // the caller already cleared the whole key region (saves a barrier)
-  int tab_voxels;   // voxels the dense counting-sort table may cover (two 16-bit counters per word of the key region)
-  unsigned char* srng;  // LDS, CFEAR_LDS_SAMPLE_CAP x (uint4 of eight 16-bit candidate ranges) then x (float2 centroid): what the
-                        // range pass hands to the chunk lanes and the epilogue without a trip through memory (nullptr: global arrays)
+  int tab_voxels;   // cell_grid_block only: twice the ints the LDS region in `keys` holds
 };
-#define CFEAR_LDS_SAMPLE_CAP 1365
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
 #define CFEAR_INV_TWO_PI 0.15915494309189533576888376337251
@@ -479,8 +474,8 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
   if (pt) pt->mark();
 }
 
-// MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi.
-// p2 = power of two >= n with p2 <= capacity of W.keys.
+// MapPointNormal::ComputeNormals + ComputeSearchTreeFromCells for the cloud already in S->xyi: the general path (any
+// cloud size, any voxel grid, any intensities) in global arrays. p2 = power of two >= n with p2 <= capacity of W.keys.
 __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W, int p2,
                                       PhaseTimer* pt = nullptr, const float* bounds = nullptr) {
   // global working arrays through global-typed pointers: global_load / global_store instead of flat instructions (a flat
@@ -493,10 +488,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   g_f64* const g_part = (g_f64*)W.part;
   g_f32* const g_samples = (g_f32*)W.samples;
   g_i32* const g_rng = (g_i32*)W.rng;
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  __attribute__((address_space(3))) u32x4* const l_rng = (__attribute__((address_space(3))) u32x4*)W.srng;
-  __attribute__((address_space(3))) f32x2* const l_cxy = (__attribute__((address_space(3))) f32x2*)(W.srng + (size_t)CFEAR_LDS_SAMPLE_CAP * 16);
   const int tid = threadIdx.x, nt = blockDim.x;
   const g_f32* const xyi = (const g_f32*)S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
@@ -522,78 +513,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
   const int min_b1 = (int)floorf(mny * inv), max_b1 = (int)floorf(mxy * inv);
   const int div0 = max_b0 - min_b0 + 1, div1 = max_b1 - min_b1 + 1;
-  const long long Gll = (long long)div0 * (long long)div1;
   int nv_out = 0;
-  if (W.lds && Gll <= (long long)W.tab_voxels && n <= 8 * nt) {
-    // ---- LDS counting sort over the dense voxel grid: 16-bit counters packed two per word in the (not yet
-    // used) key region; the atomic scatter is unordered, ranking by point index inside each voxel restores the point order,
-    // which makes the whole sort stable ([3P] std::sort on the voxel index, pinned as stable) ----
-    const int G = (int)Gll;
-    uint32_t* tab = reinterpret_cast<uint32_t*>(W.keys);
-    if (!W.tab_zeroed) {  // block-uniform
-      for (int g = tid; g <= (G >> 1); g += nt) tab[g] = 0u;
-      __syncthreads();
-    }
-    for (int i = tid; i < n; i += nt) {
-      const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
-      const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
-      const int vid = ijk0 + ijk1 * div0;
-      W.order[i] = vid;  // parked until the scatter
-      atomicAdd(&tab[vid >> 1], 1u << (16 * (vid & 1)));
-    }
-    __syncthreads();
-    if (pt) pt->mark();
-    int nvv;
-    {
-      const int ipt = ((G + nt - 1) / nt + 1) & ~1;  // even: a thread owns whole words
-      const int g0 = tid * ipt, g1 = min(G, g0 + ipt);
-      int cnt = 0, occ = 0;
-      for (int g = g0; g < g1; g++) { const int c = (tab[g >> 1] >> (16 * (g & 1))) & 0xFFFF; cnt += c; occ += c > 0 ? 1 : 0; }
-      unsigned long long tot;  // points and occupied voxels scanned together (32 bits each)
-      const unsigned long long ex = block_exclusive_scan64((unsigned long long)(unsigned)cnt | ((unsigned long long)(unsigned)occ << 32),
-                                                           reinterpret_cast<unsigned long long*>(W.red_i), &tot);
-      int o = (int)(unsigned)ex, ov = (int)(ex >> 32);
-      nvv = (int)(tot >> 32);
-      for (int g = g0; g < g1; g += 2) {
-        const uint32_t w = tab[g >> 1];
-        const int c0 = w & 0xFFFF, c1 = (g + 1 < g1) ? (int)(w >> 16) : 0;
-        if (c0 > 0) { W.vlist[ov] = g; W.vstart[ov] = o; ov++; }
-        const int s0 = o; o += c0;
-        if (c1 > 0) { W.vlist[ov] = g + 1; W.vstart[ov] = o; ov++; }
-        const int s1 = o; o += c1;
-        tab[g >> 1] = (uint32_t)s0 | ((uint32_t)s1 << 16);  // counters become start offsets (scatter cursors)
-      }
-      nv_out = nvv;
-      if (tid == 0) { W.vstart[nvv] = n; S->n_samples = nvv; S->n_points = n; S->status = 0; }
-      __syncthreads();
-    }
-    // scatter: the voxel index parked in order[i] is consumed before any slot of order[] is overwritten.
-    // The atomic slot order inside a voxel is arbitrary; the final slot of a point is the voxel start plus
-    // the number of voxel members with a smaller point index (rank by counting).
-    {
-      int pos[8], pi[8], pv[8], np = 0;
-      for (int i = tid; i < n && np < 8; i += nt) {
-        const int vid = W.order[i];
-        const uint32_t old = atomicAdd(&tab[vid >> 1], 1u << (16 * (vid & 1)));
-        pos[np] = (int)((old >> (16 * (vid & 1))) & 0xFFFF); pi[np] = i; pv[np] = vid; np++;
-      }
-      __syncthreads();
-      for (int r = 0; r < np; r++) W.order[pos[r]] = pi[r];
-      __syncthreads();
-      for (int r = 0; r < np; r++) {  // the cursors now hold the voxel ends (= start of the next voxel)
-        const int vid = pv[r];
-        const int b = (int)((tab[vid >> 1] >> (16 * (vid & 1))) & 0xFFFF);
-        const int a = vid > 0 ? (int)((tab[(vid - 1) >> 1] >> (16 * ((vid - 1) & 1))) & 0xFFFF) : 0;
-        int c = 0;
-        for (int q = a; q < b; q++) c += W.order[q] < pi[r] ? 1 : 0;
-        pos[r] = a + c;
-      }
-      __syncthreads();
-      for (int r = 0; r < np; r++) W.order[pos[r]] = pi[r];
-      __syncthreads();
-    }
-    if (pt) pt->mark();
-  } else {
+  {
   for (int i = tid; i < p2; i += nt) {
     uint64_t key = ~0ull;
     if (i < n) {
@@ -626,7 +547,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   }
   const int nv = nv_out;  // known to every thread: no read-back of S->n_samples through memory
-  const bool lds_samples = W.srng != nullptr && nv <= CFEAR_LDS_SAMPLE_CAP && n < 65535;  // block-uniform
   // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)
   for (int q = tid; q < n; q += nt) {
     const int pi = W.order[q];
@@ -657,8 +577,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
       const float cnt = (float)(b - a);
       cx = sx / cnt; cy = sy / cnt;
-      if (lds_samples) l_cxy[v] = f32x2{cx, cy};  // read by the chunk lanes and the epilogue
-      else { g_samples[3 * v] = cx; g_samples[3 * v + 1] = cy; g_samples[3 * v + 2] = si / cnt; }
+      g_samples[3 * v] = cx; g_samples[3 * v + 1] = cy; g_samples[3 * v + 2] = si / cnt;
     }
     int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
     int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
@@ -684,11 +603,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       }
     }
     if (nr > 4) R[0] = -1;  // only with leaf < radius: the chunk lanes search again (copies made below)
-    if (lds_samples) {  // offsets into the sorted points are below 65536 here; 0xFFFF in the first field = "search again"
-      const unsigned f = (nr > 4) ? 0xFFFFu : (unsigned)R[0];
-      l_rng[v] = u32x4{f | ((unsigned)R[1] << 16), (unsigned)R[2] | ((unsigned)R[3] << 16), (unsigned)R[4] | ((unsigned)R[5] << 16),
-                       (unsigned)R[6] | ((unsigned)R[7] << 16)};
-    } else {
+    {
       g_i32x4* Rg = (g_i32x4*)(g_rng + 8 * (size_t)v);
       Rg[0] = i32x4{R[0], R[1], R[2], R[3]}; Rg[1] = i32x4{R[4], R[5], R[6], R[7]};
     }
@@ -728,12 +643,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     const int j = w - W.vstart[v];
     float cx, cy;
     i32x4 r0, r1;
-    if (lds_samples) {
-      const f32x2 cc = l_cxy[v]; cx = cc.x; cy = cc.y;
-      const u32x4 q = l_rng[v];
-      r0 = i32x4{(q.x & 0xFFFFu) == 0xFFFFu ? -1 : (int)(q.x & 0xFFFFu), (int)(q.x >> 16), (int)(q.y & 0xFFFFu), (int)(q.y >> 16)};
-      r1 = i32x4{(int)(q.z & 0xFFFFu), (int)(q.z >> 16), (int)(q.w & 0xFFFFu), (int)(q.w >> 16)};
-    } else {
+    {
       cx = g_samples[3 * v]; cy = g_samples[3 * v + 1];
       const g_i32x4* R = (const g_i32x4*)(g_rng + 8 * (size_t)v);
       r0 = R[0]; r1 = R[1];
@@ -806,7 +716,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         const int m = (int)md;
         if (m >= 6) {  // :291
           float cx, cy;
-          if (lds_samples) { const f32x2 cc = l_cxy[v]; cx = cc.x; cy = cc.y; } else { cx = g_samples[3 * v]; cy = g_samples[3 * v + 1]; }
+          cx = g_samples[3 * v]; cy = g_samples[3 * v + 1];
           const double m1x = s1x / s0, m1y = s1y / s0;
           const double ux = (double)cx + m1x, uy = (double)cy + m1y;
           const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
@@ -842,10 +752,6 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         g_f32* mf = (g_f32*)S->mean_f;
         mf[2 * o] = (float)c.mean[0];
         mf[2 * o + 1] = (float)c.mean[1];
-        if (W.lds && o < CFEAR_LDS_POINT_CAP / 2) {  // a copy for the grid build below (the voxel list is not needed any more)
-          auto* lmw = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
-          lmw[2 * o] = (float)c.mean[0]; lmw[2 * o + 1] = (float)c.mean[1];
-        }
         const size_t cc = (size_t)cap_cells;
         g_f64* rs = (g_f64*)S->rsrc + o;
         rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1];
@@ -862,7 +768,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   if (pt) pt->mark();
   if (pt) pt->mark();
-  cell_grid_block(S, n_cells_out, P, W, W.lds && n_cells_out <= CFEAR_LDS_POINT_CAP / 2, pt);
+  cell_grid_block(S, n_cells_out, P, W, false, pt);
 }
 
 // GetClosestIdx (pointnormal.cpp:238-254): 1-NN over the float cell means, accepted iff d2 < d*d.

@@ -77,8 +77,7 @@ __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; retur
 __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds) {
   FeatureScratch W;
   W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
-  W.srng = nullptr;
-  W.vcur = B.vcur; W.lds = false; W.tab_zeroed = false; W.tab_voxels = 0;
+  W.vcur = B.vcur; W.lds = false; W.tab_voxels = 0;
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
   W.cap = B.cap_points;
   W.samples = B.samples;

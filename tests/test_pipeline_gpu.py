@@ -90,6 +90,39 @@ def test_features_match_oracle(oracle, seq, res, wi, df):
     ctx.close()
 
 
+@pytest.mark.parametrize("case", ["fractional_intensities", "more_points_than_compact", "huge_voxel_grid", "small_leaf"])
+def test_general_feature_path_matches_oracle(oracle, seq, case):
+    """Clouds outside the limits of the compact (two workgroups per compute unit) feature path take the general path in
+    global arrays: intensities that are not integers 0..255, more than 4864 points, a voxel grid beyond 32768 voxels. Same
+    results as the oracle either way; "small_leaf" stays on the compact path with more than three voxel rows per radius."""
+    imgs, _ = seq
+    res, df = 3.0, 1.0
+    slots = oracle.filter_polar(imgs[2], 60, 12)
+    xyi = oracle.compensate(oracle.cloud(slots, RR, 2.5), [1.0, 0.01, 0.02], 0)
+    if case == "fractional_intensities":
+        xyi = xyi.copy(); xyi[:, 2] += np.float32(0.25)
+    elif case == "more_points_than_compact":
+        xyi2 = oracle.compensate(oracle.cloud(oracle.filter_polar(imgs[3], 60, 12), RR, 2.5), [0.5, 0.0, 0.01], 0)
+        xyi = np.concatenate([xyi, xyi2 + np.float32([0.37, -0.21, 0])])
+        assert len(xyi) > 4864
+    elif case == "huge_voxel_grid":
+        xyi = xyi.copy(); xyi[0, :2] = [-900.0, -700.0]; xyi[1, :2] = [800.0, 650.0]  # 1700 m x 1350 m / 3 m = 255 k voxels
+    elif case == "small_leaf":
+        df = 2.5  # leaf 1.2 m: five voxel rows inside the radius
+    po = mk_params(oracle, res=res, weight_intensity=1, downsample_factor=df)
+    pg = mk_params(capi, res=res, weight_intensity=1, downsample_factor=df)
+    ctx = capi.Context(pg, 400, 3360)
+    so = oracle.Scan(xyi, po)
+    sg = ctx.scan_create(ctx.cloud_upload(xyi))
+    co, cg = so.cells(), sg.cells()
+    assert len(co) > 50
+    cells_close(cg, co)
+    rng = np.random.default_rng(5)
+    q = co["mean"][rng.integers(0, len(co), 200)] + rng.normal(0, 1.5, (200, 2))
+    assert np.array_equal(sg.closest(q, 2.0), np.array([so.closest(x, y, 2.0) for x, y in q]))
+    ctx.close()
+
+
 def test_empty_cloud_fails_loudly(hip_lib):
     ctx = capi.Context(mk_params(capi), 400, 3360)
     with pytest.raises(capi.CfearError):
