@@ -598,7 +598,9 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
       const int a = W.vstart[p0], b = W.vstart[p1];
       if (b > a) {
-        if (nr < 4) { R[2 * nr] = a; R[2 * nr + 1] = b; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)  // static indices: a run-time index would move R[] to per-thread scratch
+          if (u == nr) { R[2 * u] = a; R[2 * u + 1] = b; }
         nr++; tot += b - a;
       }
     }
