@@ -60,7 +60,7 @@ class RegSummary(C.Structure):
 EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
     "cfear_set_params", "cfear_synchronize", "cfear_tune", "cfear_kstrongest_device", "cfear_kstrongest_host",
-    "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_cloud_upload", "cfear_cloud_size",
+    "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_filter_cfar_batch_device", "cfear_cloud_upload", "cfear_cloud_size",
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
@@ -105,6 +105,7 @@ def lib():
         "cfear_filter_polar_device": (C.c_int, [vp, u8p, C.POINTER(vp), C.POINTER(vp)]),
         "cfear_filter_cfar": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_float, C.c_double, C.POINTER(vp)]),
         "cfear_filter_cfar_device": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_float, C.c_double, C.POINTER(vp)]),
+        "cfear_filter_cfar_batch_device": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_double, f32p, C.c_int, i32p]),
         "cfear_cloud_upload": (C.c_int, [vp, f32p, C.c_int, C.POINTER(vp)]),
         "cfear_cloud_size": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
         "cfear_cloud_download": (C.c_int, [vp, vp, f32p, C.c_int, C.POINTER(C.c_int)]),
@@ -262,6 +263,12 @@ class Context:
             rc = self._L.cfear_filter_cfar_device(self._h, _addr(polar), *args)
         self._check(rc, "cfear_filter_cfar")
         return Cloud(self, c)
+
+    def filter_cfar_batch(self, d_polar, n_scans, d_xyi, capacity, d_counts, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0):
+        """CA-CFAR over n_scans device-resident sweeps; d_xyi [n_scans, capacity, 3] float32 and d_counts [n_scans] int32 on the device"""
+        self._check(self._L.cfear_filter_cfar_batch_device(self._h, _addr(d_polar), int(n_scans), int(window_size), int(nb_guard_cells),
+                                                           C.c_float(false_alarm_rate), C.c_double(max_distance), _addr(d_xyi), int(capacity),
+                                                           _addr(d_counts)), "cfear_filter_cfar_batch_device")
 
     def cloud_upload(self, xyi):
         xyi = np.ascontiguousarray(xyi, dtype=np.float32).reshape(-1, 3)

@@ -95,6 +95,7 @@ void cfear_destroy(cfear_ctx* ctx) {
   if (ctx->d_polar) (void)hipFree(ctx->d_polar);
   if (ctx->d_slots) (void)hipFree(ctx->d_slots);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_cfar_rows) (void)hipFree(ctx->d_cfar_rows);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

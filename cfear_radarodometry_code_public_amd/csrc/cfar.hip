@@ -32,9 +32,10 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restr
   __shared__ uint32_t prefix[CFAR_MAX_R + 1];                        // prefix[i] = sum of squares of bins < i
   __shared__ __attribute__((aligned(16))) uint8_t rowbuf[CFAR_MAX_R + 8];
   __shared__ int red_i[64];
-  const int az = blockIdx.x, tid = threadIdx.x, R = P.R;
+  // batches: image blockIdx.x / A, azimuth blockIdx.x % A; the images lie back to back, so row blockIdx.x starts at blockIdx.x * R
+  const int grow = blockIdx.x, img = grow / P.A, az = grow - img * P.A, tid = threadIdx.x, R = P.R;
   // ---- stage the row with aligned dword loads (the bytes around the row belong to the neighbouring rows) ----
-  const long long row_off = (long long)az * R;
+  const long long row_off = (long long)grow * R;
   const int first = (int)(row_off & 3);
   const long long base = row_off - first;
   const int ndw = (first + R + 3) >> 2;
@@ -86,10 +87,11 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restr
   int total;
   int o = block_exclusive_scan(cnt, red_i, &total);
   if (!EMIT) {
-    if (tid == 0) row_count[az] = total;
+    if (tid == 0) row_count[grow] = total;
     return;
   }
-  o += row_base[az];
+  o += row_base[grow];
+  xyi += 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
   while (hit) {
     const int b = __ffsll((long long)hit) - 1;
     hit &= hit - 1;
@@ -104,10 +106,11 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restr
   }
 }
 
-// exclusive scan of the A row counts (single workgroup); total -> *d_total
+// exclusive scan of the A row counts of image blockIdx.x (one workgroup per image); total -> d_total[blockIdx.x]
 __global__ __launch_bounds__(1024) void cfar_row_scan_kernel(const int* __restrict__ row_count, int A, int* __restrict__ row_base,
                                                              int* __restrict__ d_total) {
   __shared__ int red_i[64];
+  row_count += (size_t)blockIdx.x * A; row_base += (size_t)blockIdx.x * A; d_total += blockIdx.x;
   const int ipt = (A + blockDim.x - 1) / blockDim.x;
   const int i0 = threadIdx.x * ipt, i1 = min(A, i0 + ipt);
   int s = 0;
@@ -166,6 +169,39 @@ int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_
   if (!ctx || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: bad argument");
   if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: polar buffer must be 4-byte aligned");
   return cfar_run(ctx, d_polar, (long long)ctx->A * ctx->R, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
+}
+
+int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
+                                   float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts) {
+  if (!ctx || !d_polar || !d_xyi || !d_counts || n_scans <= 0 || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: bad argument");
+  if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: polar buffer must be 4-byte aligned");
+  if (window_size < 1 || nb_guard_cells < 0 || !(false_alarm_rate > 0.f))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: window_size >= 1, nb_guard_cells >= 0, false_alarm_rate > 0 required");
+  if (ctx->R > CFAR_MAX_R) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: more than 16384 range bins");
+  if ((long long)n_scans * ctx->A > 0x7FFFFFFFLL) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: too many rows");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t rows = (size_t)n_scans * ctx->A;
+  if (2 * rows > ctx->cfar_rows_cap) {  // row counts and row bases of the whole batch
+    if (ctx->d_cfar_rows) { CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_cfar_rows); }
+    ctx->d_cfar_rows = nullptr; ctx->cfar_rows_cap = 0;
+    if (hipMalloc(&ctx->d_cfar_rows, sizeof(int) * 2 * rows) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
+    ctx->cfar_rows_cap = 2 * rows;
+  }
+  CfarParams P;
+  P.A = ctx->A; P.R = ctx->R; P.window = window_size; P.guard = nb_guard_cells;
+  P.range_res = (double)ctx->par.range_res; P.static_threshold = (double)ctx->par.z_min; P.min_distance = (double)ctx->par.min_distance;
+  P.max_distance = max_distance;
+  const double N = (double)(window_size * 2);
+  P.scaling = N * (pow((double)false_alarm_rate, -1. / N) - 1.);
+  int* d_count = ctx->d_cfar_rows; int* d_base = d_count + rows;
+  const long long alloc = (long long)rows * ctx->R;
+  hipLaunchKernelGGL((cfar_kernel<false>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
+                     (float*)nullptr, 0);
+  hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_counts);
+  hipLaunchKernelGGL((cfar_kernel<true>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
+                     d_xyi, capacity);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
 }
 
 int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, int nb_guard_cells, float false_alarm_rate,

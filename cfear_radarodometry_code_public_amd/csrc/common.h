@@ -31,6 +31,8 @@ struct cfear_ctx {
   // scratch for the per-call feature / registration kernels
   void* d_scratch = nullptr;
   size_t scratch_bytes = 0;
+  int* d_cfar_rows = nullptr;  // row counts / bases of cfear_filter_cfar_batch_device
+  size_t cfar_rows_cap = 0;
   // streams of the batched odometry objects of this context (cfear_synchronize waits for them too)
   std::vector<hipStream_t> aux_streams;
   // launch-shape knobs (cfear_tune): filter occupancy variant (5..7 waves per SIMD), rows walked per filter wave,

@@ -123,6 +123,12 @@ int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, i
                       double max_distance, cfear_cloud** cloud);
 int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_guard_cells,
                              float false_alarm_rate, double max_distance, cfear_cloud** cloud);
+/* The same filter over a batch of device-resident sweeps (n_scans images back to back), asynchronous on the context stream:
+ * image i's detections go to d_xyi + i * capacity * 3 (x, y, intensity floats, same order as the per-call version, at most
+ * `capacity` of them) and their number - the true count, which may exceed `capacity` - to d_counts[i]. The clouds feed
+ * cfear_cloud_upload-style consumers or a caller's own kernels; sizes are known on the device without a host round trip. */
+int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
+                                   float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts);
 /* Upload an existing cloud: xyi = n x (x, y, intensity) floats. */
 int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cloud);
 int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* cloud, int* n);

@@ -49,3 +49,34 @@ def test_world_sweep_host_and_device_entry_points(oracle):
 def test_empty_result_and_saturated_image(oracle):
     assert run(np.zeros((16, 512), dtype=np.uint8), oracle) == 0
     run(np.full((16, 512), 255, dtype=np.uint8), oracle)  # uniform: I^2 = mean -> detection iff scaling < 1
+
+
+@pytest.mark.parametrize("A,R,n", [(400, 3360, 5), (37, 1001, 7)])
+def test_batched_device_entry_matches_per_image_clouds(oracle, A, R, n):
+    """cfear_filter_cfar_batch_device: n images back to back, per image a cloud slot of `capacity` points and the true
+    detection count - every image's cloud bit-identical to the oracle's, a too small capacity truncates without overrun."""
+    import torch
+    rng = np.random.default_rng(A * 7 + R)
+    imgs = rng.integers(0, 256, size=(n, A, R), dtype=np.uint8)
+    imgs[:, :, ::11] = np.minimum(imgs[:, :, ::11].astype(int) + 100, 255).astype(np.uint8)
+    imgs[2] = synth.world_scan(synth.World(5), 3, A, R) if A == 400 else imgs[2] // 3  # a sparse image in the middle of the batch
+    exp = [oracle.cfar(imgs[i], RR, 60.0, 2.5, 10, 20, 0.01) for i in range(n)]
+    cap = max(len(e) for e in exp) + 5
+    ctx = capi.Context(capi.default_params(range_res=RR, z_min=60.0, min_distance=2.5), A, R)
+    d = torch.from_numpy(imgs).cuda()
+    for capacity in (cap, max(cap // 3, 1)):
+        cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        flat = torch.full((n * capacity * 3 + 3,), -7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.filter_cfar_batch(d, n, flat, capacity, cnt)
+        ctx.synchronize()
+        got_n = cnt.cpu().numpy()
+        got = flat.cpu().numpy()
+        assert np.all(got[n * capacity * 3:] == -7.0)  # nothing past the last slot
+        for i in range(n):
+            assert got_n[i] == len(exp[i])
+            m = min(len(exp[i]), capacity)
+            slot = got[i * capacity * 3:(i + 1) * capacity * 3].reshape(capacity, 3)
+            assert np.array_equal(slot[:m], exp[i][:m]), i
+            assert np.all(slot[m:] == -7.0)
+    ctx.close()
