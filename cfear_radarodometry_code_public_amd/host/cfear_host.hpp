@@ -241,6 +241,12 @@ struct cell {
     c.lambda_min = 1; c.lambda_max = 1; c.sum_intensity_ = 1.0; c.avg_intensity_ = 1.0; c.Nsamples_ = 1; c.valid_ = true;
     return c;
   }
+#ifdef CFEAR_HOST_BOOST_SERIALIZATION  // pointnormal.h:86-101: the same archive layout, so the reference's SaveSimpleGraph / LoadSimpleGraph
+  template <class Archive>             // (types.cpp:103-130, the .sgh export for TBV-SLAM) keep working on these cells
+  void serialize(Archive& ar, const unsigned int) {
+    ar & u_; ar & cov_; ar & scale_; ar & snormal_; ar & lambda_min; ar & lambda_max; ar & sum_intensity_; ar & avg_intensity_; ar & Nsamples_; ar & valid_;
+  }
+#endif
   // cell TransformCopy(T) (pointnormal.cpp:515-527), arithmetic as written there: C = R * T * cov * R^T with the affine T
   // applied to the columns of cov (so the translation enters the product)
   cell TransformCopy(const Affine3d& T) const {
@@ -321,8 +327,28 @@ class MapPointNormal {
   cfear_scan* handle() const { return scan_; }
   const DevicePtr& device() const { return dev_; }
   static double downsample_factor;  // pointnormal.h:241 (read when a map is built)
+#ifdef CFEAR_HOST_BOOST_SERIALIZATION
+  // pointnormal.h:201-226: cells, input_, downsampled_, radius_, weight_intensity_ in this order; loading rebuilds the device
+  // scan from the cells (the reference rebuilds its kd-tree, :225)
+  MapPointNormal() : dev_(Device::Default()) {}
+  template <class Archive>
+  void save(Archive& ar, const unsigned int) const {
+    const_cast<MapPointNormal*>(this)->fetch();
+    CFEAR_DOWNSAMPLED_PTR downsampled = cfear_make_downsampled(cells_);
+    ar & cells_; ar & input_; ar & downsampled; ar & radius_; ar & weight_intensity_;
+  }
+  template <class Archive>
+  void load(Archive& ar, const unsigned int) {
+    std::vector<cell> cs; CFEAR_DOWNSAMPLED_PTR downsampled;
+    ar & cs; ar & input_; ar & downsampled; ar & radius_; ar & weight_intensity_;
+    if (scan_) { cfear_scan_release(dev_->ctx(), scan_); scan_ = nullptr; }
+    FromCells(cs);
+  }
+  BOOST_SERIALIZATION_SPLIT_MEMBER()
+#endif
  private:
   void Build(const DeviceCloud& cld, float radius, const Vector2d& origin, bool weight_intensity) {
+    radius_ = radius; weight_intensity_ = weight_intensity;
     if (origin(0) != 0 || origin(1) != 0) throw std::runtime_error("MapPointNormal: origin must be (0,0) as in odometrykeyframefuser.cpp:161");
     cfear_params p = dev_->params(); p.res = radius; p.weight_intensity = weight_intensity ? 1 : 0; p.downsample_factor = downsample_factor;
     ScopedParams sp(dev_, p);  // this map's settings, for this call only
@@ -366,6 +392,7 @@ class MapPointNormal {
     fetched_ = true;
   }
   DevicePtr dev_; CloudPtr input_; cfear_scan* scan_ = nullptr; std::vector<cell> cells_; bool fetched_ = false;
+  float radius_ = 0; bool weight_intensity_ = false;  // pointnormal.h:199-200 (kept for the archive)
 };
 inline double MapPointNormal::downsample_factor = 1;
 

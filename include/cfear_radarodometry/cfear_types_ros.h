@@ -22,6 +22,14 @@
 #define CFEAR_HOST_TYPES_DEFINED 1
 #define CFEAR_SHARED_PTR boost::shared_ptr
 #define CFEAR_TIMING CFEAR_Radarodometry::timing  // statistics.h: the reference's global timing object
+// boost archives of cells / maps (pointnormal.h:86-101, :201-226) keep the reference's layout, so SaveSimpleGraph / LoadSimpleGraph
+// (types.cpp:103-130: the .sgh export) work unchanged on the drop-in classes; the Eigen / PCL adaptors are the reference's own
+#include <boost/serialization/serialization.hpp>
+#include <boost/serialization/split_member.hpp>
+#include <boost/serialization/vector.hpp>
+#include "cfear_radarodometry/serialization.h"
+#define CFEAR_HOST_BOOST_SERIALIZATION 1
+#define CFEAR_DOWNSAMPLED_PTR pcl::PointCloud<pcl::PointXY>::Ptr
 
 namespace CFEAR_Radarodometry {
 
@@ -63,6 +71,14 @@ inline int cfear_cv_rows(const CvImagePtr& c) { return c->image.rows; }
 inline int cfear_cv_cols(const CvImagePtr& c) { return c->image.cols; }
 inline const uint8_t* cfear_cv_data(const CvImagePtr& c) { return c->image.ptr<uint8_t>(0); }
 inline void cfear_cloud_stamp_from_cv(PointCloudXYZI& c, const CvImagePtr& img) { pcl_conversions::toPCL(img->header.stamp, c.header.stamp); }  // radar_driver.cpp:66-67
+
+// downsampled_ of the reference (pointnormal.cpp:151-158): the float cell means as a PointXY cloud (template: `cell` is declared later)
+template <class CellVector>
+inline pcl::PointCloud<pcl::PointXY>::Ptr cfear_make_downsampled(const CellVector& cells) {
+  pcl::PointCloud<pcl::PointXY>::Ptr d(new pcl::PointCloud<pcl::PointXY>());
+  for (const auto& c : cells) { pcl::PointXY p; p.x = (float)c.u_(0); p.y = (float)c.u_(1); d->push_back(p); }
+  return d;
+}
 
 inline double cfear_tx(const Affine3d& T) { return T.translation()(0); }
 inline double cfear_ty(const Affine3d& T) { return T.translation()(1); }

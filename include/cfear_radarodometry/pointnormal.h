@@ -8,5 +8,5 @@
 #include "../../cfear_radarodometry_code_public_amd/host/cfear_host.hpp"
 // pointnormal.h:45-105 class cell, :110-243 class MapPointNormal (both constructors :118,:120; GetCells, GetCell, GetClosest,
 // GetClosestIdx, GetCellRelTimeStamp, TransformCells, TransformMap, GetMean2d / GetCov2d / GetNormal2d, GetScan, GetSize,
-// static downsample_factor). The RViz publishers (PublishMap ..., pointnormal.cpp:363-512) and boost serialization are not on
-// the path and are not provided.
+// static downsample_factor). Boost serialization of cells and maps keeps the reference's archive layout (the .sgh export of types.cpp:103-130
+// works on these classes). The RViz publishers (PublishMap ..., pointnormal.cpp:363-512) are not on the path and not provided.
