@@ -121,6 +121,26 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
   return base + inc - v;
 }
 
+// The same with ONE barrier: the partial sums go to a 16-int slot of `scratch` (slot 0..3) that no wave may still be reading,
+// i.e. between this scan and the previous one that used the same slot there must be a barrier (any barrier) - back-to-back
+// scans alternate slots. (The two-barrier version protects its scratch with a barrier of its own; at 8 waves that is ~0.5 us
+// per scan, and the feature kernel has seven of them per scan of the radar.)
+__device__ __forceinline__ int block_exclusive_scan_1b(int v, int* scratch, int slot, int* total) {
+  auto* sl = CFEAR_LDS_PTR(int, scratch) + 16 * slot;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int inc = wave_inclusive_scan(v);
+  if (lane == 63) sl[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < nw; i++) {
+    const int s = sl[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
 // Exclusive prefix sum of one 64-bit value per thread (e.g. four 16-bit counters packed side by side);
 // *total = block sum. scratch: >= 32 unsigned long long in LDS.
 template <int NT = 0>

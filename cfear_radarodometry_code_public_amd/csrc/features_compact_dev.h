@@ -108,7 +108,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     const int w0 = tid * wpt, w1 = min(NW, w0 + wpt);
     int cnt = 0;
     for (int w = w0; w < w1; w++) cnt += __popc(bm[w]);
-    int ex = block_exclusive_scan(cnt, W.red_i, &nv);
+    int ex = block_exclusive_scan_1b(cnt, W.red_i, 0, &nv);  // (one-barrier scans: a barrier separates each from the one before)
     for (int w = w0; w < w1; w++) { bmp[w] = (unsigned short)ex; ex += __popc(bm[w]); }
   }
   __syncthreads();
@@ -131,7 +131,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     int cnt = 0;
     for (int g = g0; g < g1; g++) cnt += (int)vst[g];
     int tot;
-    int o = block_exclusive_scan(cnt, W.red_i, &tot);
+    int o = block_exclusive_scan_1b(cnt, W.red_i, 0, &tot);
     for (int g = g0; g < g1; g++) { const int c = (int)vst[g]; vst[g] = (unsigned short)o; o += c; }
     if (tid == 0) { S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
@@ -161,7 +161,13 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     if (i < n) {
       const int a = (int)vst[pv[r]], b = (int)vst[pv[r] + 1];
       int c = 0;
-      for (int q = a; q < b; q++) c += (int)ord[q] < i ? 1 : 0;
+      for (int q = a; q < b; q += 4) {  // four members per trip: independent LDS loads (a dependent load per member was the cost)
+        int o4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) o4[u] = (int)ord[min(q + u, b - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) c += ((q + u < b) & (o4[u] < i)) ? 1 : 0;
+      }
       const float x = xyi[3 * i], y = xyi[3 * i + 1], w = xyi[3 * i + 2];
       pxy[a + c] = f32x2{x, y};
       // what the moments need of the intensity: the weight max(I - 60, 0) (pointnormal.cpp:15), an integer 0..195, or 1
@@ -180,7 +186,13 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   auto centroid = [&](int v, float& cx, float& cy) {
     const int a = (int)vst[v], b = (int)vst[v + 1];
     float sx = 0.f, sy = 0.f;
-    for (int q = a; q < b; q++) { const f32x2 p = pxy[q]; sx += p.x; sy += p.y; }
+    for (int q = a; q < b; q += 4) {  // four loads in flight, added in point order
+      f32x2 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) p[u] = pxy[min(q + u, b - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const bool on = q + u < b; sx = on ? sx + p[u].x : sx; sy = on ? sy + p[u].y : sy; }
+    }
     const float cnt = (float)(b - a);
     cx = sx / cnt; cy = sy / cnt;
   };
@@ -197,6 +209,22 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     const int k0 = w.gx0 + gy * div0, k1 = w.gx1 + gy * div0 + 1;
     a = (int)vst[rank(k0)]; b = (int)vst[rank(k1)];
   };
+  // the ranges of window rows gy .. gy + 3 at once (rows past the window: empty): the eight rank queries and the eight
+  // start lookups are independent LDS reads - row after row they were a chain of dependent ones
+  auto row_ranges4 = [&](const Win& w, int gy, int (&a)[4], int (&b)[4]) {
+    int r0[4], r1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int g = min(gy + u, w.gy1);
+      r0[u] = rank(w.gx0 + g * div0); r1[u] = rank(w.gx1 + g * div0 + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool on = (gy + u <= w.gy1) & (w.gx0 <= w.gx1);
+      const int sa = (int)vst[r0[u]], sb = (int)vst[r1[u]];
+      a[u] = sa; b[u] = on ? sb : sa;
+    }
+  };
   // Candidate counts range from 1 to ~1000 per sample point, so the work is cut into chunks of at most C candidates:
   // (1) per sample the candidate total, (2) a scan turns the totals into a chunk list, (3) one lane per chunk accumulates
   // partial moments, (4) the epilogue adds a sample's partials in chunk order (deterministic).
@@ -211,16 +239,20 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       centroid(v, cx, cy);
       const Win w = window(cx, cy);
       int tot = 0;
-      for (int gy = w.gy0; gy <= w.gy1 && w.gx0 <= w.gx1; gy++) { int a, b; row_range(w, gy, a, b); tot += b - a; }
+      for (int gy = w.gy0; gy <= w.gy1; gy += 4) {
+        int a[4], b[4];
+        row_ranges4(w, gy, a, b);
+        tot += (b[0] - a[0]) + (b[1] - a[1]) + (b[2] - a[2]) + (b[3] - a[3]);
+      }
       ord[v] = (unsigned short)(tot >= 6 ? tot : 0);  // fewer than six candidates can never make a cell (pointnormal.cpp:291)
     }
     if (pt) pt->mark();
     int o, oa;
-    for (;;) {  // block-uniform: double the chunk size until the chunk list and the active-sample list fit side by side
+    for (int it = 0;; it++) {  // block-uniform: double the chunk size until the chunk list and the active-sample list fit side by side
       int cnt = 0, act = 0;
       for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) / C; act += t > 0 ? 1 : 0; }
       int tot2;
-      const int ex = block_exclusive_scan(cnt | (act << 16), W.red_i, &tot2);  // both counts < 32768: one scan for the two
+      const int ex = block_exclusive_scan_1b(cnt | (act << 16), W.red_i, it & 1, &tot2);  // both counts < 32768: one scan for the two
       o = ex & 0xFFFF; oa = ex >> 16; NC = tot2 & 0xFFFF; NA = tot2 >> 16;
       if (NC + NA <= ccap) break;
       C <<= 1;
@@ -248,10 +280,14 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     int m = 0;
     double s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
     const double cxd = (double)cx, cyd = (double)cy;
-    for (int gy = win.gy0; gy <= win.gy1 && left > 0; gy++) {
-      int a, b;
-      row_range(win, gy, a, b);
+    for (int gy4 = win.gy0; gy4 <= win.gy1 && left > 0; gy4 += 4) {
+     int ra[4], rb[4];
+     row_ranges4(win, gy4, ra, rb);
+#pragma unroll
+     for (int u = 0; u < 4; u++) {
+      const int a = ra[u], b = rb[u];
       const int len = b - a;
+      if (left <= 0 || len <= 0) continue;
       if (skip >= len) { skip -= len; continue; }
       const int s = a + skip, e = min(b, s + left);
       for (int q = s; q < e; q += 4) {
@@ -259,18 +295,19 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int qq = min(q + u, e - 1); p[u] = pxy[qq]; iw[u] = (int)pw[qq]; }  // independent LDS loads first
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const float dx = cx - p[u].x, dy = cy - p[u].y;
-          float d2 = dx * dx; d2 += dy * dy;
-          if (q + u < e && d2 < r2) {  // pointnormal.cpp:291 radius test (float, strict)
-            const double w = (double)iw[u];  // the weight byte staged with the point (:15)
-            const double ex = (double)p[u].x - cxd, ey = (double)p[u].y - cyd;
-            m++; s0 += w; s1x += w * ex; s1y += w * ey;
-            sxx += w * (ex * ex); sxy += w * (ex * ey); syy += w * (ey * ey);
-          }
+        for (int u = 0; u < 4; u++) {  // branch-free: a candidate outside the radius (or past the chunk) enters with weight 0 - adding
+          const float dx = cx - p[u].x, dy = cy - p[u].y;  // zeros leaves the sums bit-identical, and the lanes of a wave hold different
+          float d2 = dx * dx; d2 += dy * dy;               // candidates anyway, so a branch would run its body for almost every trip
+          const bool in = (q + u < e) & (d2 < r2);  // pointnormal.cpp:291 radius test (float, strict)
+          const double w = in ? (double)iw[u] : 0.0;  // the weight byte staged with the point (:15)
+          const double ex = (double)p[u].x - cxd, ey = (double)p[u].y - cyd;
+          const double wex = w * ex, wey = w * ey;
+          m += in ? 1 : 0; s0 += w; s1x += wex; s1y += wey;
+          sxx = __builtin_fma(wex, ex, sxx); sxy = __builtin_fma(wex, ey, sxy); syy = __builtin_fma(wey, ey, syy);
         }
       }
       left -= e - s; skip = 0;
+     }
     }
     g_part[wq] = (double)m; g_part[cs + wq] = s0; g_part[2 * cs + wq] = s1x; g_part[3 * cs + wq] = s1y;
     g_part[4 * cs + wq] = sxx; g_part[5 * cs + wq] = sxy; g_part[6 * cs + wq] = syy;
@@ -287,7 +324,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
-    for (int a0 = 0; a0 < NA; a0 += nt) {  // rounds over the active samples, in sample order
+    for (int a0 = 0, round = 0; a0 < NA; a0 += nt, round++) {  // rounds over the active samples, in sample order
       const int ai = a0 + tid;
       cfear_cell c;
       int valid = 0;
@@ -329,7 +366,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         }
       }
       int round_total;
-      const int o = base + block_exclusive_scan(valid, W.red_i, &round_total);
+      const int o = base + block_exclusive_scan_1b(valid, W.red_i, round & 1, &round_total);
       if (valid && o < cap_cells) {
         typedef __attribute__((address_space(1))) cfear_cell g_cell;
         typedef double f64x2 __attribute__((ext_vector_type(2)));

@@ -213,7 +213,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
     }
   }
   int total;
-  int o = block_exclusive_scan(cnt, red_i, &total);  // (its barriers also publish the table)
+  int o = block_exclusive_scan_1b(cnt, red_i, 0, &total);  // (its barrier also publishes the table; the first scan of the kernel)
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
   int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
   auto point = [&](uint32_t s) {
