@@ -383,11 +383,15 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
   }
   float gcell = (float)(2.0 * P.assoc_radius);
   int gw, gh;
-  for (;;) {
+  for (int it = 0;; it++) {
     gw = (int)floorf((gx1 - gx0) / gcell) + 1;
     gh = (int)floorf((gy1 - gy0) / gcell) + 1;
-    if ((long long)gw * gh <= S->cap_grid) break;
+    if (gw >= 1 && gh >= 1 && (long long)gw * gh <= S->cap_grid) break;
     gcell *= 2.f;
+    if (it >= 64 || !(gcell > 0.f) || !isfinite(gcell)) {  // non-finite extents (or a non-positive cell size): one bucket, never a spin
+      gw = 1; gh = 1; gcell = 3.0e38f;
+      break;
+    }
   }
   const int G = gw * gh;
   // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets, grid_rows3): the association reads
