@@ -89,3 +89,41 @@ def test_register_soft_matches_oracle(oracle, cost, sig):
     assert np.allclose(rg[2], ro[2], rtol=1e-6, atol=1e-12)
     assert abs(Sg.final_cost - So.final_cost) < 1e-9 * max(1.0, So.final_cost)
     ctx.close()
+
+
+def test_scan_from_cells_round_trip_and_tune_knobs(oracle):
+    """cfear_scan_from_cells (raw / transformed-copy maps are built on the host and handed over as cells): a scan rebuilt from the
+    downloaded cells of another scan answers GetClosestIdx identically and registers identically; cfear_tune rejects unknown
+    keys and its launch-shape knobs do not change results."""
+    RRl = np.float32(0.0595238)
+    imgs, _ = synth.world_sequence(3, seed=33)
+    p = capi.default_params(range_res=RRl, res=3.0, weight_intensity=1, weight_opt=4)
+    ctx = capi.Context(p, 400, 3360)
+    scans = []
+    for t in range(3):
+        c, _ = ctx.filter_polar(imgs[t], peaks=False)
+        scans.append(ctx.scan_create(c))
+    rebuilt = [ctx.scan_from_cells(s.cells()) for s in scans]
+    for a, b in zip(scans, rebuilt):
+        assert a.size == b.size
+        ca, cb = a.cells(), b.cells()
+        for f in ("mean", "cov", "normal", "scale", "nsamples"):
+            assert np.array_equal(ca[f], cb[f]), f
+        rng = np.random.default_rng(1)
+        q = ca["mean"][rng.integers(0, len(ca), 300)] + rng.normal(0, 1.5, (300, 2))
+        assert np.array_equal(a.closest(q, 2.0), b.closest(q, 2.0))
+    poses = np.array([[0, 0, 0], [1.0, 0.02, 0.02], [2.1, 0.08, 0.05]])
+    r1 = ctx.register(scans, poses)
+    r2 = ctx.register(rebuilt, poses)
+    assert np.array_equal(r1[1], r2[1]) and r1[3].outer_iterations == r2[3].outer_iterations
+    assert list(r1[3].inner_iterations[:8]) == list(r2[3].inner_iterations[:8])
+    # launch-shape knobs: filter occupancy variant / rows per wave
+    base = ctx.kstrongest_host(imgs[:2])
+    for occ, rows in ((5, 1), (6, 8), (7, 4)):
+        ctx.tune(capi.TUNE_FILTER_OCCUPANCY, occ); ctx.tune(capi.TUNE_FILTER_ROWS_PER_WAVE, rows)
+        assert np.array_equal(ctx.kstrongest_host(imgs[:2]), base)
+    with pytest.raises(capi.CfearError):
+        ctx.tune(99, 1)
+    with pytest.raises(capi.CfearError):
+        ctx.scan_from_cells(np.zeros(0, dtype=capi.CELL_DTYPE))
+    ctx.close()
