@@ -67,6 +67,10 @@ struct OdoParams {
   int A, k, compensate, ccw, use_keyframe, submap;
   double min_keyframe_dist, min_keyframe_rot_deg;
   long long* phase_times;  // optional [B][32] wall_clock64 ticks (tools/)
+  long long* wg_times;     // optional [B][32]: start / end clock of every workgroup of the PRODUCTION kernels (slots 0, 1 features;
+                           // 14, 15 registration) - two clock reads per workgroup, off the critical path
+  int phase_detail;        // also accumulate the evaluation / controller times of every LM command (three clock reads per command:
+                           // the registration kernel runs at half speed with them)
   int seq0;  // first sequence of this launch (sub-batches run on their own streams)
 };
 
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   const Aff2 TprevMot = st->Tmot;  // :146
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   if (TIMED) pt.mark();
+  if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32] = (long long)wall_clock64();
   // the voxel bitmap and the counting-sort counters start all-zero (cleared here: the barriers of the cloud pass publish it)
   {
     uint32_t* z = reinterpret_cast<uint32_t*>(lds + FeatLdsC::bm);
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
                                  (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds);
   if (TIMED) { pt.mark(); pt.mark(); }
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true);  // :161
+  if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 
 template <bool TIMED>
@@ -249,8 +255,9 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
   const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
   const int nkf = st->nkf;
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
-  pt.acc = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
+  pt.acc = (TIMED && OP.phase_times && OP.phase_detail) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
   if (TIMED) pt.mark();
+  if (!TIMED && OP.wg_times && tid == 0) OP.wg_times[(size_t)q * 32 + 14] = (long long)wall_clock64();
   const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
   cfear_reg_summary* sum = &summaries[q];
   __syncthreads();  // every thread has read the state before thread 0 rewrites it
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
     st->frames++; st->last_slot = cur_slot;
     double v[3]; aff_to_xyt(Tcurrent, v);
     poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
+    if (!TIMED && OP.wg_times) OP.wg_times[(size_t)q * 32 + 15] = (long long)wall_clock64();
   }
 }
 
@@ -443,6 +451,8 @@ struct cfear_odometry {
   uint32_t* d_slots[2] = {nullptr, nullptr};  // filter output, double-buffered: the filter runs one sweep ahead
   uint8_t* d_polar = nullptr;  // staging for step_host
   long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
+  int phase_detail = 1;
+  bool wg_only = false;  // the table only receives the workgroups' start / end clocks, from the production kernels
   // The filter of a sweep needs nothing but its input, and it is bound by HBM while features / registration are chains
   // of short dependent phases. With overlap on it runs on a stream of its own (sf) into the slot buffer of its parity;
   // features / registration follow on a second stream (so) once their slot buffer is written (ev_filt) and release it
@@ -1079,7 +1089,8 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
   OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
   OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
-  OP.phase_times = o->d_phase_times;
+  OP.phase_times = o->wg_only ? nullptr : o->d_phase_times; OP.phase_detail = o->phase_detail;
+  OP.wg_times = o->wg_only ? o->d_phase_times : nullptr;
   OP.seq0 = 0;
   const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
   hipStream_t sf = o->overlap ? o->sf : ctx->stream, so = o->overlap ? o->so : ctx->stream;
@@ -1102,7 +1113,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_filt[buf], 0));
   }
   if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
-  if (o->d_phase_times)
+  if (OP.phase_times)
     hipLaunchKernelGGL(features_step_kernel<true>, dim3(o->B), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, OP, o->d_states,
                        o->d_scan_ptrs, o->d_scratch_hdr);
   else
@@ -1110,7 +1121,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
                        o->d_scan_ptrs, o->d_scratch_hdr);
   if (o->overlap) { CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_free[buf], so)); o->filt_pending[buf] = true; }
   if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
-  if (o->d_phase_times)
+  if (OP.phase_times)
     hipLaunchKernelGGL(register_step_kernel<true>, dim3(o->B), dim3(BLOCK_R), 0, so, OP, o->d_states, o->d_scan_ptrs,
                        o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
   else
@@ -1128,6 +1139,10 @@ int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, int enable, lo
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t bytes = sizeof(long long) * 32 * (size_t)o->B;
+  if (enable == 1 || enable == 2 || enable == 3) {  // (any other non-zero value: read without changing the mode)
+    o->phase_detail = enable == 1 ? 1 : 0;
+    o->wg_only = enable == 3;
+  }
   if (!enable) {
     if (o->d_phase_times) (void)hipFree(o->d_phase_times);
     o->d_phase_times = nullptr;

@@ -255,7 +255,10 @@ int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* odo, doub
 /* Per-workgroup phase timestamps (tuning / bench.py's workgroup-time percentiles): enable = 1 switches the odometry steps
  * to the timed instantiations of the features and registration kernels (thread 0 of every workgroup stores wall_clock64()
  * ticks of 10 ns: slots 0..13 features phases, 14..28 registration phases, 29..31 accumulated evaluation / controller
- * ticks and evaluation count); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
+ * ticks and evaluation count - these three need clock reads around every LM command and halve the speed of the
+ * registration kernel; enable = 2 leaves them out: phase stamps only, still the timed instantiations; enable = 3 keeps the
+ * PRODUCTION kernels and only records every workgroup's start and end clock in slots 0, 1 and 14, 15 - what bench.py's
+ * workgroup-time percentiles use); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
  * copied out (synchronises) and cleared. enable = 0 frees the table: back to the production kernels. */
 int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* odo, int enable, long long* host_ticks);
 
