@@ -340,9 +340,10 @@ class Context:
         return bool(ok.value), cov.reshape(6, 6), costs
 
     def odometry(self, n_sequences, overlap=None):
-        """overlap: None = the context's setting (default on), True / False = filter one sweep ahead on its own stream or not"""
+        """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
+        sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams"""
         if overlap is not None:
-            self.tune(TUNE_ODOMETRY_OVERLAP, 1 if overlap else 0)
+            self.tune(TUNE_ODOMETRY_OVERLAP, int(overlap))
         return Odometry(self, n_sequences)
 
 

@@ -460,11 +460,18 @@ struct cfear_odometry {
   // can start on compute units that the last rounds of registration(t) leave idle. The context stream joins in the
   // reading calls (odo_join). With overlap off (the default, see DESIGN.md: the three kernels want the same registers and
   // LDS of a compute unit, so running them side by side stretches all of them) they run in turn on the context stream.
-  int overlap = 0;
+  int overlap = 0;  // 0: the three kernels in turn on the context stream; n >= 1: filter stream + n odometry streams (below)
   long long step_no = 0;
-  hipStream_t sf = nullptr, so = nullptr;
-  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_copied = nullptr;
-  hipEvent_t ev_filt[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  // overlap = n: the filter runs on a LOW-priority stream of its own (sf) into the slot buffer of its parity, one sweep ahead;
+  // the sequences are cut into n contiguous ranges whose features / registration kernels run on n HIGH-priority streams
+  // (so[i]). Different ranges are at different points of their features -> registration chain, so the ragged last round of one
+  // kernel is filled with workgroups of another (a features workgroup and a registration workgroup fit a compute unit
+  // together), and the filter takes what is left.
+  hipStream_t sf = nullptr;
+  std::vector<hipStream_t> so;
+  hipEvent_t ev_in = nullptr, ev_copied = nullptr;
+  hipEvent_t ev_filt[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_free[2], ev_done;  // per odometry stream
   bool filt_pending[2] = {false, false};  // ev_filt / ev_free have been recorded at least once
   // profiling: timing events taken from a pool that is created up front (and grown in blocks)
   bool profile = false;
@@ -490,8 +497,10 @@ static int odo_timed_event(cfear_ctx* ctx, cfear_odometry* o, std::vector<hipEve
 // make everything the internal streams have been given so far visible to the context stream
 static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
   if (o->overlap && o->step_no > 0) {
-    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_done, o->so));  // so waits for every filter it consumes: joining so joins sf
-    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_done, 0));
+    for (size_t i = 0; i < o->so.size(); i++) {  // an odometry stream waits for every filter it consumes: joining them joins sf
+      CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_done[i], o->so[i]));
+      CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_done[i], 0));
+    }
   }
   return CFEAR_OK;
 }
@@ -988,7 +997,9 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   if (!o) return;
   if (ctx) {
     (void)hipSetDevice(ctx->device);
-    for (hipStream_t st : {o->sf, o->so}) {
+    std::vector<hipStream_t> all = o->so;
+    all.push_back(o->sf);
+    for (hipStream_t st : all) {
       if (!st) continue;
       (void)hipStreamSynchronize(st);
       for (size_t i = 0; i < ctx->aux_streams.size(); i++)
@@ -1000,9 +1011,10 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
                   o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : o->pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {o->ev_in, o->ev_done, o->ev_copied, o->ev_filt[0], o->ev_filt[1], o->ev_free[0], o->ev_free[1]}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {o->ev_in, o->ev_copied, o->ev_filt[0], o->ev_filt[1]}) if (e) (void)hipEventDestroy(e);
+  for (auto* v : {&o->ev_free[0], &o->ev_free[1], &o->ev_done}) for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
   if (o->sf) (void)hipStreamDestroy(o->sf);
-  if (o->so) (void)hipStreamDestroy(o->so);
+  for (hipStream_t st : o->so) if (st) (void)hipStreamDestroy(st);
   delete o;
 }
 
@@ -1066,15 +1078,27 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   rc = cfear_odometry_reset(ctx, o);
   if (rc != CFEAR_OK) { cfear_odometry_destroy(ctx, o); return rc; }
   ok = hipEventCreateWithFlags(&o->ev_copied, hipEventDisableTiming) == hipSuccess;
-  o->overlap = ctx->tune_odo_overlap ? 1 : 0;
+  o->overlap = ctx->tune_odo_overlap < 0 ? 0 : (ctx->tune_odo_overlap > 8 ? 8 : ctx->tune_odo_overlap);
+  if (o->overlap > B) o->overlap = B;
   if (ok && o->overlap) {
-    ok = ok && hipStreamCreateWithFlags(&o->sf, hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&o->so, hipStreamNonBlocking) == hipSuccess;
-    for (hipEvent_t* e : {&o->ev_in, &o->ev_done, &o->ev_filt[0], &o->ev_filt[1], &o->ev_free[0], &o->ev_free[1]})
+    int least = 0, greatest = 0;  // numerically lower = higher priority
+    ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&o->sf, hipStreamNonBlocking, least) == hipSuccess;
+    for (int i = 0; ok && i < o->overlap; i++) {
+      hipStream_t st = nullptr;
+      ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) == hipSuccess;
+      if (ok) o->so.push_back(st);
+      for (auto* v : {&o->ev_free[0], &o->ev_free[1], &o->ev_done}) {
+        hipEvent_t e = nullptr;
+        ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (ok) v->push_back(e);
+      }
+    }
+    for (hipEvent_t* e : {&o->ev_in, &o->ev_filt[0], &o->ev_filt[1]})
       ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   }
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_HIP, "odometry stream creation"); }
-  if (o->overlap) { ctx->aux_streams.push_back(o->sf); ctx->aux_streams.push_back(o->so); }
+  if (o->overlap) { ctx->aux_streams.push_back(o->sf); for (hipStream_t st : o->so) ctx->aux_streams.push_back(st); }
   *out = o;
   return CFEAR_OK;
 }
@@ -1093,12 +1117,13 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   OP.wg_times = o->wg_only ? o->d_phase_times : nullptr;
   OP.seq0 = 0;
   const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
-  hipStream_t sf = o->overlap ? o->sf : ctx->stream, so = o->overlap ? o->so : ctx->stream;
+  hipStream_t sf = o->overlap ? o->sf : ctx->stream;
   int rc = CFEAR_OK;
   if (o->overlap) {
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_in, ctx->stream));  // the sweeps are ready at this point of the context stream
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(sf, o->ev_in, 0));
-    if (o->filt_pending[buf]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(sf, o->ev_free[buf], 0));  // features(t-2) has read this buffer
+    if (o->filt_pending[buf])  // features(t-2) of every range has read this buffer
+      for (hipEvent_t e : o->ev_free[buf]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(sf, e, 0));
   }
   // radar_driver.cpp:58
   if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, sf)) != CFEAR_OK) return rc;
@@ -1107,27 +1132,37 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, sf)) != CFEAR_OK) return rc;
   if (o->overlap) {
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_filt[buf], sf));
-    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(so, o->ev_filt[buf], 0));
     // d_polar keeps its stream-order meaning for the caller: whatever the context stream is given after this call (the
     // caller's next write into the buffer, its release to a caching allocator) waits for the filter, the only reader
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_filt[buf], 0));
   }
-  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
-  if (OP.phase_times)
-    hipLaunchKernelGGL(features_step_kernel<true>, dim3(o->B), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, OP, o->d_states,
-                       o->d_scan_ptrs, o->d_scratch_hdr);
-  else
-    hipLaunchKernelGGL(features_step_kernel<false>, dim3(o->B), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, OP, o->d_states,
-                       o->d_scan_ptrs, o->d_scratch_hdr);
-  if (o->overlap) { CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_free[buf], so)); o->filt_pending[buf] = true; }
-  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
-  if (OP.phase_times)
-    hipLaunchKernelGGL(register_step_kernel<true>, dim3(o->B), dim3(BLOCK_R), 0, so, OP, o->d_states, o->d_scan_ptrs,
-                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-  else
-    hipLaunchKernelGGL(register_step_kernel<false>, dim3(o->B), dim3(BLOCK_R), 0, so, OP, o->d_states, o->d_scan_ptrs,
-                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+  const int nsub = o->overlap ? o->overlap : 1;
+  const int per = (o->B + nsub - 1) / nsub;
+  for (int i = 0; i < nsub; i++) {
+    OdoParams P = OP;
+    P.seq0 = i * per;
+    const int count = std::min(per, o->B - P.seq0);
+    if (count <= 0) break;
+    hipStream_t so = o->overlap ? o->so[i] : ctx->stream;
+    if (o->overlap) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(so, o->ev_filt[buf], 0));
+    if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+    if (P.phase_times)
+      hipLaunchKernelGGL(features_step_kernel<true>, dim3(count), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, P, o->d_states,
+                         o->d_scan_ptrs, o->d_scratch_hdr);
+    else
+      hipLaunchKernelGGL(features_step_kernel<false>, dim3(count), dim3(BLOCK_F), 0, so, o->d_slots[buf], ctx->d_trig, P, o->d_states,
+                         o->d_scan_ptrs, o->d_scratch_hdr);
+    if (o->overlap) CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_free[buf][i], so));
+    if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+    if (P.phase_times)
+      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, so, P, o->d_states, o->d_scan_ptrs,
+                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    else
+      hipLaunchKernelGGL(register_step_kernel<false>, dim3(count), dim3(BLOCK_R), 0, so, P, o->d_states, o->d_scan_ptrs,
+                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
+  }
+  if (o->overlap) o->filt_pending[buf] = true;
   o->step_no++;
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;

@@ -77,9 +77,10 @@ int cfear_synchronize(cfear_ctx* ctx);
 
 /* Launch-shape knobs of a context (tuning; an integration never needs them, tools/ and bench.py do). Results do not depend on
  * them. FILTER_OCCUPANCY: 5..7 filter waves per SIMD (default 7); FILTER_ROWS_PER_WAVE: consecutive azimuths walked by one
- * filter wave (default 4); ODOMETRY_OVERLAP: batched odometry objects created afterwards run the filter of a sweep on a stream
- * of their own, one sweep ahead of the features / registration kernels (1; default 0 = the three kernels strictly in turn on
- * the context stream, which measured faster: DESIGN.md). */
+ * filter wave (default 4); ODOMETRY_OVERLAP = n (0..8): batched odometry objects created afterwards run the filter of a sweep
+ * on a low-priority stream of their own, one sweep ahead, and the features / registration kernels of n contiguous ranges of
+ * the sequences on n high-priority streams (0 = the three kernels strictly in turn on the context stream; DESIGN.md has the
+ * measurements). */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 

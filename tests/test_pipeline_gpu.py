@@ -216,8 +216,9 @@ def test_reference_presets_through_device_fuser(oracle, k, cost, res, submap):
 
 
 def test_filter_ahead_streams_give_identical_results(oracle):
-    """The batched odometry runs the filter of a sweep on a stream of its own, one sweep ahead of the features /
-    registration kernels (double-buffered slots; cfear_tune ODOMETRY_OVERLAP). It must not change any result, for
+    """The batched odometry can run the filter of a sweep on a low-priority stream of its own, one sweep ahead, and the features /
+    registration kernels of n ranges of the sequences on n high-priority streams (double-buffered slots; cfear_tune
+    ODOMETRY_OVERLAP = n). It must not change any result, for
     device-resident input (free-running streams) and for host input (staging buffer reuse), with reads in between."""
     import torch
     imgs, _ = synth.world_sequence(8, seed=13)
@@ -229,7 +230,7 @@ def test_filter_ahead_streams_give_identical_results(oracle):
     torch.cuda.synchronize()
     pg = mk_params(capi)
     results = {}
-    for overlap in (False, True):
+    for overlap in (0, 1, 3):
         ctx = capi.Context(pg, 400, 3360)
         odo = ctx.odometry(B, overlap=overlap)
         mid = None
@@ -247,17 +248,18 @@ def test_filter_ahead_streams_give_identical_results(oracle):
         results[overlap] = (poses, mid, [(s[0].outer_iterations, list(s[0].inner_iterations[:8]), s[1], s[2]) for s in summ])
         odo.release()
         ctx.close()
-    assert np.array_equal(results[False][0], results[True][0])
-    assert np.array_equal(results[False][1], results[True][1])
-    assert results[False][2] == results[True][2]
-    assert np.all(np.isfinite(results[True][0])) and np.abs(results[True][0][:, :2]).max() > 1.0  # the sequences moved
+    for n in (1, 3):
+        assert np.array_equal(results[0][0], results[n][0])
+        assert np.array_equal(results[0][1], results[n][1])
+        assert results[0][2] == results[n][2]
+    assert np.all(np.isfinite(results[1][0])) and np.abs(results[1][0][:, :2]).max() > 1.0  # the sequences moved
     # against the oracle's fuser, sweep by sweep order
     po = mk_params(oracle)
     for q in (0, 3):
         fu = oracle.Fuser(po)
         for t in range(8):
             exp = fu.process_polar(streams[q][t])
-        got = results[True][0][q]
+        got = results[3][0][q]
         assert np.all(np.abs(got[:2] - exp[:2]) < POS_TOL) and abs(got[2] - exp[2]) < ROT_TOL, (q, got, exp)
 
 
