@@ -47,3 +47,26 @@ def test_oxford_png_directory_replay(oracle, tmp_path):
     for t in range(3):
         exp = fu.process_polar(imgs[t])
     assert np.all(np.abs(np.array(out["final_pose"]) - exp) < [1e-4, 1e-4, 1e-5])
+
+
+def test_bench_two_ranks_through_the_launcher_on_one_gpu():
+    """`python bench.py --gpus 2` end to end with real device work: the launcher starts two ranks, each generates its own streams,
+    runs its resident sequences through the HIP path and the throughput is reduced (SUM scans, MAX seconds) into one JSON line
+    from rank 0. No second GPU in the test box: --share-gpu puts both ranks on cuda:0 and the reduction on gloo (the line
+    says so); the 8-GPU run differs in the device index and the RCCL backend only."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "6", "--warmup", "2", "--sequences", "64",
+                          "--unique", "2", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["sweeps_per_step"] == 128 and "INVALID" in r
+    assert len(r["per_rank_scans_per_s"]) == 2 and all(v > 0 for v in r["per_rank_scans_per_s"])
+    assert abs(r["value"] - 2 * 64 * 6 / (r["ms_per_step"] * 6 / 1e3)) < 1e-6 * r["value"]
+    assert r["state"]["replicas_bit_identical"] is True
