@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     uint32_t peak = 0;
     const bool interior = mpos >= 3 && mpos < R - 3;  // :251
     uint32_t covered = 0x7Fu;
-    if (__ballot(kept && !interior) != 0) {
+    const bool edge_points = __ballot(kept && !interior) != 0;  // wave-uniform: a kept point within 3 bins of a row end (rare)
+    if (edge_points) {
       // scores exist only where a valid kept point's +-3 window put them in the map (:253-263);
       // everything else reads as the unordered_map default 0 (:271-276)
       covered = 0;
@@ -468,9 +469,11 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 #pragma unroll
       for (int u = 1; u < 7; u++) sm[u] = sm[u - 1] - bv[u - 1] + bv[u + 6];
       bool largest = true;
+      if (edge_points) {  // (all seven scores exist otherwise: the masking is skipped for the whole wave)
 #pragma unroll
-      for (int u = 0; u < 7; u++)
-        if (!((covered >> u) & 1u)) sm[u] = 0;
+        for (int u = 0; u < 7; u++)
+          if (!((covered >> u) & 1u)) sm[u] = 0;
+      }
 #pragma unroll
       for (int i = 1; i <= 3; i++) {
         if (sm[3 - i] > sm[3] || sm[3] < sm[3 + i]) largest = false;  // :282

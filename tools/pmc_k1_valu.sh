@@ -1,7 +1,7 @@
 #!/bin/bash
-# VALU / SALU / LDS instructions per row of the k-strongest kernel (world data), per debug phase
+# VALU / SALU / LDS instructions per row of the k-strongest kernel (world data), (uniform, world)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-K1_N=256 K1_REPS=1 K1_CONFIGS="${1:-8,4,0}" timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d /tmp/pmc_valu -o k1 -- python $R/tools/gpu_time_k1.py > /tmp/pmc_valu.log 2>&1
+K1_N=256 K1_REPS=1 K1_CONFIGS="${1:-7,4}" timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d /tmp/pmc_valu -o k1 -- python $R/tools/gpu_time_k1.py > /tmp/pmc_valu.log 2>&1
 python - <<'PY'
 import sqlite3, glob, collections
 db = glob.glob('/tmp/pmc_valu/**/*.db', recursive=True)[0]
