@@ -7,6 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcfear_hip.so")
+if os.environ.get("CFEAR_HIP_LIB"):  # tools/: a profile build of the same sources (e.g. tools/build_stop_variants.sh)
+    LIB = os.path.abspath(os.environ["CFEAR_HIP_LIB"])
 
 # -ffp-contract=off: several decisions on the path are rounding sensitive (voxel index, float
 # d^2 < r^2, float centroid sums) and the reference is built without FMA contraction.

@@ -24,17 +24,17 @@ struct FeatLdsC {  // byte offsets into the LDS segment
   static constexpr size_t red_f = red_i + 64 * sizeof(int);                 // 64 floats
   static constexpr size_t bm = red_f + 64 * sizeof(float);                  // bitmap words (+1: rank(G) looks one past)
   static constexpr size_t bmp = bm + (CFEAR_CPT_VOXELS / 32 + 4) * 4;       // u16 prefix per bitmap word (+1)
-  static constexpr size_t vst = bmp + (CFEAR_CPT_VOXELS / 32 + 8) * 2;      // u16 [cap + 2]: counters, cursors, then voxel starts
+  static constexpr size_t vst = bmp + (CFEAR_CPT_VOXELS / 32 + 8) * 2;      // u16 [cap + 2]: voxel starts (vst[c] .. vst[c + 1] = the slots of occupied voxel c)
   static constexpr size_t ord = vst + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap + 2]: parked voxel ids, unordered slots, candidate totals, chunk starts
   static constexpr size_t chk = ord + (CFEAR_CPT_CAP + 8) * 2;              // u16 [cap]: sample of every chunk; later the float cell means
   static constexpr size_t pw = chk + CFEAR_CPT_CAP * 2;                     // u8 [cap] moment weights (from the intensities) in sorted order
-  static constexpr size_t pxy = (pw + CFEAR_CPT_CAP + 15) / 16 * 16;        // float2 [cap] points in sorted order; before that the bearing table of the cloud pass, afterwards the grid counters
+  static constexpr size_t pxy = (pw + CFEAR_CPT_CAP + 15) / 16 * 16;        // float2 [cap] points in sorted order; before that the bearing table of the cloud pass and the counting-sort counters, afterwards the grid counters
   static constexpr size_t total = pxy + CFEAR_CPT_CAP * 8;
 };
 static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit need <= 80,384 B each (LDS comes in 1,280-byte granules)");
 
 // Returns false (before touching anything but registers) when the cloud does not fit this path: more than CFEAR_CPT_CAP
-// points or a voxel grid beyond the bitmap. zeroed: the caller cleared bm / vst already (saves a barrier).
+// points or a voxel grid beyond the bitmap. zeroed: the caller cleared bm already (saves a barrier).
 __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W,
                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed) {
   typedef __attribute__((address_space(1))) double g_f64;
@@ -46,13 +46,14 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   typedef __attribute__((address_space(3))) f32x2 l_f32x2;
   l_u32* const bm = (l_u32*)(lds + FeatLdsC::bm);
   l_u16* const bmp = (l_u16*)(lds + FeatLdsC::bmp);
-  l_u32* const vstw = (l_u32*)(lds + FeatLdsC::vst);  // packed pairs for the atomics
   l_u16* const vst = (l_u16*)(lds + FeatLdsC::vst);
   l_u16* const ord = (l_u16*)(lds + FeatLdsC::ord);
   l_u16* const chk = (l_u16*)(lds + FeatLdsC::chk);
   l_u8* const pw = (l_u8*)(lds + FeatLdsC::pw);
   l_f32x2* const pxy = (l_f32x2*)(lds + FeatLdsC::pxy);
   g_f64* const g_part = (g_f64*)W.part;
+  typedef __attribute__((address_space(1))) f32x2 g_f32x2;
+  g_f32x2* const g_cen = (g_f32x2*)W.samples;  // voxel centroids (8-byte aligned: the scratch arrays start on 256 B)
   const int tid = threadIdx.x, nt = blockDim.x;
   const g_f32* const xyi = (const g_f32*)S->xyi;
   const int ccap = min(CFEAR_CPT_CAP, W.cap);  // points / chunk records the arrays (LDS and the global partial sums) hold
@@ -80,19 +81,23 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   const int G = (int)Gll, NW = (G >> 5) + 1;  // bitmap words incl. the one rank(G) looks at
   if (!zeroed) {
     for (int i = tid; i < CFEAR_CPT_VOXELS / 32 + 4; i += nt) bm[i] = 0u;
-    for (int i = tid; i < (CFEAR_CPT_CAP + 8) / 2; i += nt) vstw[i] = 0u;
     __syncthreads();
   }
-  // points of this thread: i = tid + r * nt (at most PT of them)
+  // points of this thread: wave w owns the index range [w * R * 64, (w + 1) * R * 64) and meets it in index order - round r
+  // of lane l is point (w * R + r) * 64 + l (at most PT rounds). That order is what makes the scatter below stable.
   constexpr int PT = 10;
-  if (n > PT * nt) return false;  // block-uniform (a launch with fewer than 487 threads)
+  const int wv = tid >> 6, ln = tid & 63, nwv = nt >> 6;
+  const int R = (n + 64 * nwv - 1) / (64 * nwv);  // rounds
+  if (R > PT) return false;  // block-uniform (a launch with fewer than 487 threads)
+  auto pidx = [&](int r) -> int { return (wv * R + r) * 64 + ln; };
+  auto pon = [&](int r) -> bool { return (r < R) & (pidx(r) < n); };
   // ---- occupied voxels: bitmap (a point's voxel index stays in its thread's registers) ----
   int pv[PT];
 #pragma unroll
   for (int r = 0; r < PT; r++) {
-    const int i = tid + r * nt;
+    const int i = pidx(r);
     pv[r] = 0;
-    if (i < n) {
+    if (pon(r)) {
       const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
       const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
       pv[r] = ijk0 + ijk1 * div0;
@@ -101,8 +106,17 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   }
   __syncthreads();
   if (pt) pt->mark();
+  CFEAR_STOP_AT(2, true);
   // ---- popcount prefix per bitmap word; nv = occupied voxels = sample points ----
-  int nv;
+  // Counting-sort counters: one set of 16-bit counters per wave (where the sorted points go later) when they fit, else one
+  // set for all. With a set per wave the sort is STABLE without a fix-up: a voxel's slots are handed out wave after wave
+  // (the prefix below), inside a wave round after round (the LDS executes a wave's atomics in program order) and inside one
+  // atomic instruction lane after lane. That last order is how gfx950 resolves same-address lanes (tools/micro/
+  // lds_atomic_order.hip) but nothing documents it, so the result is checked (a point's predecessor in its voxel must have a
+  // smaller index) and a block that finds a violation - or whose counters do not fit - ranks its points by counting instead.
+  l_u32* const cw = (l_u32*)(lds + FeatLdsC::pxy);
+  l_u16* const cw16 = (l_u16*)(lds + FeatLdsC::pxy);
+  int nv, VS, NS;
   {
     const int wpt = (NW + nt - 1) / nt;
     const int w0 = tid * wpt, w1 = min(NW, w0 + wpt);
@@ -110,73 +124,88 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     for (int w = w0; w < w1; w++) cnt += __popc(bm[w]);
     int ex = block_exclusive_scan_1b(cnt, W.red_i, 0, &nv);  // (one-barrier scans: a barrier separates each from the one before)
     for (int w = w0; w < w1; w++) { bmp[w] = (unsigned short)ex; ex += __popc(bm[w]); }
+    VS = (nv + 2) & ~1;  // counters per set (even: a set starts on a word)
+    NS = (nwv * VS <= (int)(CFEAR_CPT_CAP * 8 / 2)) ? nwv : 1;
+    for (int i = tid; i < NS * VS / 2; i += nt) cw[i] = 0u;
   }
   __syncthreads();
+  const int cbase = NS > 1 ? wv * VS : 0;
   // rank of voxel index k among the occupied voxels = number of occupied voxels below k (k in 0..G)
   auto rank = [&](int k) -> int { return (int)bmp[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u)); };
-  // ---- stable counting sort over the occupied voxels ([3P] std::sort on the voxel index, pinned as stable): counters of
-  // voxel c at vst[c + 1] (16 bits, two per word), so that after the scatter vst[c] is the start of voxel c ----
+  // ---- counting sort over the occupied voxels ([3P] std::sort on the voxel index, pinned as stable) ----
 #pragma unroll
   for (int r = 0; r < PT; r++) {
-    if (tid + r * nt < n) {
+    if (pon(r)) {
       pv[r] = rank(pv[r]);  // compact voxel index from here on
-      const int c1 = pv[r] + 1;
-      __hip_atomic_fetch_add(&vstw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int c1 = cbase + pv[r];
+      __hip_atomic_fetch_add(&cw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
-  {  // exclusive scan of the counters: entry c + 1 becomes the cursor (start) of voxel c; entry 0 stays 0
-    const int ipt = (((nv + 1) + nt - 1) / nt + 1) & ~1;  // even: a thread owns whole words
-    const int g0 = tid * ipt, g1 = min(nv + 1, g0 + ipt);
+  {  // voxel starts (vst[c], vst[nv] = n); a counter becomes the first slot its wave may hand out in that voxel
+    const int ipt = (nv + nt - 1) / nt;
+    const int g0 = tid * ipt, g1 = min(nv, g0 + ipt);
     int cnt = 0;
-    for (int g = g0; g < g1; g++) cnt += (int)vst[g];
+    for (int g = g0; g < g1; g++)
+      for (int q = 0; q < NS; q++) cnt += (int)cw16[q * VS + g];
     int tot;
     int o = block_exclusive_scan_1b(cnt, W.red_i, 0, &tot);
-    for (int g = g0; g < g1; g++) { const int c = (int)vst[g]; vst[g] = (unsigned short)o; o += c; }
-    if (tid == 0) { S->n_samples = nv; S->n_points = n; S->status = 0; }
+    for (int g = g0; g < g1; g++) {
+      vst[g] = (unsigned short)o;
+      for (int q = 0; q < NS; q++) { const int c = (int)cw16[q * VS + g]; cw16[q * VS + g] = (unsigned short)o; o += c; }
+    }
+    if (tid == 0) { vst[nv] = (unsigned short)n; S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
   }
-  // scatter: the slot order inside a voxel is whatever the atomics gave; the final slot of a point is the voxel start plus
-  // the number of voxel members with a smaller point index (rank by counting)
   int pos[PT];
 #pragma unroll
   for (int r = 0; r < PT; r++) {
     pos[r] = 0;
-    if (tid + r * nt < n) {
-      const int c1 = pv[r] + 1;
-      const unsigned old = __hip_atomic_fetch_add(&vstw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (pon(r)) {
+      const int c1 = cbase + pv[r];
+      const unsigned old = __hip_atomic_fetch_add(&cw[c1 >> 1], 1u << (16 * (c1 & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       pos[r] = (int)((old >> (16 * (c1 & 1))) & 0xFFFFu);
+      ord[pos[r]] = (unsigned short)pidx(r);
     }
   }
-  __syncthreads();  // vst[c + 1] = end of voxel c = start of voxel c + 1 from here on; vst[0] = 0
-#pragma unroll
-  for (int r = 0; r < PT; r++)
-    if (tid + r * nt < n) ord[pos[r]] = (unsigned short)(tid + r * nt);
   __syncthreads();
-  // final position; the point goes straight to its place in the sorted arrays (x, y as floats, the intensity - an integer
-  // 0..255 from the filter's slots - as a byte)
+  bool ordered = false;
+  if (NS > 1) {  // block-uniform
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < PT; r++)
+      if (pon(r)) bad |= ((pos[r] > (int)vst[pv[r]]) & ((int)ord[max(pos[r] - 1, 0)] >= pidx(r))) ? 1 : 0;
+    ordered = !__syncthreads_or(bad);
+  }
+  // the point goes straight to its place in the sorted arrays (x, y as floats, the intensity - an integer 0..255 from the
+  // filter's slots - as a byte); the counters are dead from here on
 #pragma unroll
   for (int r = 0; r < PT; r++) {
-    const int i = tid + r * nt;
-    if (i < n) {
-      const int a = (int)vst[pv[r]], b = (int)vst[pv[r] + 1];
-      int c = 0;
-      for (int q = a; q < b; q += 4) {  // four members per trip: independent LDS loads (a dependent load per member was the cost)
-        int o4[4];
+    const int i = pidx(r);
+    if (pon(r)) {
+      int fin = pos[r];
+      if (!ordered) {  // final slot = voxel start + number of voxel members with a smaller point index (rank by counting)
+        const int a = (int)vst[pv[r]], b = (int)vst[pv[r] + 1];
+        int c = 0;
+        for (int q = a; q < b; q += 4) {  // four members per trip: independent LDS loads
+          int o4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) o4[u] = (int)ord[min(q + u, b - 1)];
+          for (int u = 0; u < 4; u++) o4[u] = (int)ord[min(q + u, b - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; u++) c += ((q + u < b) & (o4[u] < i)) ? 1 : 0;
+          for (int u = 0; u < 4; u++) c += ((q + u < b) & (o4[u] < i)) ? 1 : 0;
+        }
+        fin = a + c;
       }
       const float x = xyi[3 * i], y = xyi[3 * i + 1], w = xyi[3 * i + 2];
-      pxy[a + c] = f32x2{x, y};
+      pxy[fin] = f32x2{x, y};
       // what the moments need of the intensity: the weight max(I - 60, 0) (pointnormal.cpp:15), an integer 0..195, or 1
       const int iw = (int)w;
-      pw[a + c] = (unsigned char)(P.weight_intensity ? (iw > 60 ? iw - 60 : 0) : 1);
+      pw[fin] = (unsigned char)(P.weight_intensity ? (iw > 60 ? iw - 60 : 0) : 1);
     }
   }
   __syncthreads();
   if (pt) { pt->mark(); pt->mark(); pt->mark(); }
+  CFEAR_STOP_AT(3, true);
   // ---- radius search + cell statistics per sample point (pointnormal.cpp:286-296, :7-63) ----
   // One pass over the candidates with moments shifted by the sample point c:
   //   mean = c + S1/S0,  cov = S2/S0 - (S1/S0)(S1/S0)^T   (== sum w_i (x_i-u)(x_i-u)^T with sum w_i = 1)
@@ -237,6 +266,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     for (int v = i0; v < i1; v++) {
       float cx, cy;
       centroid(v, cx, cy);
+      g_cen[v] = f32x2{cx, cy};  // computed once: the chunks and the epilogue read it back (a dense voxel has ~100 members and ~30 chunks)
       const Win w = window(cx, cy);
       int tot = 0;
       for (int gy = w.gy0; gy <= w.gy1; gy += 4) {
@@ -247,6 +277,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       ord[v] = (unsigned short)(tot >= 6 ? tot : 0);  // fewer than six candidates can never make a cell (pointnormal.cpp:291)
     }
     if (pt) pt->mark();
+    CFEAR_STOP_AT(4, true);
     int o, oa;
     for (int it = 0;; it++) {  // block-uniform: double the chunk size until the chunk list and the active-sample list fit side by side
       int cnt = 0, act = 0;
@@ -269,12 +300,14 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     __syncthreads();
   }
   if (pt) pt->mark();
+  CFEAR_STOP_AT(5, true);
   const size_t cs = (size_t)W.cap;
+  f32x2 cen_next = g_cen[tid < NC ? (int)chk[tid] : 0];
   for (int wq = tid; wq < NC; wq += nt) {
     const int v = (int)chk[wq];
     const int j = wq - (int)ord[v];
-    float cx, cy;
-    centroid(v, cx, cy);
+    const float cx = cen_next.x, cy = cen_next.y;
+    cen_next = g_cen[wq + nt < NC ? (int)chk[wq + nt] : 0];  // the next chunk's centroid is on its way while this one is summed
     const Win win = window(cx, cy);
     int skip = j * C, left = C;
     int m = 0;
@@ -314,6 +347,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   }
   __syncthreads();
   if (pt) pt->mark();
+  CFEAR_STOP_AT(6, true);
   // ---- cell epilogue + compaction: a cell is built in registers and, if it is valid, written straight to its final
   // slot; one block scan per round of blockDim samples keeps the sample order (pointnormal.cpp:292-294)
   int n_cells_out;
@@ -342,8 +376,8 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         }
         const int m = (int)md;
         if (m >= 6) {  // :291
-          float cx, cy;
-          centroid(v, cx, cy);
+          const f32x2 cen = g_cen[v];
+          const float cx = cen.x, cy = cen.y;
           const double m1x = s1x / s0, m1y = s1y / s0;
           const double ux = (double)cx + m1x, uy = (double)cy + m1y;
           const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
@@ -395,6 +429,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     __syncthreads();
   }
   if (pt) { pt->mark(); pt->mark(); }
+  CFEAR_STOP_AT(7, true);
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162): counters and offsets go over
   // the staged points (consumed)
   FeatureScratch Wg = W;

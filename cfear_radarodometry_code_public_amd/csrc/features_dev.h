@@ -42,6 +42,14 @@ struct FeatureParams {
   double assoc_radius;       // registration.h:122 (sizes the NN grid)
 };
 
+// Instruction profile per phase (tools/build_stop_variants.sh, never the product build): -DCFEAR_FEATURES_STOP=k makes the
+// feature build return after phase k, so that the PMC counters of successive variants difference into per-phase counts.
+#ifdef CFEAR_FEATURES_STOP
+#define CFEAR_STOP_AT(k, ret) do { if (CFEAR_FEATURES_STOP == (k)) return ret; } while (0)
+#else
+#define CFEAR_STOP_AT(k, ret) do { } while (0)
+#endif
+
 // optional per-block phase timestamps (bring-up / tuning): thread 0 stores wall_clock64() ticks (100 MHz)
 struct PhaseTimer {
   long long* t;    // next free tick slot of this kernel's share of the 32 per sequence

@@ -4,8 +4,8 @@
 //
 // One radar sweep of B independent sequences = three launches on the context stream, no host round trip:
 //   kstrongest_kernel      (kstrongest.hip)  B*A wavefront-rows, HBM streaming
-//   features_step_kernel   one 1024-thread workgroup per sequence: cloud + motion compensation, counting sort over
-//                          the voxel grid and sorted points in LDS (all 160 KB of a compute unit), chunked cell statistics, cell-mean grid
+//   features_step_kernel   one 512-thread workgroup per sequence (79,680 B of LDS, two per compute unit): cloud + motion
+//                          compensation, voxel bitmap + counting sort, chunked cell statistics, cell-mean grid
 //   register_step_kernel   one 256-thread workgroup per sequence (53 KB LDS incl. the match array, three per compute
 //                          unit so that the serial Levenberg-Marquardt controllers of different sequences overlap):
 //                          association, robust normal equations, LM, outer loop, keyframe logic
@@ -221,10 +221,10 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   if (TIMED) pt.mark();
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32] = (long long)wall_clock64();
-  // the voxel bitmap and the counting-sort counters start all-zero (cleared here: the barriers of the cloud pass publish it)
+  // the voxel bitmap starts all-zero (cleared here: the barriers of the cloud pass publish it)
   {
     uint32_t* z = reinterpret_cast<uint32_t*>(lds + FeatLdsC::bm);
-    for (int i = threadIdx.x; i < (int)((FeatLdsC::ord - FeatLdsC::bm) / 4); i += BLOCK_F) z[i] = 0u;
+    for (int i = threadIdx.x; i < (int)((FeatLdsC::bmp - FeatLdsC::bm) / 4); i += BLOCK_F) z[i] = 0u;
   }
   // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
   double mot[3]; aff_to_xyt(TprevMot, mot);
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
                                  reinterpret_cast<double*>(lds + FeatLdsC::pxy),  // 6 doubles per bearing where the sorted points go later
                                  (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds);
   if (TIMED) { pt.mark(); pt.mark(); }
+  CFEAR_STOP_AT(1, );
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true);  // :161
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
