@@ -260,6 +260,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   // (chunks of 16: with 512 lanes and some 300-1500 samples of 6..300 candidates each, shorter chunks spread the work more
   // evenly over the lanes than chunks of 32 - fewer lanes wait for the longest chunk of their wave)
   int C = 16, NC, NA;  // chunk size, chunks, samples that have chunks ("active": only they can become cells)
+  bool listed = true;  // the active samples are listed behind the chunks (when both lists fit): the epilogue then runs over them only
   {
     const int ipt = (nv + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
@@ -279,13 +280,16 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     if (pt) pt->mark();
     CFEAR_STOP_AT(4, true);
     int o, oa;
-    for (int it = 0;; it++) {  // block-uniform: double the chunk size until the chunk list and the active-sample list fit side by side
+    for (int it = 0;; it++) {  // block-uniform: the chunk list and the active-sample list side by side; if they do not fit, the chunk
+                               // list alone (the epilogue then visits every sample), with the chunk size doubled until it fits
       int cnt = 0, act = 0;
       for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) / C; act += t > 0 ? 1 : 0; }
       int tot2;
       const int ex = block_exclusive_scan_1b(cnt | (act << 16), W.red_i, it & 1, &tot2);  // both counts < 32768: one scan for the two
       o = ex & 0xFFFF; oa = ex >> 16; NC = tot2 & 0xFFFF; NA = tot2 >> 16;
       if (NC + NA <= ccap) break;
+      listed = false;
+      if (NC <= ccap) break;  // (an active sample has a chunk, so NC >= NA; NC -> NA <= nv <= ccap as the chunks grow)
       C <<= 1;
     }
     for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk, active samples in order
@@ -294,7 +298,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       ord[i] = (unsigned short)o;
       for (int j = 0; j < c; j++) chk[o + j] = (unsigned short)i;
       o += c;
-      if (t > 0) { chk[NC + oa] = (unsigned short)i; oa++; }
+      if (listed & (t > 0)) { chk[NC + oa] = (unsigned short)i; oa++; }
     }
     if (tid == 0) ord[nv] = (unsigned short)NC;
     __syncthreads();
@@ -302,14 +306,19 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   if (pt) pt->mark();
   CFEAR_STOP_AT(5, true);
   const size_t cs = (size_t)W.cap;
+  // One chunk per lane and trip; the lanes of a 16-lane row that hold chunks of the same sample (chunks are listed sample by
+  // sample) then add their partial moments together with row shifts, and only the first lane of such a run stores: a dense
+  // sample has ~30 chunks, and the epilogue's walk over them - a dependent memory round trip each - was its long pole.
   f32x2 cen_next = g_cen[tid < NC ? (int)chk[tid] : 0];
-  for (int wq = tid; wq < NC; wq += nt) {
-    const int v = (int)chk[wq];
+  for (int wb = 0; wb < NC; wb += nt) {  // wave-uniform trip count: every lane takes part in the row shifts
+    const int wq = wb + tid;
+    const bool act = wq < NC;
+    const int v = (int)chk[act ? wq : 0];
     const int j = wq - (int)ord[v];
     const float cx = cen_next.x, cy = cen_next.y;
     cen_next = g_cen[wq + nt < NC ? (int)chk[wq + nt] : 0];  // the next chunk's centroid is on its way while this one is summed
     const Win win = window(cx, cy);
-    int skip = j * C, left = C;
+    int skip = j * C, left = act ? C : 0;
     int m = 0;
     double s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
     const double cxd = (double)cx, cyd = (double)cy;
@@ -342,8 +351,23 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       left -= e - s; skip = 0;
      }
     }
-    g_part[wq] = (double)m; g_part[cs + wq] = s0; g_part[2 * cs + wq] = s1x; g_part[3 * cs + wq] = s1y;
-    g_part[4 * cs + wq] = sxx; g_part[5 * cs + wq] = sxy; g_part[6 * cs + wq] = syy;
+    double acc[7] = {(double)m, s0, s1x, s1y, sxx, sxy, syy};
+    const int key = act ? v + 1 : 0;
+#define CFEAR_ROW_STEP(D)                                                                                   \
+    {                                                                                                       \
+      const bool same = act & (__builtin_amdgcn_update_dpp(0, key, 0x100 + (D), 0xF, 0xF, true) == key);    \
+      _Pragma("unroll") for (int q = 0; q < 7; q++) {                                                       \
+        const double t = dpp_get<0x100 + (D), 0xF>(acc[q]); /* row_shl: the value of lane + D of this row, 0 past its end */ \
+        acc[q] += same ? t : 0.0;                                                                           \
+      }                                                                                                     \
+    }
+    CFEAR_ROW_STEP(1) CFEAR_ROW_STEP(2) CFEAR_ROW_STEP(4) CFEAR_ROW_STEP(8)
+#undef CFEAR_ROW_STEP
+    const bool head = ((tid & 15) == 0) | (__builtin_amdgcn_update_dpp(0, key, 0x111, 0xF, 0xF, true) != key);  // row_shr:1 = lane - 1
+    if (act & head) {
+#pragma unroll
+      for (int q = 0; q < 7; q++) g_part[q * cs + wq] = acc[q];
+    }
   }
   __syncthreads();
   if (pt) pt->mark();
@@ -358,21 +382,25 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
-    for (int a0 = 0, round = 0; a0 < NA; a0 += nt, round++) {  // rounds over the active samples, in sample order
+    const int NE = listed ? NA : nv;
+    for (int a0 = 0, round = 0; a0 < NE; a0 += nt, round++) {  // rounds over the active (or all) samples, in sample order
       const int ai = a0 + tid;
       cfear_cell c;
       int valid = 0;
-      if (ai < NA) {
-        const int v = (int)chk[NC + ai];
+      if (ai < NE) {
+        const int v = listed ? (int)chk[NC + ai] : ai;
         double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
         const int w0 = (int)ord[v], w1 = (int)ord[v + 1];
-        for (int w = w0; w < w1; w += 2) {  // two chunks per trip: fourteen loads in flight together, added in chunk order
-          const int wb = min(w + 1, w1 - 1);
+        // the sample's partial sums sit at its first chunk and at every chunk that starts a 16-lane row (see above); two per
+        // trip: fourteen loads in flight together, added in chunk order
+        for (int w = w0; w < w1;) {
+          const int wn = (w | 15) + 1, wb = min(wn, w1 - 1);
           double pa[7], pb[7];
 #pragma unroll
           for (int q = 0; q < 7; q++) { pa[q] = g_part[q * cs + w]; pb[q] = g_part[q * cs + wb]; }
           md += pa[0]; s0 += pa[1]; s1x += pa[2]; s1y += pa[3]; sxx += pa[4]; sxy += pa[5]; syy += pa[6];
-          if (w + 1 < w1) { md += pb[0]; s0 += pb[1]; s1x += pb[2]; s1y += pb[3]; sxx += pb[4]; sxy += pb[5]; syy += pb[6]; }
+          if (wn < w1) { md += pb[0]; s0 += pb[1]; s1x += pb[2]; s1y += pb[3]; sxx += pb[4]; sxy += pb[5]; syy += pb[6]; }
+          w = (wn | 15) + 1;
         }
         const int m = (int)md;
         if (m >= 6) {  // :291

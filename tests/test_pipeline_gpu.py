@@ -90,11 +90,14 @@ def test_features_match_oracle(oracle, seq, res, wi, df):
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["fractional_intensities", "more_points_than_compact", "huge_voxel_grid", "small_leaf"])
+@pytest.mark.parametrize("case", ["fractional_intensities", "more_points_than_compact", "huge_voxel_grid", "small_leaf", "many_voxels"])
 def test_general_feature_path_matches_oracle(oracle, seq, case):
     """Clouds outside the limits of the compact (two workgroups per compute unit) feature path take the general path in
     global arrays: intensities that are not integers 0..255, more than 4864 points, a voxel grid beyond 32768 voxels. Same
-    results as the oracle either way; "small_leaf" stays on the compact path with more than three voxel rows per radius."""
+    results as the oracle either way; "small_leaf" stays on the compact path with more than three voxel rows per radius;
+    "many_voxels" stays on it with more occupied voxels (> 2431) than its per-wave sort counters hold, so that the sort runs on
+    one counter set and ranks the members of a voxel (up to ~100 of them here) by counting - the path a block also takes if
+    it ever finds its ordered scatter out of order."""
     imgs, _ = seq
     res, df = 3.0, 1.0
     slots = oracle.filter_polar(imgs[2], 60, 12)
@@ -109,6 +112,14 @@ def test_general_feature_path_matches_oracle(oracle, seq, case):
         xyi = xyi.copy(); xyi[0, :2] = [-900.0, -700.0]; xyi[1, :2] = [800.0, 650.0]  # 1700 m x 1350 m / 3 m = 255 k voxels
     elif case == "small_leaf":
         df = 2.5  # leaf 1.2 m: five voxel rows inside the radius
+    elif case == "many_voxels":
+        rng = np.random.default_rng(11)
+        keep = xyi[rng.permutation(len(xyi))[:2100]]  # the scan's own clusters (cells come from these)
+        gx, gy = np.meshgrid(np.arange(-26, 26), np.arange(-25, 25))  # 2600 lone points, one per voxel of a 3 m lattice
+        lone = np.stack([gx.ravel() * 3.0 + 1.1 + rng.uniform(-0.9, 0.9, gx.size), gy.ravel() * 3.0 + 1.3 + rng.uniform(-0.9, 0.9, gx.size),
+                         rng.integers(61, 200, gx.size)], axis=1).astype(np.float32)
+        xyi = np.concatenate([keep, lone])[rng.permutation(2100 + gx.size)]
+        assert len(xyi) <= 4864
     po = mk_params(oracle, res=res, weight_intensity=1, downsample_factor=df)
     pg = mk_params(capi, res=res, weight_intensity=1, downsample_factor=df)
     ctx = capi.Context(pg, 400, 3360)
