@@ -36,7 +36,8 @@ static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit
 // Returns false (before touching anything but registers) when the cloud does not fit this path: more than CFEAR_CPT_CAP
 // points or a voxel grid beyond the bitmap. zeroed: the caller cleared bm already (saves a barrier).
 __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n, const FeatureParams& P, const FeatureScratch& W,
-                                                 unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed) {
+                                                 unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed,
+                                                 const PointRegs& PR) {
   typedef __attribute__((address_space(1))) double g_f64;
   typedef __attribute__((address_space(1))) float g_f32;
   typedef __attribute__((address_space(3))) unsigned l_u32;
@@ -55,9 +56,8 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   typedef __attribute__((address_space(1))) f32x2 g_f32x2;
   g_f32x2* const g_cen = (g_f32x2*)W.samples;  // voxel centroids (8-byte aligned: the scratch arrays start on 256 B)
   const int tid = threadIdx.x, nt = blockDim.x;
-  const g_f32* const xyi = (const g_f32*)S->xyi;
   const int ccap = min(CFEAR_CPT_CAP, W.cap);  // points / chunk records the arrays (LDS and the global partial sums) hold
-  if (n <= 0 || n > ccap) return false;
+  if (n <= 0 || n > ccap || PR.rounds <= 0) return false;  // block-uniform
   // ---- PCL VoxelGrid (pointnormal.cpp:277-280), leaf = radius_/downsample_factor ----
   const float leaf = (float)((double)P.radius / P.downsample_factor);
   const float inv = 1.0f / leaf;
@@ -65,9 +65,10 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   if (bounds) {  // block-uniform: the caller already knows the bounding box
     mnx = bounds[0]; mxx = bounds[1]; mny = bounds[2]; mxy = bounds[3];
   } else {
-    for (int i = tid; i < n; i += nt) {
-      const float x = xyi[3 * i], y = xyi[3 * i + 1];
-      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+#pragma unroll
+    for (int r = 0; r < CFEAR_PT; r++) {
+      const float x = PR.x[r], y = PR.y[r];
+      if (preg_on(PR, r)) { mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y); }
     }
     float bb[4] = {mnx, mxx, mny, mxy};
     block_bounds(bb, W.red_f);
@@ -83,23 +84,20 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     for (int i = tid; i < CFEAR_CPT_VOXELS / 32 + 4; i += nt) bm[i] = 0u;
     __syncthreads();
   }
-  // points of this thread: wave w owns the index range [w * R * 64, (w + 1) * R * 64) and meets it in index order - round r
-  // of lane l is point (w * R + r) * 64 + l (at most PT rounds). That order is what makes the scatter below stable.
-  constexpr int PT = 10;
-  const int wv = tid >> 6, ln = tid & 63, nwv = nt >> 6;
-  const int R = (n + 64 * nwv - 1) / (64 * nwv);  // rounds
-  if (R > PT) return false;  // block-uniform (a launch with fewer than 487 threads)
-  auto pidx = [&](int r) -> int { return (wv * R + r) * 64 + ln; };
-  auto pon = [&](int r) -> bool { return (r < R) & (pidx(r) < n); };
+  // the points are in registers (PointRegs): wave w holds a contiguous run of the cloud and meets it in index order, round
+  // after round, lane after lane. That order is what makes the scatter below stable.
+  constexpr int PT = CFEAR_PT;
+  const int wv = tid >> 6, nwv = nt >> 6;
+  auto pidx = [&](int r) -> int { return preg_idx(PR, r); };
+  auto pon = [&](int r) -> bool { return preg_on(PR, r); };
   // ---- occupied voxels: bitmap (a point's voxel index stays in its thread's registers) ----
   int pv[PT];
 #pragma unroll
   for (int r = 0; r < PT; r++) {
-    const int i = pidx(r);
     pv[r] = 0;
     if (pon(r)) {
-      const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
-      const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+      const int ijk0 = (int)(floorf(PR.x[r] * inv) - (float)min_b0);
+      const int ijk1 = (int)(floorf(PR.y[r] * inv) - (float)min_b1);
       pv[r] = ijk0 + ijk1 * div0;
       __hip_atomic_fetch_or(&bm[pv[r] >> 5], 1u << (pv[r] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -196,10 +194,12 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         }
         fin = a + c;
       }
-      const float x = xyi[3 * i], y = xyi[3 * i + 1], w = xyi[3 * i + 2];
-      pxy[fin] = f32x2{x, y};
+      // (one 8-byte store from the two bit patterns: built as a float vector, the optimizer widens the read of PR.x[r] into a
+      // vector load that spans x[r + 1], which keeps the whole register array in scratch memory)
+      ((__attribute__((address_space(3))) unsigned long long*)pxy)[fin] =
+          (unsigned long long)__float_as_uint(PR.x[r]) | ((unsigned long long)__float_as_uint(PR.y[r]) << 32);
       // what the moments need of the intensity: the weight max(I - 60, 0) (pointnormal.cpp:15), an integer 0..195, or 1
-      const int iw = (int)w;
+      const int iw = preg_w(PR, r);
       pw[fin] = (unsigned char)(P.weight_intensity ? (iw > 60 ? iw - 60 : 0) : 1);
     }
   }

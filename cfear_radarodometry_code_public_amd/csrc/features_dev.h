@@ -142,7 +142,7 @@ __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m
 // Here the points of bearing b lie on the ray theta_b up to the float rounding of (x, y), so these are expanded
 // around per-bearing values kept in LDS (tab: 4 doubles per bearing: angle, sin, cos of d_b * m2, d_b):
 //   atan2(y, x) = theta_b + atan((y c_b - x s_b) / (x c_b + y s_b)),  argument ~1e-7 => atan(t) = t to f64 precision
-//   sin/cos(arg) around arg_b = d_b * m2 to second order in (arg - arg_b) ~ 1e-9
+//   sin/cos(arg) around arg_b = d_b * m2 to first order in (arg - arg_b) ~ 1e-9 (the second-order term is 1e-18)
 // which agrees with evaluating the reference's expressions to within f64 rounding (the test tolerance on
 // compensated points stays one float ulp, as for any two libm implementations). The sweep fraction a / (2 pi) is a
 // multiplication by the rounded reciprocal here (a double division costs some 35 instructions per point): one ulp of d,
@@ -158,22 +158,52 @@ __device__ __noinline__ float2 compensate_point_plain(float x, float y, double m
   return make_float2((float)((c1 * px + (-s1) * py) + d * m0), (float)((s1 * px + c1 * py) + d * m1));
 }
 
-// quotient of a small numerator by a well-scaled denominator (the ray-offset term of the compensation: |num| ~ 1e-7 den,
-// den = a range of 2.5 .. 400 m): hardware reciprocal, two Newton steps, one residual correction - the quotient without the
-// scaling / special-case handling of a full IEEE division (a third of its instructions); agrees with it to an ulp of a
-// term that is added to an angle 1e7 times its size.
-__device__ __forceinline__ double div_well_scaled(double num, double den) {
-  double r = __builtin_amdgcn_rcp(den);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  const double q = num * r;
-  return __builtin_fma(__builtin_fma(-den, q, num), r, q);
+// The points of a block in registers, handed from the cloud pass to the feature build. Wave w holds a contiguous run of the
+// cloud, round after round in index order: the point of lane l in round r has index wbase + (points of the wave's earlier
+// rounds) + (points of lower lanes in round r) - the order the stable counting sort of the feature build relies on.
+#define CFEAR_PT 10  // rounds of 64 points a wave holds at most (A * k <= 5120 with 8 waves: every reference configuration)
+struct PointRegs {
+  float x[CFEAR_PT], y[CFEAR_PT];
+  int wi[CFEAR_PT];                    // intensity (bits 0..7; the compact feature path takes integer intensities 0..255 only)
+                                       // | index of the point in the cloud << 8
+  unsigned long long bal[CFEAR_PT];    // wave-uniform: the lanes that hold a point in round r
+  unsigned onm;                        // bit r: this lane holds a point in round r
+  int wbase;                           // index of the wave's first point
+  int rounds;                          // rounds in use (block-uniform); 0: the cloud does not fit, the points are not here
+};
+__device__ __forceinline__ bool preg_on(const PointRegs& R, int r) { return ((R.onm >> r) & 1u) != 0; }
+__device__ __forceinline__ int preg_idx(const PointRegs& R, int r) { return R.wi[r] >> 8; }
+__device__ __forceinline__ int preg_w(const PointRegs& R, int r) { return R.wi[r] & 255; }
+__device__ __forceinline__ int preg_idx_from_ballots(const PointRegs& R, int r) {  // r: a compile-time constant in an unrolled loop
+  int run = R.wbase;
+#pragma unroll
+  for (int q = 0; q < CFEAR_PT; q++) run += q < r ? __popcll(R.bal[q]) : 0;
+  return run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(R.bal[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)R.bal[r], 0u));
+}
+// a cloud in memory -> registers (per-call feature builds; the general cloud pass)
+__device__ __forceinline__ void point_regs_from_global(const float* __restrict__ xyi, int n, PointRegs& R) {
+  const __attribute__((address_space(1))) float* const g = (const __attribute__((address_space(1))) float*)xyi;
+  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = blockDim.x >> 6;
+  const int rounds = (n + 64 * nwv - 1) / (64 * nwv);
+  R.rounds = rounds <= CFEAR_PT ? rounds : 0;
+  R.wbase = wv * rounds * 64; R.onm = 0u;
+#pragma unroll
+  for (int r = 0; r < CFEAR_PT; r++) {
+    const int t = (wv * rounds + r) * 64 + ln;
+    const bool on = (r < R.rounds) & (t < n);
+    const int tt = on ? t : 0;
+    R.bal[r] = __ballot(on);
+    R.onm |= on ? 1u << r : 0u;
+    R.x[r] = g[3 * tt]; R.y[r] = g[3 * tt + 1]; R.wi[r] = ((int)g[3 * tt + 2] & 255) | (tt << 8);
+  }
 }
 
+// slots of one sweep -> compensated cloud (getPeaksFilteredPointCloud, radar_filters.cpp:309-337, + Compensate, utils.cpp:96-107)
+// in S->xyi AND in the registers of the block (PR), with the bounding box. Returns the number of points.
 __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
                                        float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
                                        double m0, double m1, double m2, int ccw, int* red_i, float* red_f, double* tab,
-                                       int tab_bearings, float bounds[4]) {
+                                       int tab_bearings, float bounds[4], PointRegs& PR) {
   // the sweep's slots, the trigonometric table and the cloud are global arrays: global-typed pointers give global_load /
   // global_store instead of flat instructions (which also count against the LDS counter)
   const __attribute__((address_space(1))) uint32_t* const g_slots = (const __attribute__((address_space(1))) uint32_t*)slots;
@@ -183,14 +213,13 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // radar_filters.cpp:315
   const double range_res_half = range_res / 2.0;
   const int items = A * k;
-  const int ipt = (items + blockDim.x - 1) / blockDim.x;
-  const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
+  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = blockDim.x >> 6;
   // per-bearing table in LDS, six doubles each: principal angle, sin / cos of the compensation rotation at the bearing's
   // angle, its sweep fraction, cos / sin of the bearing (so that the per-point loop has no global load to wait for)
   auto* ltab = CFEAR_LDS_PTR(double, tab);
   const bool tabbed = A <= tab_bearings;       // block-uniform; more bearings than the table holds: plain formulas
-  const bool expand = compensate && tabbed;
-  if (tabbed) {
+  auto build_table = [&]() {
+   if (tabbed) {
     for (int b = threadIdx.x; b < A; b += blockDim.x) {
       ltab[6 * b + 4] = g_trig[2 * b]; ltab[6 * b + 5] = g_trig[2 * b + 1];
       if (compensate) {
@@ -204,110 +233,121 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       }
     }
   }
-  // the thread's slots in registers (one batch of loads) when there are few of them, as in every reference configuration
-  constexpr int SV = 10;  // A * k / blockDim slots: 4800 / 512
-  const bool few = ipt <= SV;  // block-uniform
-  uint32_t sv[SV];
-#pragma unroll
-  for (int u = 0; u < SV; u++) sv[u] = (few && i0 + u < i1) ? g_slots[i0 + u] : 0u;
-  int cnt = 0;
-  if (few) {
-#pragma unroll
-    for (int u = 0; u < SV; u++) cnt += (i0 + u < i1 && CFEAR_SLOT_VALID(sv[u]) && CFEAR_SLOT_RANGE(sv[u]) > min_range_bin) ? 1 : 0;  // :327
-  } else {
-    for (int i = i0; i < i1; i++) {
-      const uint32_t s = g_slots[i];
-      cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
-    }
-  }
-  int total;
-  int o = block_exclusive_scan_1b(cnt, red_i, 0, &total);  // (its barrier also publishes the table; the first scan of the kernel)
+  };
   float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+  const int RC = (items + 64 * nwv - 1) / (64 * nwv);  // rounds of 64 slots per wave
+  int total;
+  if (tabbed && RC <= CFEAR_PT && k < 65536 && items < 65536) {  // block-uniform: every reference configuration
+    // Wave w takes the slots [w * RC * 64, (w + 1) * RC * 64) round after round, lane <-> slot: coalesced loads, and the
+    // kept points of the wave are contiguous in the cloud, in register order (see PointRegs).
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)k - 1u) / (unsigned)k);  // t / k = umulhi(t, magic) for t, k < 65536
+    uint32_t sv[CFEAR_PT];
+#pragma unroll
+    for (int r = 0; r < CFEAR_PT; r++) {  // the slots are on their way from memory while the table is built
+      const int t = (wv * RC + r) * 64 + ln;
+      sv[r] = g_slots[((r < RC) & (t < items)) ? t : 0];
+    }
+    build_table();
+    int wtot = 0;
+    PR.onm = 0u;
+#pragma unroll
+    for (int r = 0; r < CFEAR_PT; r++) {
+      const int t = (wv * RC + r) * 64 + ln;
+      const bool inr = (r < RC) & (t < items);
+      const bool on = inr & (CFEAR_SLOT_VALID(sv[r]) != 0) & (CFEAR_SLOT_RANGE(sv[r]) > min_range_bin);  // :327
+      PR.bal[r] = __ballot(on);
+      PR.onm |= on ? 1u << r : 0u;
+      wtot += __popcll(PR.bal[r]);
+    }
+    {  // index of the wave's first point (this barrier also publishes the table; the first use of the scan scratch)
+      auto* sl = CFEAR_LDS_PTR(int, red_i);
+      if (ln == 0) sl[wv] = wtot;
+      __syncthreads();
+      int base = 0; total = 0;
+      for (int i = 0; i < nwv; i++) { const int c = sl[i]; base += i < wv ? c : 0; total += c; }
+      PR.wbase = base;
+    }
+    if (total > cap) {  // block-uniform, never with the capacities the library allocates: keep the first cap points
+      bool keep[CFEAR_PT];
+#pragma unroll
+      for (int r = 0; r < CFEAR_PT; r++) keep[r] = preg_on(PR, r) && preg_idx_from_ballots(PR, r) < cap;
+      PR.onm = 0u;
+#pragma unroll
+      for (int r = 0; r < CFEAR_PT; r++) { PR.bal[r] = __ballot(keep[r]); PR.onm |= keep[r] ? 1u << r : 0u; }
+    }
+    PR.rounds = RC;
+#pragma unroll
+    for (int r = 0; r < CFEAR_PT; r++) {  // branch-free per round (independent chains of double-precision operations interleave)
+      const uint32_t s = sv[r];
+      const bool on = preg_on(PR, r);
+      const int range = CFEAR_SLOT_RANGE(s);
+      const int t = (wv * RC + r) * 64 + ln;
+      const int bb = min((int)__umulhi((unsigned)t, magic), A - 1);
+      const double cb = ltab[6 * bb + 4], sb = ltab[6 * bb + 5];
+      const double rad = range_res_half + range_res * range;
+      float x = (float)(rad * cb);  // :329
+      float y = (float)(rad * sb);  // :330
+      if (compensate) {  // block-uniform
+        // utils.cpp:96-107 expanded around the bearing (see above). The angle of (x, y) off the bearing's ray - the float
+        // rounding of x and y, ~1e-8 rad - is (y c_b - x s_b) / (x c_b + y s_b); its denominator is the range to 1e-8 and two
+        // digits of the quotient are plenty (it moves the point by ~1e-9 m): a hardware reciprocal of the range
+        const double px = (double)x, py = (double)y;
+        const double ab = ltab[6 * bb], s_b = ltab[6 * bb + 1], c_b = ltab[6 * bb + 2], d_b = ltab[6 * bb + 3];
+        const double a = ab + (py * cb - px * sb) * __builtin_amdgcn_rcp(rad);
+        const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;
+        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+        const double e = (d - d_b) * m2;  // ~1e-9 * m2: first order in e is exact to double precision
+        const double s1 = s_b + e * c_b, c1 = c_b - e * s_b;
+        x = (float)((c1 * px + (-s1) * py) + d * m0);
+        y = (float)((s1 * px + c1 * py) + d * m1);
+      }
+      const int o = preg_idx_from_ballots(PR, r);
+      PR.x[r] = x; PR.y[r] = y; PR.wi[r] = (int)CFEAR_SLOT_INTENSITY(s) | (o << 8);
+      if (on) {
+        g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+      }
+    }
+    total = total < cap ? total : cap;
+    bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
+    block_bounds(bounds, red_f);  // (its barriers come after every store of the cloud: the general feature path may read it back)
+    return total;
+  }
+  // general: any number of slots, a thread takes a contiguous run of them; the cloud goes to memory and comes back
+  build_table();
+  const int ipt = (items + blockDim.x - 1) / blockDim.x;
+  const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
+  int cnt = 0;
+  for (int i = i0; i < i1; i++) {
+    const uint32_t s = g_slots[i];
+    cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
+  }
+  int o = block_exclusive_scan_1b(cnt, red_i, 0, &total);  // (its barrier also publishes the table)
   int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
-  auto point = [&](uint32_t s) {
+  for (int i = i0; i < i1; i++, jb++) {
+    if (jb == k) { jb = 0; b++; }
+    const uint32_t s = g_slots[i];
     const int range = CFEAR_SLOT_RANGE(s);
     if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
       const double cb = tabbed ? ltab[6 * b + 4] : g_trig[2 * b], sb = tabbed ? ltab[6 * b + 5] : g_trig[2 * b + 1];
       const double rad = range_res_half + range_res * range;
       float x = (float)(rad * cb);  // :329
       float y = (float)(rad * sb);  // :330
-      if (compensate && !expand) {  // utils.cpp:96-107 as written (out of line: atan2 + sincos would cost the common path registers)
+      if (compensate) {  // utils.cpp:96-107 as written (out of line)
         const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
         x = p.x; y = p.y;
-      } else if (compensate) {
-        const double px = (double)x, py = (double)y;
-        const double ab = ltab[6 * b], s_b = ltab[6 * b + 1], c_b = ltab[6 * b + 2], d_b = ltab[6 * b + 3];
-        const double a = ab + div_well_scaled(py * cb - px * sb, px * cb + py * sb);
-        const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;  // (one ulp of the quotient by 2 pi: see cloud_step_block)
-        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-        const double e = d * m2 - d_b * m2;
-        const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
-        x = (float)((c1 * px + (-s1) * py) + d * m0);
-        y = (float)((s1 * px + c1 * py) + d * m1);
       }
       g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       o++;
     }
-  };
-  if (few && expand && ipt <= k) {
-    // two points per trip, branch-free: each point is one chain of dependent double-precision operations (two divisions),
-    // and one wave running one chain issues an instruction every 8-10 cycles; two chains interleave
-    struct Pt { float x, y, w; bool on; };
-    auto calc = [&](int u) {
-      Pt p;
-      const uint32_t s = u < SV ? sv[u < SV ? u : 0] : 0u;
-      const int range = CFEAR_SLOT_RANGE(s);
-      p.on = (u < SV) && (i0 + u < i1) && CFEAR_SLOT_VALID(s) && range > min_range_bin;
-      const int bb = min(b + ((jb + u >= k) ? 1 : 0), A - 1);  // at most one bearing change inside a thread's items (ipt <= k)
-      const double cb = ltab[6 * bb + 4], sb = ltab[6 * bb + 5];
-      const double rad = range_res_half + range_res * range;
-      const double px = (double)(float)(rad * cb), py = (double)(float)(rad * sb);  // :329-330 (float store, read back)
-      const double ab = ltab[6 * bb], s_b = ltab[6 * bb + 1], c_b = ltab[6 * bb + 2], d_b = ltab[6 * bb + 3];
-      const double den = px * cb + py * sb;
-      const double a = ab + div_well_scaled(py * cb - px * sb, p.on ? den : 1.0);
-      const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;
-      const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-      const double e = d * m2 - d_b * m2;
-      const double s1 = s_b + e * (c_b - 0.5 * e * s_b), c1 = c_b - e * (s_b + 0.5 * e * c_b);
-      p.x = (float)((c1 * px + (-s1) * py) + d * m0);
-      p.y = (float)((s1 * px + c1 * py) + d * m1);
-      p.w = (float)CFEAR_SLOT_INTENSITY(s);
-      return p;
-    };
-    auto emit = [&](const Pt& p) {
-      if (p.on && o < cap) {
-        g_xyi[3 * o + 0] = p.x; g_xyi[3 * o + 1] = p.y; g_xyi[3 * o + 2] = p.w;
-        mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x); mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
-        o++;
-      }
-    };
-#pragma unroll
-    for (int u = 0; u < SV; u += 2) {  // static slot indices (a runtime index would move the slots out of registers)
-      if (u < ipt) {
-        const Pt p0 = calc(u), p1 = calc(u + 1);
-        emit(p0); emit(p1);
-      }
-    }
-  } else if (few) {
-#pragma unroll 1
-    for (int u = 0; u < ipt && i0 + u < i1; u++, jb++) {  // one copy of the per-point arithmetic; the slot comes out of its register by selects
-      if (jb == k) { jb = 0; b++; }
-      uint32_t s = sv[0];
-#pragma unroll
-      for (int w = 1; w < SV; w++) s = (u == w) ? sv[w] : s;
-      point(s);
-    }
-  } else {
-    for (int i = i0; i < i1; i++, jb++) {
-      if (jb == k) { jb = 0; b++; }
-      point(g_slots[i]);
-    }
   }
+  total = total < cap ? total : cap;
   bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
   block_bounds(bounds, red_f);
   __syncthreads();
-  return total < cap ? total : cap;
+  point_regs_from_global(xyi, total, PR);
+  return total;
 }
 
 // closed-form symmetric 2x2 eigen-decomposition; identical formulas to the oracle's eig2()

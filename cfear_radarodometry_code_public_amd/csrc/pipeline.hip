@@ -92,9 +92,10 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
 // byte_intensities: every intensity of the cloud is an integer in 0..255 (block-uniform; always true for clouds made from
 // the filter's slots) - the compact path keeps them as bytes
 __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
-                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities) {
+                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities,
+                                                  const PointRegs& PR) {
   const FeatureScratch W = make_fscratch(B, lds);
-  if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed)) return;
+  if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR)) return;
   features_block(S, n, P, W, next_pow2(n), pt, bounds);
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
@@ -131,8 +132,10 @@ __global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const flo
     S->xyi[3 * i] = x; S->xyi[3 * i + 1] = y; S->xyi[3 * i + 2] = w;
     bytes &= (w >= 0.f && w <= 255.f && w == (float)(int)w) ? 1 : 0;
   }
-  const bool byte_intensities = __syncthreads_and(bytes) != 0;
-  features_dispatch(S, n, P, B, lds, nullptr, nullptr, false, byte_intensities);
+  const bool byte_intensities = __syncthreads_and(bytes) != 0;  // (the barrier also makes the copy visible to the whole block)
+  PointRegs PR;
+  point_regs_from_global(S->xyi, n, PR);
+  features_dispatch(S, n, P, B, lds, nullptr, nullptr, false, byte_intensities, PR);
 }
 
 // MapPointNormal from given cells (raw = true identity cells, pointnormal.cpp:76-82; the transformed-copy constructor
@@ -229,14 +232,15 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
   double mot[3]; aff_to_xyt(TprevMot, mot);
   float bounds[4];
+  PointRegs PR;
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
                                  reinterpret_cast<int*>(lds + FeatLdsC::red_i), reinterpret_cast<float*>(lds + FeatLdsC::red_f),
                                  reinterpret_cast<double*>(lds + FeatLdsC::pxy),  // 6 doubles per bearing where the sorted points go later
-                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds);
+                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds, PR);
   if (TIMED) { pt.mark(); pt.mark(); }
   CFEAR_STOP_AT(1, );
-  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true);  // :161
+  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR);  // :161
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 
