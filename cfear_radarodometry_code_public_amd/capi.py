@@ -463,13 +463,14 @@ class Odometry:
                          "cfear_odometry_profile_read_stages")
         return tf.value, tr.value, n.value
 
-    def phase_times(self, mode, light=False, workgroups_only=False):
+    def phase_times(self, mode, light=False, workgroups_only=False, controller=False):
         """None: switch to the timed kernel instantiations (light: phase stamps only, without the per-LM-command clock reads that
-        halve the speed of the registration kernel; workgroups_only: production kernels, start / end clock per workgroup); True: read + clear the [B][32] tick table of the steps since the last read;
+        halve the speed of the registration kernel; workgroups_only: production kernels, start / end clock per workgroup; controller: slots 0..7 of a sequence hold the
+        breakdown of the registration's command loop instead of the feature kernel's stamps); True: read + clear the [B][32] tick table of the steps since the last read;
         False: back to the production kernels."""
         L, c = self._ctx._L, self._ctx
         if mode is None:
-            c._check(L.cfear_odometry_phase_times(c._h, self._h, 3 if workgroups_only else (2 if light else 1), None), "cfear_odometry_phase_times")
+            c._check(L.cfear_odometry_phase_times(c._h, self._h, 3 if workgroups_only else (4 if controller else (2 if light else 1)), None), "cfear_odometry_phase_times")
             return None
         if mode is False:
             c._check(L.cfear_odometry_phase_times(c._h, self._h, 0, None), "cfear_odometry_phase_times")

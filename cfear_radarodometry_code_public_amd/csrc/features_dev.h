@@ -55,6 +55,7 @@ struct PhaseTimer {
   long long* t;    // next free tick slot of this kernel's share of the 32 per sequence
   int n, cap;
   long long* acc;  // three accumulators (slots 29..31 of the sequence) or null
+  long long* acc2 = nullptr;  // eight accumulators of the controller breakdown (phase_detail 2; slots 0..7 of the sequence) or null
   __device__ inline void mark() { if (t && threadIdx.x == 0 && n < cap) t[n++] = (long long)wall_clock64(); }
 };
 

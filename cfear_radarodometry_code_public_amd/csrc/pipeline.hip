@@ -261,6 +261,8 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
   const int nkf = st->nkf;
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
   pt.acc = (TIMED && OP.phase_times && OP.phase_detail) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
+  pt.acc2 = (TIMED && OP.phase_times && OP.phase_detail == 2) ? OP.phase_times + (size_t)q * 32 : nullptr;  // (over the feature kernel's stamps)
+  if (TIMED && pt.acc2 && tid == 0) for (int i = 0; i < 8; i++) pt.acc2[i] = 0;
   if (TIMED) pt.mark();
   if (!TIMED && OP.wg_times && tid == 0) OP.wg_times[(size_t)q * 32 + 14] = (long long)wall_clock64();
   const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
@@ -1179,8 +1181,8 @@ int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* o, int enable, lo
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t bytes = sizeof(long long) * 32 * (size_t)o->B;
-  if (enable == 1 || enable == 2 || enable == 3) {  // (any other non-zero value: read without changing the mode)
-    o->phase_detail = enable == 1 ? 1 : 0;
+  if (enable >= 1 && enable <= 4) {  // (any other non-zero value: read without changing the mode)
+    o->phase_detail = enable == 1 ? 1 : (enable == 4 ? 2 : 0);
     o->wg_only = enable == 3;
   }
   if (!enable) {

@@ -133,6 +133,8 @@ struct RegShared {
   int lds_match, pad_a;  // compacted matches live in the LDS match array (M <= CFEAR_MATCH_LDS_CAP)
   double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
   double c, s;  // cos/sin of x[2], computed once by the controller
+  double cur_c, cur_s, prev_c, prev_s;  // cos/sin of xcur[2] and prev_par[2]: the values published with the evaluation that produced
+                                        // them, so that a re-association / first evaluation at xcur needs no sincos of its own
   double Ttar[CFEAR_REG_MAX_SCANS][6];  // keyframe poses as affine maps (vectorToAffine3d, registration.cpp:130-136)
   double Trel[CFEAR_REG_MAX_SCANS][6];  // Ttar^-1 * Tsrc (n_scan_normal.cpp:224)
   GridView kf[CFEAR_REG_MAX_SCANS];      // 1-NN search view of every scan (filled once per Register call)
@@ -151,8 +153,13 @@ struct RegShared {
   NormalEq G;  // sums of the evaluation just done (gather_partials): an 80-byte struct returned by value from an out-of-line
                // function travels through per-thread scratch, a round trip to memory on the controller's serial chain
   double x_cost, x_norm, sc0, sc1, sc2, radius, decrease_factor, dg0, dg1, dg2, xc[3], model_cost_change;
-  int reuse_diagonal, num_invalid, iteration, pad1;
+  int reuse_diagonal, num_invalid, iteration, nrec;  // nrec: outer iterations recorded in orec
+  // per-outer-iteration summary (cfear_reg_summary::inner_iterations ...) of the first CFEAR_OUTER_LDS iterations, written to
+  // memory once at the end: a store to memory in an out-of-line controller function is a memory round trip on the serial
+  // chain (the calling convention waits for it at the return) - 1.8 us per outer iteration
+  struct OuterRec { int inner, term; double cost, pose[3]; } orec[8];
 };
+#define CFEAR_OUTER_LDS 8
 
 // RegShared lives in LDS. Through a generic pointer every field access converts the address (64-bit add, compare with
 // null, select: three extra instructions each, a third of the controller's instruction stream); the functions below take
@@ -172,9 +179,9 @@ __device__ __forceinline__ void neq_store(LNormalEq* p, const NormalEq& e) {
 #define CFEAR_GENERIC(T, lvalue) (*(T*)&(lvalue))  // generic-address-space view of an LDS object (for by-reference parameters)
 
 // ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
-// 636 matches x 64 B + the rest of the registration kernels' LDS = 53,568 B: three workgroups per compute unit need
+// 630 matches x 64 B + the rest of the registration kernels' LDS <= 53,760 B: three workgroups per compute unit need
 // <= 53,760 B each (LDS is handed out in 1,280-byte granules; 53,824 B already drops the kernel to two per CU and +34 % time)
-#define CFEAR_MATCH_LDS_CAP 636
+#define CFEAR_MATCH_LDS_CAP 630
 struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
 __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   MatchPtrs m;
@@ -729,24 +736,47 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
 // Same arithmetic, in the same order, as the CPU oracle's register / LM routines (tests compare iteration counts).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void ctl_publish_eval(LRegShared* sh, double x0, double x1, double x2, int state) {
+__device__ __forceinline__ void ctl_publish_eval(LRegShared* sh, double x0, double x1, double x2, int state, double cs, double sn) {
   sh->x[0] = x0; sh->x[1] = x1; sh->x[2] = x2;
-  { double sn, cs; sincos(x2, &sn, &cs); sh->c = cs; sh->s = sn; }
+  sh->c = cs; sh->s = sn;
   sh->cmd = REG_CMD_EVAL; sh->state = state;
 }
+__device__ __forceinline__ void ctl_publish_eval_cur(LRegShared* sh, int state) {  // at xcur: its cos / sin are known
+  ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], state, sh->cur_c, sh->cur_s);
+}
 
-__device__ __noinline__ void ctl_publish_candidate(LRegShared* sh) { ctl_publish_eval(sh, sh->xc[0], sh->xc[1], sh->xc[2], REG_ST_LM_CAND); }
+__device__ __noinline__ void ctl_publish_candidate(LRegShared* sh) {
+  const double x2 = sh->xc[2];
+  double sn, cs;
+  sincos(x2, &sn, &cs);
+  ctl_publish_eval(sh, sh->xc[0], sh->xc[1], x2, REG_ST_LM_CAND, cs, sn);
+}
 
-// transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i
-__device__ __noinline__ void ctl_publish_build(LRegShared* sh) {
+// transforms of all keyframes for the current pose of the last scan; lane i handles keyframe i. first: the first association
+// of a registration computes the keyframe maps and the cos / sin of the pose; the later ones find the maps in LDS (the
+// keyframes do not move) and the cos / sin where the evaluation that led to xcur left them - the same numbers, without four
+// sincos calls on the controller's serial chain per re-association
+__device__ __noinline__ void ctl_publish_build(LRegShared* sh, bool first) {
   const auto& io = sh->rio;  // fields read through the LDS-typed pointer
   const int n = io.n, L = 3 * (n - 1);
-  const Aff2 Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
+  Aff2 Tsrc;
+  if (first) {
+    Tsrc = aff_from_xyt(sh->xcur[0], sh->xcur[1], sh->xcur[2]);
+    sh->cur_c = Tsrc.l0; sh->cur_s = Tsrc.l2; sh->prev_c = Tsrc.l0; sh->prev_s = Tsrc.l2;
+  } else {
+    const double cs = sh->cur_c, sn = sh->cur_s;
+    Tsrc.l0 = cs; Tsrc.l1 = -sn; Tsrc.l2 = sn; Tsrc.l3 = cs; Tsrc.t0 = sh->xcur[0]; Tsrc.t1 = sh->xcur[1];
+  }
   for (int i = lane_id(); i < n - 1; i += 64) {
-    const Aff2 Tt = aff_from_xyt(io.par[3 * i], io.par[3 * i + 1], io.par[3 * i + 2]);
-    const Aff2 Tr = aff_mul(aff_inv(Tt), Tsrc);  // Tsrctotar (:224)
     auto* a = sh->Ttar[i]; auto* b = sh->Trel[i];
-    a[0] = Tt.l0; a[1] = Tt.l1; a[2] = Tt.l2; a[3] = Tt.l3; a[4] = Tt.t0; a[5] = Tt.t1;
+    Aff2 Tt;
+    if (first) {
+      Tt = aff_from_xyt(io.par[3 * i], io.par[3 * i + 1], io.par[3 * i + 2]);
+      a[0] = Tt.l0; a[1] = Tt.l1; a[2] = Tt.l2; a[3] = Tt.l3; a[4] = Tt.t0; a[5] = Tt.t1;
+    } else {
+      Tt.l0 = a[0]; Tt.l1 = a[1]; Tt.l2 = a[2]; Tt.l3 = a[3]; Tt.t0 = a[4]; Tt.t1 = a[5];
+    }
+    const Aff2 Tr = aff_mul(aff_inv(Tt), Tsrc);  // Tsrctotar (:224)
     b[0] = Tr.l0; b[1] = Tr.l1; b[2] = Tr.l2; b[3] = Tr.l3; b[4] = Tr.t0; b[5] = Tr.t1;
   }
   io.par[L] = sh->xcur[0]; io.par[L + 1] = sh->xcur[1]; io.par[L + 2] = sh->xcur[2];
@@ -789,6 +819,11 @@ __device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNo
   } else if (lane < 3) {
     io.poses[L + lane] = sh->tsrc_last[lane];
   }
+  if (io.out && lane < CFEAR_OUTER_LDS && lane < sh->nrec) {  // the per-iteration records kept in LDS (ctl_lm_done)
+    const auto& rec = sh->orec[lane];
+    io.out->inner_iterations[lane] = rec.inner; io.out->termination[lane] = rec.term; io.out->outer_cost[lane] = rec.cost;
+    io.out->outer_pose[lane][0] = rec.pose[0]; io.out->outer_pose[lane][1] = rec.pose[1]; io.out->outer_pose[lane][2] = rec.pose[2];
+  }
   if (lane == 0) {
     if (io.out) {
       io.out->success = ret; io.out->usable = sh->success ? 1 : 0; io.out->outer_iterations = sh->itr;
@@ -812,7 +847,12 @@ __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
   const int itr = sh->itr;
   sh->success = (sh->ss.termination != 2);
   if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
-  if (lane_id() == 0 && io.out && itr - 1 < CFEAR_MAX_OUTER) {
+  if (itr - 1 < CFEAR_OUTER_LDS) {  // (every lane stores the same values)
+    auto& rec = sh->orec[itr - 1];
+    rec.inner = sh->ss.num_iterations; rec.term = sh->ss.termination; rec.cost = sh->ss.final_cost;
+    rec.pose[0] = sh->xcur[0]; rec.pose[1] = sh->xcur[1]; rec.pose[2] = sh->xcur[2];
+    sh->nrec = itr;
+  } else if (lane_id() == 0 && io.out && itr - 1 < CFEAR_MAX_OUTER) {
     io.out->inner_iterations[itr - 1] = sh->ss.num_iterations; io.out->termination[itr - 1] = sh->ss.termination;
     io.out->outer_cost[itr - 1] = sh->ss.final_cost;
     io.out->outer_pose[itr - 1][0] = sh->xcur[0]; io.out->outer_pose[itr - 1][1] = sh->xcur[1]; io.out->outer_pose[itr - 1][2] = sh->xcur[2];
@@ -821,20 +861,23 @@ __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
   const double rel_improvement = (sh->prev_score - current_score) / sh->prev_score;
   bool brk = false, reverted = false;
   if (itr > P.min_itr) {  // :134-149
-    if (sh->prev_score < current_score) { sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; brk = true; reverted = true; }
+    if (sh->prev_score < current_score) {
+      sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; sh->cur_c = sh->prev_c; sh->cur_s = sh->prev_s;
+      brk = true; reverted = true;
+    }
     else if (rel_improvement < 0.00001) brk = true;
     else if (sh->ss.last_relative_decrease < 0.00001 || sh->ss.num_iterations == 1) brk = true;
   }
   if (!brk) {
     sh->prev_score = current_score;
-    sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
+    sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2]; sh->prev_c = sh->cur_c; sh->prev_s = sh->cur_s;
     sh->itr = itr + 1;  // for-loop increment (:102)
     if (sh->itr <= P.max_outer && sh->success) return CTL_BUILD;
   }
   // loop left: covariance of the last built problem at the final parameters if the solution is usable (:164-183). The LM
   // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
   // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
-  if (sh->success && reverted) { ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_COV); return CTL_WAIT; }
+  if (sh->success && reverted) { ctl_publish_eval_cur(sh, REG_ST_COV); return CTL_WAIT; }
   return sh->success ? CTL_FINISH_E : CTL_FINISH_NONE;
 }
 
@@ -915,7 +958,7 @@ __device__ __noinline__ int ctl_after_build(LRegShared* sh) {
     return CTL_FINISH_NONE;
   }
   if (sh->prior_on) sh->nres += 3;  // the prior block joins after the residual-count check (:370-377)
-  ctl_publish_eval(sh, sh->xcur[0], sh->xcur[1], sh->xcur[2], REG_ST_LM_IT0);
+  ctl_publish_eval_cur(sh, REG_ST_LM_IT0);
   return CTL_WAIT;
 }
 
@@ -952,7 +995,7 @@ __device__ __noinline__ int ctl_after_candidate(LRegShared* sh) {
   sh->ss.num_iterations++;
   sh->ss.last_relative_decrease = relative_decrease;
   if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
-    sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2];
+    sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2]; sh->cur_c = sh->c; sh->cur_s = sh->s;
     sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
     neq_store(&sh->E, C); sh->x_cost = cand_cost;
     const double t = 2.0 * relative_decrease - 1.0;
@@ -976,24 +1019,34 @@ __device__ __noinline__ int ctl_after_cov(LRegShared* sh) {
   return CTL_FINISH_G;
 }
 
-// consumes the result of the command just executed and publishes the next one
-__device__ __forceinline__ void ctl_step(LRegShared* sh) {
+// consumes the result of the command just executed and publishes the next one. acc (tools, timed instantiation only):
+// accumulators [4..7] += time in the state function, in ctl_lm_next, in the publishing function, in ctl_lm_done
+__device__ __forceinline__ void ctl_step(LRegShared* sh, long long* acc = nullptr) {  // acc: registers of the caller (static indices)
   int nx;
+  long long t0 = 0;
+  if (acc) t0 = (long long)wall_clock64();
   switch (sh->state) {
     case REG_ST_BUILD: nx = ctl_after_build(sh); break;
     case REG_ST_LM_IT0: nx = ctl_after_it0(sh); break;
     case REG_ST_LM_CAND: nx = ctl_after_candidate(sh); break;
     default: nx = ctl_after_cov(sh); break;
   }
+  if (acc) { const long long t = (long long)wall_clock64(); acc[4] += t - t0; t0 = t; }
   while (nx != CTL_WAIT) {
+    int slot = 6;
     switch (nx) {
-      case CTL_LM_NEXT: nx = ctl_lm_next(sh); break;
-      case CTL_LM_DONE: nx = ctl_lm_done(sh); break;
-      case CTL_BUILD: ctl_publish_build(sh); nx = CTL_WAIT; break;
+      case CTL_LM_NEXT: nx = ctl_lm_next(sh); slot = 5; break;
+      case CTL_LM_DONE: nx = ctl_lm_done(sh); slot = 7; break;
+      case CTL_BUILD: ctl_publish_build(sh, false); nx = CTL_WAIT; break;
       case CTL_EVAL_CAND: ctl_publish_candidate(sh); nx = CTL_WAIT; break;
       case CTL_FINISH_E: ctl_finish(sh, true, &sh->E); nx = CTL_WAIT; break;
       case CTL_FINISH_G: ctl_finish(sh, true, &sh->G); nx = CTL_WAIT; break;
       default: ctl_finish(sh, false, &sh->E); nx = CTL_WAIT; break;
+    }
+    if (acc) {
+      const long long t = (long long)wall_clock64(), d = t - t0;
+      acc[5] += slot == 5 ? d : 0; acc[6] += slot == 6 ? d : 0; acc[7] += slot == 7 ? d : 0;
+      t0 = t;
     }
   }
 }
@@ -1051,16 +1104,23 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
     sh->tsrc_last[0] = poses[L]; sh->tsrc_last[1] = poses[L + 1]; sh->tsrc_last[2] = poses[L + 2];
     sh->prev_score = 1.7976931348623157e308;
-    sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1;
+    sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1; sh->nrec = 0;
     sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
-    ctl_publish_build(ls);
+    ctl_publish_build(ls, true);
   }
+  // tools (timed instantiation, phase_detail 2): where a command's time goes, seen by thread 0. acc2[0..3] += wait at the
+  // command barrier, execution of the command by wave 0, wait at the result barrier, commands; [4..7]: see ctl_step
+  long long* const acc2g = (pt && pt->acc2 && tid == 0) ? pt->acc2 : nullptr;
+  long long ac[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (in registers; stored once at the end)
+  long long* const acc2 = acc2g ? ac : nullptr;
   for (;;) {
     long long t0c = 0;
-    if (pt && pt->acc && tid == 0) t0c = (long long)wall_clock64();
+    if (pt && (pt->acc || acc2) && tid == 0) t0c = (long long)wall_clock64();
     __syncthreads();  // command visible to every wave
     const int cmd = ls->cmd;
     if (cmd == REG_CMD_DONE) break;
+    long long tb = 0;
+    if (acc2) tb = (long long)wall_clock64();
     if (cmd == REG_CMD_BUILD) {
       if (pt) pt->mark();
       const int M = build_problem_block(scans, n, ls, ls->itr);
@@ -1070,14 +1130,16 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
     }
     long long t1 = 0;
-    if (pt && pt->acc && tid == 0) t1 = (long long)wall_clock64();
+    if (pt && (pt->acc || acc2) && tid == 0) t1 = (long long)wall_clock64();
     __syncthreads();  // results visible to the controller
-    if (master) ctl_step(ls);
+    if (acc2 && cmd != REG_CMD_BUILD) { const long long t = (long long)wall_clock64(); acc2[0] += tb - t0c; acc2[1] += t1 - tb; acc2[2] += t - t1; acc2[3] += 1; }
+    if (master) ctl_step(ls, (cmd != REG_CMD_BUILD) ? acc2 : nullptr);
     if (pt && pt->acc && tid == 0 && cmd != REG_CMD_BUILD) {  // tools: time in evaluations (incl. the barrier before) and in the controller
       const long long t2 = (long long)wall_clock64();
       pt->acc[0] += t1 - t0c; pt->acc[1] += t2 - t1; pt->acc[2] += 1;
     }
   }
+  if (acc2g) for (int i = 0; i < 8; i++) acc2g[i] = ac[i];
   const int ret = ls->ret;
   __syncthreads();
   return ret;
@@ -1109,7 +1171,7 @@ __device__ inline void get_cost_block(ScanDev* const* scans, int n, const double
     const int L = 3 * (n - 1);
     sh->xcur[0] = par_lds[L]; sh->xcur[1] = par_lds[L + 1]; sh->xcur[2] = par_lds[L + 2];
     sh->prior_on = 0;
-    ctl_publish_build(ls);
+    ctl_publish_build(ls, true);
   }
   __syncthreads();
   const int M = build_problem_block(scans, n, ls, itr);

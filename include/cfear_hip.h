@@ -259,7 +259,10 @@ int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* odo, doub
  * ticks and evaluation count - these three need clock reads around every LM command and halve the speed of the
  * registration kernel; enable = 2 leaves them out: phase stamps only, still the timed instantiations; enable = 3 keeps the
  * PRODUCTION kernels and only records every workgroup's start and end clock in slots 0, 1 and 14, 15 - what bench.py's
- * workgroup-time percentiles use); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
+ * workgroup-time percentiles use; enable = 4: timed instantiations, and slots 0..7 hold - instead of the first feature
+ * stamps - the breakdown of the registration's command loop over its evaluation commands: ticks waiting at the command
+ * barrier, executing the command, waiting at the result barrier, the command count, ticks in the controller's state
+ * function, trust-region step, publishing function and end-of-solve function); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
  * copied out (synchronises) and cleared. enable = 0 frees the table: back to the production kernels. */
 int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* odo, int enable, long long* host_ticks);
 
