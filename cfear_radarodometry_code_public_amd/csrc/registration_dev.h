@@ -213,7 +213,73 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
   const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
   const int nthr = min(CFEAR_REG_BLOCK, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < M; i += nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
+  if (!res_out) {
+    // The solver's evaluations. A wave running one chain of dependent double-precision operations issues an instruction
+    // every ~10 cycles, so (1) a thread takes its matches two at a time, as two independent chains; (2) the chain is kept
+    // short: the corrector sqrt(rho') only ever enters the sums squared (J~^T r~ = rho' w J^T r, J~^T J~ = rho' w J^T J), so
+    // that square root is not taken, and Huber's rho' = a / sqrt(s) is a reciprocal square root instead of a square root and a
+    // division; (3) no branches: an absent second match runs with weight 0. (Ulps away from scaling residuals and Jacobians
+    // by sqrt(rho' w) first, which is how GetCost's residuals below are still formed.)
+    constexpr int nr = (COST == CFEAR_COST_P2L) ? 1 : 2;
+    struct Head { double r[2], J[2][3], w2, cost; };  // what a match contributes, before it is multiplied out (few live registers)
+    auto head = [&](int i, bool on) -> Head {
+      Head h;
+      const double sx = rd(5, i), sy = rd(6, i), tmx = rd(0, i), tmy = rd(1, i), wgt = on ? rd(7, i) : 0.0;
+      const double px = (c * sx - s * sy) + x0;
+      const double py = (s * sx + c * sy) + x1;
+      const double dtx = -s * sx - c * sy;
+      const double dty = c * sx - s * sy;
+      if (COST == CFEAR_COST_P2L) {
+        const double nx = rd(2, i), ny = rd(3, i);
+        h.r[0] = (px - tmx) * nx + (py - tmy) * ny;
+        h.J[0][0] = nx; h.J[0][1] = ny; h.J[0][2] = dtx * nx + dty * ny;
+        h.r[1] = 0; h.J[1][0] = h.J[1][1] = h.J[1][2] = 0;
+      } else if (COST == CFEAR_COST_P2D) {
+        const double l00 = rd(2, i), l10 = rd(3, i), l11 = rd(4, i);
+        const double dx = px - tmx, dy = py - tmy;
+        h.r[0] = l00 * dx; h.r[1] = l10 * dx + l11 * dy;
+        h.J[0][0] = l00; h.J[0][1] = 0; h.J[0][2] = l00 * dtx;
+        h.J[1][0] = l10; h.J[1][1] = l11; h.J[1][2] = l10 * dtx + l11 * dty;
+      } else {
+        h.r[0] = tmx - px; h.r[1] = tmy - py;
+        h.J[0][0] = -1; h.J[0][1] = 0; h.J[0][2] = -dtx;
+        h.J[1][0] = 0; h.J[1][1] = -1; h.J[1][2] = -dty;
+      }
+      double sq = h.r[0] * h.r[0];
+      if (nr == 2) sq += h.r[1] * h.r[1];
+      double rho_v, rho_d1;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
+      if (HUBER) {
+        const double la = loss_limit, lb = la * la;
+        const bool out = sq > lb;
+        const double rs = rsqrt(out ? sq : 1.0), rt = sq * rs;  // 1 / sqrt(s), sqrt(s)
+        rho_v = out ? 2.0 * la * rt - lb : sq;
+        rho_d1 = out ? fmax(CFEAR_DBL_MIN, la * rs) : 1.0;
+      } else {
+        const Rho rho = loss_eval(ls->rp.loss, loss_limit, sq);
+        rho_v = rho.v; rho_d1 = rho.d1;
+      }
+      h.cost = 0.5 * (rho_v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
+      h.w2 = rho_d1 * wgt;
+      return h;
+    };
+    auto add = [&](const Head& h) {
+      a.cost += h.cost;
+#pragma unroll
+      for (int k = 0; k < nr; k++) {
+        const double j0 = h.w2 * h.J[k][0], j1 = h.w2 * h.J[k][1], j2 = h.w2 * h.J[k][2];
+        a.g0 += j0 * h.r[k]; a.g1 += j1 * h.r[k]; a.g2 += j2 * h.r[k];
+        a.h00 += j0 * h.J[k][0]; a.h01 += j0 * h.J[k][1]; a.h02 += j0 * h.J[k][2];
+        a.h11 += j1 * h.J[k][1]; a.h12 += j1 * h.J[k][2]; a.h22 += j2 * h.J[k][2];
+      }
+    };
+#pragma unroll 1
+    for (int i = threadIdx.x; i < M; i += 2 * nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
+      const bool onb = i + nthr < M;
+      const Head A = head(i, true), B = head(onb ? i + nthr : i, onb);
+      add(A); add(B);
+    }
+  } else
+  for (int i = threadIdx.x; i < M; i += nthr) {  // GetCost: also the robustified residuals, in residual-block order
     const double sx = rd(5, i), sy = rd(6, i), tmx = rd(0, i), tmy = rd(1, i), wgt = rd(7, i);
     const double px = (c * sx - s * sy) + x0;
     const double py = (s * sx + c * sy) + x1;
@@ -242,9 +308,8 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     }
     double sq = r[0] * r[0];
     if (nr == 2) sq += r[1] * r[1];
-    Rho rho;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
-    if (HUBER) {  // the default loss inline: a function with a call inside saves and restores a register through scratch, a
-                  // round trip to memory at its exit, whichever path is taken (the other losses are out of line)
+    Rho rho;
+    if (HUBER) {
       const double la = loss_limit, lb = la * la;
       if (sq > lb) { const double r = sqrt(sq); rho.v = 2.0 * la * r - lb; rho.d1 = fmax(CFEAR_DBL_MIN, la / r); }
       else { rho.v = sq; rho.d1 = 1.0; }
@@ -253,10 +318,8 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     }
     a.cost += 0.5 * (rho.v * wgt);  // ScaledLoss (n_scan_normal.cpp:277)
     const double sr = sqrt(rho.d1 * wgt);
-    if (res_out) {  // GetCost: the robustified residuals in residual-block order
-      for (int k = 0; k < nr; k++)
-        if (i * nr + k < res_cap) res_out[i * nr + k] = sr * r[k];
-    }
+    for (int k = 0; k < nr; k++)
+      if (i * nr + k < res_cap) res_out[i * nr + k] = sr * r[k];
     for (int k = 0; k < nr; k++) {
       const double rk = sr * r[k];
       const double j0 = sr * J[k][0], j1 = sr * J[k][1], j2 = sr * J[k][2];
@@ -286,6 +349,12 @@ __device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int
 __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                  double* res_out = nullptr, int res_cap = 0) {
   const int cost = ls->rp.cost;
+  // the default configuration (P2L, Huber, matches in LDS) inline in the kernel: out of line, its two interleaved chains reach
+  // the callee-saved registers, whose save / restore through scratch is a round trip to memory per evaluation
+  if (ls->rp.loss == CFEAR_LOSS_HUBER && cost == CFEAR_COST_P2L && lds_match && !res_out) {
+    evaluate_partial_t<true, CFEAR_COST_P2L, true>(ls, M, x0, x1, c, s, nullptr, 0);
+    return;
+  }
   if (ls->rp.loss == CFEAR_LOSS_HUBER) {
     if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
     else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
