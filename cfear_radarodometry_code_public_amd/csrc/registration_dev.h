@@ -951,7 +951,7 @@ __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
-__device__ __noinline__ int ctl_lm_next(LRegShared* sh) {
+__device__ __forceinline__ int ctl_lm_next_body(LRegShared* sh) {
   const auto& P = sh->rp;
   const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_radius = 1e-32;
   for (;;) {
@@ -1031,7 +1031,7 @@ __device__ __noinline__ int ctl_after_build(LRegShared* sh) {
   return CTL_WAIT;
 }
 
-__device__ __noinline__ int ctl_after_it0(LRegShared* sh) {
+__device__ __forceinline__ int ctl_after_it0_body(LRegShared* sh) {
   const double gradient_tolerance = 1e-10;
   gather_partials(sh->rw.red, &sh->G);
   NormalEq E = neq_load(&sh->G);
@@ -1047,7 +1047,7 @@ __device__ __noinline__ int ctl_after_it0(LRegShared* sh) {
   return CTL_LM_NEXT;
 }
 
-__device__ __noinline__ int ctl_after_candidate(LRegShared* sh) {
+__device__ __forceinline__ int ctl_after_candidate_body(LRegShared* sh) {
   const auto& P = sh->rp;
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
@@ -1080,6 +1080,18 @@ __device__ __noinline__ int ctl_after_candidate(LRegShared* sh) {
     if (cand_cost < sh->ss.final_cost) sh->ss.final_cost = cand_cost;
   }
   return CTL_LM_NEXT;
+}
+
+// The state function and the trust-region step that follows it as ONE out-of-line function: what the first leaves in LDS
+// (normal equations, radius, scaling) the second finds in registers - no store -> load round trips, one call less.
+__device__ __noinline__ int ctl_lm_next(LRegShared* sh) { return ctl_lm_next_body(sh); }
+__device__ __noinline__ int ctl_after_it0(LRegShared* sh) {
+  const int nx = ctl_after_it0_body(sh);
+  return nx == CTL_LM_NEXT ? ctl_lm_next_body(sh) : nx;
+}
+__device__ __noinline__ int ctl_after_candidate(LRegShared* sh) {
+  const int nx = ctl_after_candidate_body(sh);
+  return nx == CTL_LM_NEXT ? ctl_lm_next_body(sh) : nx;
 }
 
 __device__ __noinline__ int ctl_after_cov(LRegShared* sh) {
