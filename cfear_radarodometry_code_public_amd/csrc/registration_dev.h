@@ -850,6 +850,7 @@ __device__ __noinline__ void ctl_publish_build(LRegShared* sh, bool first) {
   }
   io.par[L] = sh->xcur[0]; io.par[L + 1] = sh->xcur[1]; io.par[L + 2] = sh->xcur[2];
   sh->x[0] = sh->xcur[0]; sh->x[1] = sh->xcur[1]; sh->x[2] = sh->xcur[2];
+  sh->c = Tsrc.l0; sh->s = Tsrc.l2;  // the build command ends with the evaluation at x (the LM's iteration 0)
   sh->cmd = REG_CMD_BUILD; sh->state = REG_ST_BUILD;
 }
 
@@ -907,7 +908,7 @@ __device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNo
 // The state functions are leaves (no call inside: a function that calls another one saves and restores a register through
 // scratch, a round trip to memory on the controller's serial chain at every exit) and return what has to happen next;
 // ctl_step, inlined into the kernel, chains them.
-enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND };
+enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND, CTL_IT0 };
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
 __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
@@ -1027,8 +1028,7 @@ __device__ __noinline__ int ctl_after_build(LRegShared* sh) {
     return CTL_FINISH_NONE;
   }
   if (sh->prior_on) sh->nres += 3;  // the prior block joins after the residual-count check (:370-377)
-  ctl_publish_eval_cur(sh, REG_ST_LM_IT0);
-  return CTL_WAIT;
+  return CTL_IT0;  // the waves evaluated the new problem at x right after building it (register_block): no command of its own
 }
 
 __device__ __forceinline__ int ctl_after_it0_body(LRegShared* sh) {
@@ -1107,7 +1107,7 @@ __device__ __forceinline__ void ctl_step(LRegShared* sh, long long* acc = nullpt
   long long t0 = 0;
   if (acc) t0 = (long long)wall_clock64();
   switch (sh->state) {
-    case REG_ST_BUILD: nx = ctl_after_build(sh); break;
+    case REG_ST_BUILD: nx = ctl_after_build(sh); if (nx == CTL_IT0) nx = ctl_after_it0(sh); break;
     case REG_ST_LM_IT0: nx = ctl_after_it0(sh); break;
     case REG_ST_LM_CAND: nx = ctl_after_candidate(sh); break;
     default: nx = ctl_after_cov(sh); break;
@@ -1206,6 +1206,10 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       if (pt) pt->mark();
       const int M = build_problem_block(scans, n, ls, ls->itr);
       if (tid == 0) ls->M = M;
+      // the first evaluation of the solve that follows, at the pose the problem was built for: straight away instead of as a
+      // command of its own (a barrier pair and a turn of the controller less per outer iteration); block-uniform condition,
+      // the same as ctl_after_build's
+      if (M * ((ls->rp.cost == CFEAR_COST_P2L) ? 1 : 2) > 1) evaluate_partial(ls, M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
       if (pt) pt->mark();
     } else {
       evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
