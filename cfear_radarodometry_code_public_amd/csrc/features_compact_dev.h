@@ -55,6 +55,9 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   g_f64* const g_part = (g_f64*)W.part;
   typedef __attribute__((address_space(1))) f32x2 g_f32x2;
   g_f32x2* const g_cen = (g_f32x2*)W.samples;  // voxel centroids (8-byte aligned: the scratch arrays start on 256 B)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+  g_u32x4* const g_rng = (g_u32x4*)W.rng;  // candidate ranges of a sample's window rows (16 bytes per sample)
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ccap = min(CFEAR_CPT_CAP, W.cap);  // points / chunk records the arrays (LDS and the global partial sums) hold
   if (n <= 0 || n > ccap || PR.rounds <= 0) return false;  // block-uniform
@@ -215,12 +218,20 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   auto centroid = [&](int v, float& cx, float& cy) {
     const int a = (int)vst[v], b = (int)vst[v + 1];
     float sx = 0.f, sy = 0.f;
-    for (int q = a; q < b; q += 4) {  // four loads in flight, added in point order
+    int q = a;
+    for (; q + 4 <= b; q += 4) {  // whole groups of four: four loads in flight, added in point order, nothing to mask
       f32x2 p[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) p[u] = pxy[min(q + u, b - 1)];
+      for (int u = 0; u < 4; u++) p[u] = pxy[q + u];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const bool on = q + u < b; sx = on ? sx + p[u].x : sx; sy = on ? sy + p[u].y : sy; }
+      for (int u = 0; u < 4; u++) { sx += p[u].x; sy += p[u].y; }
+    }
+    {  // the last one to three points
+      f32x2 p[3];
+#pragma unroll
+      for (int u = 0; u < 3; u++) p[u] = pxy[min(q + u, b - 1)];
+#pragma unroll
+      for (int u = 0; u < 3; u++) { const bool on = q + u < b; sx = on ? sx + p[u].x : sx; sy = on ? sy + p[u].y : sy; }
     }
     const float cnt = (float)(b - a);
     cx = sx / cnt; cy = sy / cnt;
@@ -270,11 +281,16 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       g_cen[v] = f32x2{cx, cy};  // computed once: the chunks and the epilogue read it back (a dense voxel has ~100 members and ~30 chunks)
       const Win w = window(cx, cy);
       int tot = 0;
+      u32x4 rec = {0xFFFFFFFFu, 0u, 0u, 0u};  // the candidate ranges of a window of up to four voxel rows, for the sample's chunk lanes
       for (int gy = w.gy0; gy <= w.gy1; gy += 4) {
         int a[4], b[4];
         row_ranges4(w, gy, a, b);
         tot += (b[0] - a[0]) + (b[1] - a[1]) + (b[2] - a[2]) + (b[3] - a[3]);
+        if (gy == w.gy0 && w.gy1 - w.gy0 < 4)
+          rec = u32x4{(unsigned)a[0] | ((unsigned)b[0] << 16), (unsigned)a[1] | ((unsigned)b[1] << 16), (unsigned)a[2] | ((unsigned)b[2] << 16),
+                      (unsigned)a[3] | ((unsigned)b[3] << 16)};
       }
+      g_rng[v] = rec;
       ord[v] = (unsigned short)(tot >= 6 ? tot : 0);  // fewer than six candidates can never make a cell (pointnormal.cpp:291)
     }
     if (pt) pt->mark();
@@ -310,21 +326,33 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   // sample) then add their partial moments together with row shifts, and only the first lane of such a run stores: a dense
   // sample has ~30 chunks, and the epilogue's walk over them - a dependent memory round trip each - was its long pole.
   f32x2 cen_next = g_cen[tid < NC ? (int)chk[tid] : 0];
+  u32x4 rec_next = g_rng[tid < NC ? (int)chk[tid] : 0];
   for (int wb = 0; wb < NC; wb += nt) {  // wave-uniform trip count: every lane takes part in the row shifts
     const int wq = wb + tid;
     const bool act = wq < NC;
     const int v = (int)chk[act ? wq : 0];
     const int j = wq - (int)ord[v];
     const float cx = cen_next.x, cy = cen_next.y;
-    cen_next = g_cen[wq + nt < NC ? (int)chk[wq + nt] : 0];  // the next chunk's centroid is on its way while this one is summed
-    const Win win = window(cx, cy);
+    const u32x4 rec = rec_next;
+    {  // the next chunk's centroid and candidate ranges are on their way while this one is summed
+      const int vn = wq + nt < NC ? (int)chk[wq + nt] : 0;
+      cen_next = g_cen[vn]; rec_next = g_rng[vn];
+    }
+    const bool stored = rec.x != 0xFFFFFFFFu;  // (a range never ends at 65535: at most CFEAR_CPT_CAP points)
+    Win win = {0, 0, 0, 0};
+    if (!stored) win = window(cx, cy);  // more than four voxel rows (leaf < radius): the ranges are looked up again
     int skip = j * C, left = act ? C : 0;
     int m = 0;
     double s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
     const double cxd = (double)cx, cyd = (double)cy;
     for (int gy4 = win.gy0; gy4 <= win.gy1 && left > 0; gy4 += 4) {
      int ra[4], rb[4];
-     row_ranges4(win, gy4, ra, rb);
+     if (stored) {
+       ra[0] = (int)(rec.x & 0xFFFFu); rb[0] = (int)(rec.x >> 16); ra[1] = (int)(rec.y & 0xFFFFu); rb[1] = (int)(rec.y >> 16);
+       ra[2] = (int)(rec.z & 0xFFFFu); rb[2] = (int)(rec.z >> 16); ra[3] = (int)(rec.w & 0xFFFFu); rb[3] = (int)(rec.w >> 16);
+     } else {
+       row_ranges4(win, gy4, ra, rb);
+     }
 #pragma unroll
      for (int u = 0; u < 4; u++) {
       const int a = ra[u], b = rb[u];
