@@ -831,12 +831,13 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
 // what the 1-NN search needs from a scan (the registration keeps one per keyframe in LDS: no pointer chasing)
 struct GridView {
   const int* gs; const float4* gp; const double* rtar;
-  float gminx, gminy, gcell;
+  double igc;  // 1 / bucket size, in double: the queries divide by it (a full division per query and keyframe otherwise)
+  float gminx, gminy;
   int gw, gh, n_cells;
 };
 __device__ __forceinline__ GridView grid_view(const ScanDev* S) {
   GridView G;
-  G.gs = S->gstart; G.gp = S->gpts; G.rtar = S->rtar; G.gminx = S->gminx; G.gminy = S->gminy; G.gcell = S->gcell;
+  G.gs = S->gstart; G.gp = S->gpts; G.rtar = S->rtar; G.gminx = S->gminx; G.gminy = S->gminy; G.igc = 1.0 / (double)S->gcell;
   G.gw = S->gw; G.gh = S->gh; G.n_cells = S->n_cells;
   return G;
 }
@@ -847,7 +848,7 @@ __device__ inline int scan_closest(const GridView& S, double px, double py, doub
   const double m = d * (1.0 + 1e-6) + 1e-6;
   // one reciprocal instead of four divisions: the window is padded by m - d >= 1e-6, an ulp in the bucket coordinate
   // cannot uncover anything within d of the query
-  const double igc = 1.0 / (double)S.gcell, gmx = (double)S.gminx, gmy = (double)S.gminy;
+  const double igc = S.igc, gmx = (double)S.gminx, gmy = (double)S.gminy;
   int gx0 = (int)floor(((double)qx - m - gmx) * igc), gx1 = (int)floor(((double)qx + m - gmx) * igc);
   int gy0 = (int)floor(((double)qy - m - gmy) * igc), gy1 = (int)floor(((double)qy + m - gmy) * igc);
   // the builder clamps bucket coordinates, so clamp the query window the same way

@@ -62,7 +62,17 @@ __device__ inline void aff_to_xyt(const Aff2& T, double v[3]) {  // Affine3dToVe
 }
 __device__ inline Aff2 aff_identity() { Aff2 T; T.l0 = 1; T.l1 = 0; T.l2 = 0; T.l3 = 1; T.t0 = 0; T.t1 = 0; return T; }
 
-__device__ inline double similarity(double x, double y) { return 2 * fmin(x, y) / (x + y); }  // registration.h:96
+// quotient of well-scaled positive numbers (sample counts >= 6, planarity scales >= log 1.5): hardware reciprocal, two Newton
+// steps, one residual correction - the quotient without the scaling / special-case handling of a full IEEE division (a third
+// of its instructions; two of these per residual block); agrees with it to an ulp
+__device__ __forceinline__ double div_well_scaled(double num, double den) {
+  double r = __builtin_amdgcn_rcp(den);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  const double q = num * r;
+  return __builtin_fma(__builtin_fma(-den, q, num), r, q);
+}
+__device__ inline double similarity(double x, double y) { return div_well_scaled(2 * fmin(x, y), x + y); }  // registration.h:96
 __device__ inline double get_weight(int opt, double n1, double n2, double sim, double p1, double p2) {  // registration.cpp:67-76
   switch (opt) {
     case 0: return 1.0;
@@ -179,9 +189,9 @@ __device__ __forceinline__ void neq_store(LNormalEq* p, const NormalEq& e) {
 #define CFEAR_GENERIC(T, lvalue) (*(T*)&(lvalue))  // generic-address-space view of an LDS object (for by-reference parameters)
 
 // ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
-// 630 matches x 64 B + the rest of the registration kernels' LDS <= 53,760 B: three workgroups per compute unit need
+// 622 matches x 64 B + the rest of the registration kernels' LDS <= 53,760 B: three workgroups per compute unit need
 // <= 53,760 B each (LDS is handed out in 1,280-byte granules; 53,824 B already drops the kernel to two per CU and +34 % time)
-#define CFEAR_MATCH_LDS_CAP 630
+#define CFEAR_MATCH_LDS_CAP 622
 struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
 __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   MatchPtrs m;
@@ -541,7 +551,7 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegS
     qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
     qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
     const int gw = sh->kf[i].gw, gh = sh->kf[i].gh, nc = sh->kf[i].n_cells;
-    const double igc = 1.0 / (double)sh->kf[i].gcell, gmx = (double)sh->kf[i].gminx, gmy = (double)sh->kf[i].gminy;
+    const double igc = sh->kf[i].igc, gmx = (double)sh->kf[i].gminx, gmy = (double)sh->kf[i].gminy;
     int ax0 = (int)floor(((double)qx[u] - m - gmx) * igc), ax1 = (int)floor(((double)qx[u] + m - gmx) * igc);
     int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
     ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
