@@ -270,7 +270,11 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int cc = min(j * 64 + lane, c_hi - 1);
-        v[j] = *reinterpret_cast<const uint4*>(wp + (uint32_t)(16 * cc));
+        {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (uint32_t)(16 * cc)));
+          v[j] = make_uint4(t.x, t.y, t.z, t.w);
+        }
       }
 #pragma unroll
       for (int j = 0; j < NCH; j++) reinterpret_cast<uint4*>(win)[j * 64 + lane] = v[j];
