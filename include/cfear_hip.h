@@ -262,7 +262,8 @@ int cfear_odometry_profile_read_stages(cfear_ctx* ctx, cfear_odometry* odo, doub
  * workgroup-time percentiles use; enable = 4: timed instantiations, and slots 0..7 hold - instead of the first feature
  * stamps - the breakdown of the registration's command loop over its evaluation commands: ticks waiting at the command
  * barrier, executing the command, waiting at the result barrier, the command count, ticks in the controller's state
- * function, trust-region step, publishing function and end-of-solve function); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
+ * function (which includes the trust-region step that follows it), in trust-region steps taken on their own, in the
+ * publishing function and in the end-of-solve function); with host_ticks != NULL the [n_sequences][32] table of the steps since the last read is
  * copied out (synchronises) and cleared. enable = 0 frees the table: back to the production kernels. */
 int cfear_odometry_phase_times(cfear_ctx* ctx, cfear_odometry* odo, int enable, long long* host_ticks);
 

@@ -442,6 +442,42 @@ def test_profile_hooks_time_every_stage(oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["detailed", "light", "workgroups", "controller"])
+def test_phase_time_modes_leave_the_results_alone(oracle, mode):
+    """cfear_odometry_phase_times: the timed instantiations of the features / registration kernels (per-phase clock stamps, the
+    command-loop breakdown) and the workgroup stamps of the production kernels give the poses of an untimed run, stamps that
+    increase along a kernel, and - in the controller mode - positive accumulators for every part of the command loop."""
+    imgs, _ = synth.world_sequence(5, seed=23)
+    ctx = capi.Context(mk_params(capi), 400, 3360)
+    odo, ref = ctx.odometry(3), ctx.odometry(3)
+    batch = lambda t: np.stack([imgs[t]] * 3)
+    odo.step_host(batch(0)); ref.step_host(batch(0))
+    odo.phase_times(None, light=mode == "light", workgroups_only=mode == "workgroups", controller=mode == "controller")
+    for t in range(1, 5):
+        odo.step_host(batch(t)); ref.step_host(batch(t))
+        ticks = odo.phase_times(True)
+        assert ticks.shape == (3, 32)
+        for q in range(3):
+            if mode == "workgroups":
+                assert 0 < ticks[q, 0] < ticks[q, 1] <= ticks[q, 14] < ticks[q, 15]  # features start / end, registration start / end
+            else:
+                reg = ticks[q, 14:29]; reg = reg[reg > 0]
+                assert len(reg) >= 4 and np.all(np.diff(reg) >= 0)
+                if mode == "controller":
+                    assert ticks[q, 3] >= 1 and np.all(ticks[q, [1, 4, 6]] > 0)  # commands; evaluation, state function (+ step), publish
+                else:
+                    feat = ticks[q, :14]; feat = feat[feat > 0]
+                    assert len(feat) >= 8 and np.all(np.diff(feat) >= 0)
+                if mode == "detailed":
+                    assert ticks[q, 31] >= 1 and ticks[q, 29] > 0 and ticks[q, 30] > 0
+    assert np.array_equal(odo.poses(), ref.poses())
+    odo.phase_times(False)
+    odo.step_host(batch(4)); ref.step_host(batch(4))
+    assert np.array_equal(odo.poses(), ref.poses())
+    odo.release(); ref.release()
+    ctx.close()
+
+
 def test_many_resident_sequences_are_independent_and_deterministic(oracle):
     """768 resident sequences (three registration workgroups on every compute unit) replaying 4 different sweeps streams:
     every replica of a stream ends bit-identical to the others, whatever workgroup slot and neighbours it had, and

@@ -19,8 +19,8 @@ for t in range(frames):
     if t >= 13:
         a = buf[:, :8].astype(np.float64) / 100.0  # us
         n = np.maximum(a[:, 3], 1)
-        names = ["wait at command barrier", "command (evaluation) in wave 0", "wait at result barrier", "commands", "state function (gather + decide)",
-                 "ctl_lm_next", "publish (candidate / build / finish)", "ctl_lm_done"]
+        names = ["wait at command barrier", "command (evaluation) in wave 0", "wait at result barrier", "commands", "state function (gather + decide + step)",
+                 "trust-region steps on their own", "publish (candidate / build / finish)", "ctl_lm_done"]
         print("frame %d: evaluation commands per registration: median %d" % (t, np.median(a[:, 3] * 100)))
         for i in (0, 1, 2, 4, 5, 6, 7):
             print("   %-40s total %.1f us   per command %.2f us" % (names[i], np.median(a[:, i]), np.median(a[:, i] / (a[:, 3] * 100).clip(1))))
