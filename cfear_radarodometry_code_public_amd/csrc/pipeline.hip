@@ -782,6 +782,9 @@ static int register_impl(cfear_ctx* ctx, cfear_scan* const* scans, int n, double
   for (int i = 0; i < n; i++) h_ptrs[i] = reinterpret_cast<ScanDev*>(scans[i]->d_block);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+  // a registration that fails does not touch the caller's covariance (reg_cov of n_scan_normal_reg::Register, n_scan_normal.cpp:82-187):
+  // the device copy starts as the caller's matrix, so that what comes back is the caller's matrix (not the previous call's result)
+  if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_cov, cov6_last, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
   const RegParams P = reg_params(ctx);
   double* d_prior = nullptr;
   if (prior_cov6) {  // staged behind the summary, in the tail of the context scratch

@@ -415,7 +415,7 @@ class n_scan_normal_reg {
     ScopedParams sp(dev, my_params(dev));  // this object's cost / loss / weights, for this call only
     std::vector<cfear_scan*> h(n); std::vector<double> poses(3 * n);
     for (size_t i = 0; i < n; i++) { h[i] = scans[i]->handle(); poses[3 * i] = cfear_tx(Tsrc[i]); poses[3 * i + 1] = cfear_ty(Tsrc[i]); poses[3 * i + 2] = cfear_yaw(Tsrc[i]); }
-    double cov[36];
+    double cov[36] = {0};  // (in/out at the C ABI: left as passed when no usable solution comes back)
     if (soft_constraints) {  // :373-377: prior from reg_cov.back() as passed in
       double prior[36];
       for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) prior[6 * a + b] = reg_cov.back()(a, b);

@@ -188,7 +188,8 @@ typedef struct cfear_reg_summary {
 /* bool Register(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc,
  *               std::vector<Matrix6d>& reg_cov, bool soft_constraints=false)
  * (n_scan_normal.cpp:82-187). scans[0..n-2] keyframes (fixed), scans[n-1] current.
- * poses_xyt: n x (x, y, theta) in/out; cov6_last: 36 doubles row-major = reg_cov.back().
+ * poses_xyt: n x (x, y, theta) in/out; cov6_last: 36 doubles row-major = reg_cov.back(), in/out: a registration that
+ * does not produce a usable solution leaves it as passed in, as the reference leaves reg_cov.
  * Returns CFEAR_OK; the reference's bool is summary->success. */
 int cfear_register(cfear_ctx* ctx, cfear_scan* const* scans, int n, double* poses_xyt, double* cov6_last,
                    cfear_reg_summary* summary);
