@@ -345,14 +345,41 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     int m = 0;
     double s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
     const double cxd = (double)cx, cyd = (double)cy;
-    for (int gy4 = win.gy0; gy4 <= win.gy1 && left > 0; gy4 += 4) {
+    // one candidate: branch-free - outside the radius (or past the chunk) it enters with weight 0: adding zeros leaves the sums
+    // bit-identical, and the lanes of a wave hold different candidates anyway, so a branch would run its body for almost every trip
+    auto add = [&](const f32x2 p, int iw, bool on) {
+      const float dx = cx - p.x, dy = cy - p.y;
+      float d2 = dx * dx; d2 += dy * dy;
+      const bool in = on & (d2 < r2);  // pointnormal.cpp:291 radius test (float, strict)
+      const double w = in ? (double)iw : 0.0;  // the weight byte staged with the point (:15)
+      const double ex = (double)p.x - cxd, ey = (double)p.y - cyd;
+      const double wex = w * ex, wey = w * ey;
+      m += in ? 1 : 0; s0 += w; s1x += wex; s1y += wey;
+      sxx = __builtin_fma(wex, ex, sxx); sxy = __builtin_fma(wex, ey, sxy); syy = __builtin_fma(wey, ey, syy);
+    };
+    if (stored) {
+      // the sample's candidates numbered 0 .. tot - 1 through its (up to four) row ranges: candidate t of row u sits at t + off[u].
+      // The chunk takes its 16 in four full trips, whatever the rows look like (row by row, ragged ends cost a trip each and
+      // the lanes of a wave wait for the chunk with the most of them)
+      const int a0 = (int)(rec.x & 0xFFFFu), a1 = (int)(rec.y & 0xFFFFu), a2 = (int)(rec.z & 0xFFFFu), a3 = (int)(rec.w & 0xFFFFu);
+      const int p1 = (int)(rec.x >> 16) - a0, p2 = p1 + (int)(rec.y >> 16) - a1, p3 = p2 + (int)(rec.z >> 16) - a2, tot = p3 + (int)(rec.w >> 16) - a3;
+      const int o1 = a1 - p1, o2 = a2 - p2, o3 = a3 - p3;
+      const int t0 = act ? skip : 0, t1 = act ? min(skip + C, tot) : 0;
+      for (int t = t0; t < t1; t += 4) {
+        f32x2 p[4]; int iw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // independent LDS loads first
+          const int tt = min(t + u, t1 - 1);
+          const int qq = tt + (tt < p1 ? a0 : (tt < p2 ? o1 : (tt < p3 ? o2 : o3)));
+          p[u] = pxy[qq]; iw[u] = (int)pw[qq];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) add(p[u], iw[u], t + u < t1);
+      }
+    } else
+    for (int gy4 = win.gy0; gy4 <= win.gy1 && left > 0; gy4 += 4) {  // more than four voxel rows: row by row
      int ra[4], rb[4];
-     if (stored) {
-       ra[0] = (int)(rec.x & 0xFFFFu); rb[0] = (int)(rec.x >> 16); ra[1] = (int)(rec.y & 0xFFFFu); rb[1] = (int)(rec.y >> 16);
-       ra[2] = (int)(rec.z & 0xFFFFu); rb[2] = (int)(rec.z >> 16); ra[3] = (int)(rec.w & 0xFFFFu); rb[3] = (int)(rec.w >> 16);
-     } else {
-       row_ranges4(win, gy4, ra, rb);
-     }
+     row_ranges4(win, gy4, ra, rb);
 #pragma unroll
      for (int u = 0; u < 4; u++) {
       const int a = ra[u], b = rb[u];
@@ -365,16 +392,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int qq = min(q + u, e - 1); p[u] = pxy[qq]; iw[u] = (int)pw[qq]; }  // independent LDS loads first
 #pragma unroll
-        for (int u = 0; u < 4; u++) {  // branch-free: a candidate outside the radius (or past the chunk) enters with weight 0 - adding
-          const float dx = cx - p[u].x, dy = cy - p[u].y;  // zeros leaves the sums bit-identical, and the lanes of a wave hold different
-          float d2 = dx * dx; d2 += dy * dy;               // candidates anyway, so a branch would run its body for almost every trip
-          const bool in = (q + u < e) & (d2 < r2);  // pointnormal.cpp:291 radius test (float, strict)
-          const double w = in ? (double)iw[u] : 0.0;  // the weight byte staged with the point (:15)
-          const double ex = (double)p[u].x - cxd, ey = (double)p[u].y - cyd;
-          const double wex = w * ex, wey = w * ey;
-          m += in ? 1 : 0; s0 += w; s1x += wex; s1y += wey;
-          sxx = __builtin_fma(wex, ex, sxx); sxy = __builtin_fma(wex, ey, sxy); syy = __builtin_fma(wey, ey, syy);
-        }
+        for (int u = 0; u < 4; u++) add(p[u], iw[u], q + u < e);
       }
       left -= e - s; skip = 0;
      }
