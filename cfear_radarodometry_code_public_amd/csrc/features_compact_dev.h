@@ -12,6 +12,8 @@
 //  * a sample's centroid and candidate row ranges are recomputed by whoever needs them (a few LDS reads) instead of being
 //    stored per sample.
 #pragma once
+#include <type_traits>
+
 #include "features_dev.h"
 
 namespace cfear_dev {
@@ -126,7 +128,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     int ex = block_exclusive_scan_1b(cnt, W.red_i, 0, &nv);  // (one-barrier scans: a barrier separates each from the one before)
     for (int w = w0; w < w1; w++) { bmp[w] = (unsigned short)ex; ex += __popc(bm[w]); }
     VS = (nv + 2) & ~1;  // counters per set (even: a set starts on a word)
-    NS = (nwv * VS <= (int)(CFEAR_CPT_CAP * 8 / 2)) ? nwv : 1;
+    NS = (nwv == 8 && 8 * VS <= (int)(CFEAR_CPT_CAP * 8 / 2)) ? 8 : 1;
     for (int i = tid; i < NS * VS / 2; i += nt) cw[i] = 0u;
   }
   __syncthreads();
@@ -143,20 +145,40 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     }
   }
   __syncthreads();
-  {  // voxel starts (vst[c], vst[nv] = n); a counter becomes the first slot its wave may hand out in that voxel
-    const int ipt = (nv + nt - 1) / nt;
-    const int g0 = tid * ipt, g1 = min(nv, g0 + ipt);
-    int cnt = 0;
-    for (int g = g0; g < g1; g++)
-      for (int q = 0; q < NS; q++) cnt += (int)cw16[q * VS + g];
-    int tot;
-    int o = block_exclusive_scan_1b(cnt, W.red_i, 0, &tot);
-    for (int g = g0; g < g1; g++) {
-      vst[g] = (unsigned short)o;
-      for (int q = 0; q < NS; q++) { const int c = (int)cw16[q * VS + g]; cw16[q * VS + g] = (unsigned short)o; o += c; }
-    }
+  {  // voxel starts (vst[c], vst[nv] = n); a counter becomes the first slot its wave may hand out in that voxel. Two voxels
+     // (one 32-bit word of every set) at a time, the sets' words in registers.
+    l_u32* const vstw = (l_u32*)(lds + FeatLdsC::vst);
+    const int nwords = (nv + 1) >> 1;  // words that hold a voxel
+    const int wpt = (nwords + nt - 1) / nt;
+    const int w0 = tid * wpt, w1 = min(nwords, w0 + wpt);
+    auto starts = [&](auto nsc) {
+      constexpr int NSC = decltype(nsc)::value;
+      const int VW = VS >> 1;  // words per set
+      int cnt = 0;
+      for (int w = w0; w < w1; w++) {
+#pragma unroll
+        for (int q = 0; q < NSC; q++) { const unsigned c = cw[q * VW + w]; cnt += (int)(c & 0xFFFFu) + (int)(c >> 16); }
+      }
+      int tot;
+      int o = block_exclusive_scan_1b(cnt, W.red_i, 0, &tot);
+      for (int w = w0; w < w1; w++) {
+        unsigned c[NSC];
+        int sum_lo = 0;
+#pragma unroll
+        for (int q = 0; q < NSC; q++) { c[q] = cw[q * VW + w]; sum_lo += (int)(c[q] & 0xFFFFu); }
+        int olo = o, ohi = o + sum_lo;
+        vstw[w] = (unsigned)olo | ((unsigned)ohi << 16);
+#pragma unroll
+        for (int q = 0; q < NSC; q++) {
+          cw[q * VW + w] = (unsigned)olo | ((unsigned)ohi << 16);
+          olo += (int)(c[q] & 0xFFFFu); ohi += (int)(c[q] >> 16);
+        }
+        o = ohi;
+      }
+    };
+    if (NS == 8) starts(std::integral_constant<int, 8>{}); else starts(std::integral_constant<int, 1>{});
+    __syncthreads();  // (the starts are complete before vst[nv] is set: for an odd nv it is the high half of the last word, holding n already)
     if (tid == 0) { vst[nv] = (unsigned short)n; S->n_samples = nv; S->n_points = n; S->status = 0; }
-    __syncthreads();
   }
   int pos[PT];
 #pragma unroll
