@@ -474,9 +474,10 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         if (m >= 6) {  // :291
           const f32x2 cen = g_cen[v];
           const float cx = cen.x, cy = cen.y;
-          const double m1x = s1x / s0, m1y = s1y / s0;
+          const double is0 = 1.0 / s0;  // one division for the five quotients by the weight sum (an ulp or two away from five divisions)
+          const double m1x = s1x * is0, m1y = s1y * is0;
           const double ux = (double)cx + m1x, uy = (double)cy + m1y;
-          const double cxx = sxx / s0 - m1x * m1x, cyx = sxy / s0 - m1x * m1y, cyy = syy / s0 - m1y * m1y;
+          const double cxx = sxx * is0 - m1x * m1x, cyx = sxy * is0 - m1x * m1y, cyy = syy * is0 - m1y * m1y;
           double lmin, lmax, vmin[2], vmax[2];
           eig2(cxx, cyx, cyy, &lmin, &lmax, vmin, vmax);
           const double cond = fabs(lmax / lmin);  // :53

@@ -305,7 +305,11 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       const int o = preg_idx_from_ballots(PR, r);
       PR.x[r] = x; PR.y[r] = y; PR.wi[r] = (int)CFEAR_SLOT_INTENSITY(s) | (o << 8);
       if (on) {
-        g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
+        {  // one 12-byte store
+          typedef float f32x3 __attribute__((ext_vector_type(3)));
+          typedef f32x3 __attribute__((aligned(4))) f32x3u;
+          *(__attribute__((address_space(1))) f32x3u*)(g_xyi + 3 * o) = f32x3{x, y, (float)CFEAR_SLOT_INTENSITY(s)};
+        }
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       }
     }
