@@ -509,24 +509,26 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
   else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, Trel, Ttar, cs, ct, ctf);
 }
 
-// ---- association of one source cell against up to four keyframes at once ------------------------------------
+// ---- association of one source cell against up to four keyframes ------------------------------------------------
 // A pair's search is a chain of dependent memory round trips (source cell -> bucket bounds -> candidates -> target
-// normal), about 1 us each from L2; pair after pair that chain was the whole cost of the association. Here the four
-// chains of a source cell advance together: all bucket bounds in one round trip, candidates two per keyframe per
-// round trip, the four gate normals in one. Same results as scan_closest + the gate of associate_pair.
+// normal), about 1 us each; pair after pair that chain was the whole cost of the association.
 struct Assoc4 { int t0, t1, t2, t3; };
 __device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0 ? a.t0 : (i == 1 ? a.t1 : (i == 2 ? a.t2 : a.t3)); }
 
-// keyframes i0 .. i0 + NI - 1 (those below nk) of source cell j; NC candidates per keyframe per round trip.
-// ti[u] = matched target cell of keyframe i0 + u or -1.
-template <int NI, int NC>
-__device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegShared* sh, int nk, int i0, int j, double curr_radius, int* ti) {
-  // Branch-free with clamped addresses and global-typed pointers: every load of a phase is issued unconditionally (a
-  // keyframe that does not exist, an empty window or a candidate past the end reads a valid dummy address and is masked
-  // afterwards), so that the loads of the NI keyframes are in flight together - with the loads inside conditionals the
-  // compiler waited for one keyframe's data before it issued the next one's, and generic pointers made them flat loads
-  // that also wait for the LDS counter. Round trips per call: source cell, bucket bounds, candidates (NC per keyframe per
-  // trip), gate normals.
+// All (up to four) keyframes of a source cell in one call, staged: the source cell (one round trip), the bucket bounds of
+// ALL keyframes (one), then keyframes 0, 1: candidates (NC per keyframe and trip) and their gate normals - whose round trip
+// overlaps the first candidate trip of keyframes 2, 3 - then those. About three round trips less per source cell than a
+// two-keyframe search called twice (source cell, bucket bounds, a gate), with the register footprint of a two-keyframe search
+// plus the parked bounds of the second pair (all four keyframes side by side did not fit the registers). Same results as
+// scan_closest + the gate of associate_pair.
+// Branch-free with clamped addresses and global-typed pointers: every load of a phase is issued unconditionally (a keyframe
+// that does not exist, an empty window or a candidate past the end reads a valid dummy address and is masked afterwards), so
+// that the loads of a phase are in flight together - with the loads inside conditionals the compiler waited for one keyframe's
+// data before it issued the next one's, and generic pointers made them flat loads that also wait for the LDS counter. The
+// candidate update uses selects and non-short-circuit predicates: a load whose only use sits in a conditional block gets sunk
+// into it and waited for alone. Returns the four matches 16 bits each (0xFFFF = none, 0xFFFE = left to
+// the caller), which needs <= 65533 cells per keyframe (else that keyframe is left to the caller).
+__device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh, int nk, int j, double curr_radius) {
   typedef __attribute__((address_space(1))) const double g_cf64;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) const u32x2 g_cu32x2;
@@ -534,19 +536,19 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegS
   typedef __attribute__((address_space(1))) const f32x4 g_cf32x4;
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) const f64x2 g_cf64x2;
-  (void)src;
+  constexpr int NC = 4;
   const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
   const size_t cc = (size_t)sh->scc;
   g_cf64* rs = (g_cf64*)sh->srs + j;
-  const double mx = rs[0], my = rs[cc], snx = rs[2 * cc], sny = rs[3 * cc];  // mean and normal of the source cell: one round trip
+  const double mx = rs[0], my = rs[cc], snx = rs[2 * cc], sny = rs[3 * cc];
   const double m = curr_radius * (1.0 + 1e-6) + 1e-6;  // window padding of scan_closest
-  float qx[NI], qy[NI];
-  int nrows[NI], wide = 0, kf[NI];
-  u32x2 L[NI], H[NI];
+  float qx[4], qy[4];
+  int nrows[4];
+  unsigned wide = 0;
+  u32x2 L[4], H[4];
 #pragma unroll
-  for (int u = 0; u < NI; u++) {
-    const int i = min(i0 + u, nk - 1);  // a keyframe past the last one repeats the last one and is dropped at the end
-    kf[u] = i;
+  for (int u = 0; u < 4; u++) {  // windows and bucket bounds of all keyframes: one round trip
+    const int i = min(u, nk - 1);
     const auto* T = sh->Trel[i];
     qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
     qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
@@ -555,89 +557,103 @@ __device__ __forceinline__ void associate_cell_t(const ScanDev* src, const LRegS
     int ax0 = (int)floor(((double)qx[u] - m - gmx) * igc), ax1 = (int)floor(((double)qx[u] + m - gmx) * igc);
     int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
     ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
-    const bool ok = (i0 + u < nk) && nc > 0 && gw > 0 && ax0 <= ax1 && ay0 <= ay1;
-    // more than three rows of buckets (a query within rounding of a bucket edge), or offsets beyond 16 bits: left to the caller
-    const bool wd = ok && (ay1 - ay0 > 2 || nc > 0xFFFF);
-    wide |= wd ? (1 << u) : 0;
+    const bool ok = (u < nk) && nc > 0 && gw > 0 && ax0 <= ax1 && ay0 <= ay1;
+    const bool wd = ok && (ay1 - ay0 > 2 || nc > 0xFFF0);  // more than three rows of buckets, or indices beyond the packing: the caller's
+    wide |= wd ? (1u << u) : 0u;
     const bool use = ok && !wd;
     nrows[u] = use ? ay1 - ay0 + 1 : 0;
     const int b0 = use ? ay0 * gw + ax0 : 0, b1 = use ? ay0 * gw + ax1 + 1 : 0;
-    g_cu32x2* g3 = (g_cu32x2*)grid_rows3(sh->kf[i].gs);  // bucket bounds of the window's rows: two 8-byte records (features_dev.h)
+    g_cu32x2* g3 = (g_cu32x2*)grid_rows3(sh->kf[i].gs);
     L[u] = g3[b0]; H[u] = g3[b1];
   }
-  int lo[NI][3], cnt[NI][2], tot[NI], kmax = 0;  // candidates of rows 0, 0..1 and of the whole window
+  int ti[4];
+  f64x2 tn[2];
+  auto search = [&](int u0) {  // keyframes u0, u0 + 1: nearest candidate of each
+    int lo[2][3], cnt[2][2], tot[2], kmax = 0;
 #pragma unroll
-  for (int u = 0; u < NI; u++) {
-    const int l0 = (int)(L[u].x & 0xFFFFu), l1 = (int)(L[u].x >> 16), l2 = (int)L[u].y;
-    const int h0 = (int)(H[u].x & 0xFFFFu), h1 = (int)(H[u].x >> 16), h2 = (int)H[u].y;
-    const int c0 = (0 < nrows[u]) ? h0 - l0 : 0;
-    const int c1 = (1 < nrows[u]) ? h1 - l1 : 0;
-    const int c2 = (2 < nrows[u]) ? h2 - l2 : 0;
-    cnt[u][0] = c0; cnt[u][1] = c0 + c1; tot[u] = c0 + c1 + c2;
-    lo[u][0] = l0; lo[u][1] = l1 - c0; lo[u][2] = l2 - (c0 + c1);  // candidate kk of row r sits at lo[r] + kk
-    kmax = max(kmax, tot[u]);
-  }
-  int best[NI];
-  float bd[NI];
+    for (int v = 0; v < 2; v++) {
+      const int u = u0 + v;
+      const int l0 = (int)(L[u].x & 0xFFFFu), l1 = (int)(L[u].x >> 16), l2 = (int)L[u].y;
+      const int h0 = (int)(H[u].x & 0xFFFFu), h1 = (int)(H[u].x >> 16), h2 = (int)H[u].y;
+      const int c0 = (0 < nrows[u]) ? h0 - l0 : 0;
+      const int c1 = (1 < nrows[u]) ? h1 - l1 : 0;
+      const int c2 = (2 < nrows[u]) ? h2 - l2 : 0;
+      cnt[v][0] = c0; cnt[v][1] = c0 + c1; tot[v] = c0 + c1 + c2;
+      lo[v][0] = l0; lo[v][1] = l1 - c0; lo[v][2] = l2 - (c0 + c1);
+      kmax = max(kmax, tot[v]);
+    }
+    int best[2] = {-1, -1};
+    float bd[2] = {3.4e38f, 3.4e38f};
+    for (int k = 0; k < kmax; k += NC) {
+      f32x4 c[2][NC];
 #pragma unroll
-  for (int u = 0; u < NI; u++) { best[u] = -1; bd[u] = 3.4e38f; }
-  for (int k = 0; k < kmax; k += NC) {
-    f32x4 c[NI][NC];
+      for (int v = 0; v < 2; v++) {
+        g_cf32x4* gp = (g_cf32x4*)sh->kf[min(u0 + v, nk - 1)].gp;
 #pragma unroll
-    for (int u = 0; u < NI; u++) {
-      g_cf32x4* gp = (g_cf32x4*)sh->kf[kf[u]].gp;
+        for (int w = 0; w < NC; w++) {
+          const int kk = k + w;
+          const int idx = kk + (kk < cnt[v][0] ? lo[v][0] : (kk < cnt[v][1] ? lo[v][1] : lo[v][2]));
+          c[v][w] = gp[kk < tot[v] ? idx : 0];
+        }
+      }
 #pragma unroll
-      for (int v = 0; v < NC; v++) {
-        const int kk = k + v;  // candidate kk of the window, rows in ascending order
-        const int idx = kk + (kk < cnt[u][0] ? lo[u][0] : (kk < cnt[u][1] ? lo[u][1] : lo[u][2]));
-        c[u][v] = gp[kk < tot[u] ? idx : 0];
+      for (int v = 0; v < 2; v++) {
+#pragma unroll
+        for (int w = 0; w < NC; w++) {
+          const float dx = qx[u0 + v] - c[v][w].x, dy = qy[u0 + v] - c[v][w].y;
+          float d2 = dx * dx; d2 += dy * dy;
+          const int ci = __float_as_int(c[v][w].z);
+          const bool take = (k + w < tot[v]) & ((d2 < bd[v]) | ((d2 == bd[v]) & (ci < best[v])));
+          bd[v] = take ? d2 : bd[v];
+          best[v] = take ? ci : best[v];
+        }
       }
     }
 #pragma unroll
-    for (int u = 0; u < NI; u++) {
-#pragma unroll
-      for (int v = 0; v < NC; v++) {
-        const float dx = qx[u] - c[u][v].x, dy = qy[u] - c[u][v].y;
-        float d2 = dx * dx; d2 += dy * dy;
-        const int ci = __float_as_int(c[u][v].z);
-        const bool take = (k + v < tot[u]) & ((d2 < bd[u]) | ((d2 == bd[u]) & (ci < best[u])));  // no short circuit, selects: a load whose
-        bd[u] = take ? d2 : bd[u];                                                          // only use sits in a conditional block
-        best[u] = take ? ci : best[u];                                                      // gets sunk into it and waited for alone
-      }
+    for (int v = 0; v < 2; v++) {
+      const int u = u0 + v;
+      ti[u] = (best[v] >= 0 && (double)bd[v] < curr_radius * curr_radius) ? best[v] : -1;
+      if (u >= nk) ti[u] = -1;
     }
-  }
-  f64x2 tn[NI];
+  };
+  auto gate_load = [&](int u0) {
 #pragma unroll
-  for (int u = 0; u < NI; u++) {
-    ti[u] = (best[u] >= 0 && (double)bd[u] < curr_radius * curr_radius) ? best[u] : -1;
-    if (i0 + u >= nk) ti[u] = -1;
-    tn[u] = ((g_cf64x2*)(sh->kf[kf[u]].rtar + 8 * (size_t)(ti[u] >= 0 ? ti[u] : 0)))[1];  // the gate normals of all keyframes in one round trip
-  }
+    for (int v = 0; v < 2; v++) tn[v] = ((g_cf64x2*)(sh->kf[min(u0 + v, nk - 1)].rtar + 8 * (size_t)(ti[u0 + v] >= 0 ? ti[u0 + v] : 0)))[1];
+  };
+  auto gate = [&](int u0) {
 #pragma unroll
-  for (int u = 0; u < NI; u++) {
-    const auto* T = sh->Trel[kf[u]];
-    const double nx = T[0] * snx + T[1] * sny;
-    const double ny = T[2] * snx + T[3] * sny;
-    const double sim = fmax(nx * tn[u].x + ny * tn[u].y, 0.0);
-    if (ti[u] >= 0 && !(sim > angle_outlier)) ti[u] = -1;  // :247
-    // a window of more than three bucket rows is left to the caller (-2): a call in here would make this function save and
-    // restore a register through scratch at every exit
-    if ((wide & (1 << u)) && i0 + u < nk) ti[u] = -2;
+    for (int v = 0; v < 2; v++) {
+      const int u = u0 + v;
+      const auto* T = sh->Trel[min(u, nk - 1)];
+      const double nx = T[0] * snx + T[1] * sny;
+      const double ny = T[2] * snx + T[3] * sny;
+      const double sim = fmax(nx * tn[v].x + ny * tn[v].y, 0.0);
+      if (ti[u] >= 0 && !(sim > angle_outlier)) ti[u] = -1;  // :247
+      if ((wide & (1u << u)) && u < nk) ti[u] = -2;
+    }
+  };
+  search(0);
+  gate_load(0);
+  if (nk > 2) {  // block-uniform
+    search(2);   // (the gate normals of keyframes 0, 1 arrive during the first candidate trip)
+    gate(0);
+    gate_load(2);
+    gate(2);
+  } else {
+    gate(0);
+    ti[2] = ti[3] = -1;
   }
-}
-// two keyframes per call (register budget of the registration kernels): (ti of i0) | (ti of i0 + 1) << 32
-__device__ __noinline__ unsigned long long associate_cell2(const ScanDev* src, const LRegShared* sh, int nk, int i0, int j, double curr_radius) {
-  int ti[2];
-  associate_cell_t<2, 4>(src, sh, nk, i0, j, curr_radius, ti);
-  return (unsigned long long)(unsigned)ti[0] | ((unsigned long long)(unsigned)ti[1] << 32);
+  unsigned long long r = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) r |= (unsigned long long)(unsigned)(ti[u] & 0xFFFF) << (16 * u);
+  return r;
 }
 __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegShared* sh, int nk, int j, double curr_radius) {
-  Assoc4 a = {-1, -1, -1, -1};
-  const unsigned long long p = associate_cell2(src, sh, nk, 0, j, curr_radius);
-  a.t0 = (int)(unsigned)p; a.t1 = (int)(unsigned)(p >> 32);
-  if (nk > 2) {
-    const unsigned long long q = associate_cell2(src, sh, nk, 2, j, curr_radius);
-    a.t2 = (int)(unsigned)q; a.t3 = (int)(unsigned)(q >> 32);
+  Assoc4 a;
+  {
+    const unsigned long long p = associate_cell4(sh, nk, j, curr_radius);
+    auto un = [](unsigned v) -> int { return v >= 0xFFFEu ? (int)v - 0x10000 : (int)v; };  // 0xFFFF -> -1, 0xFFFE -> -2
+    a.t0 = un((unsigned)(p & 0xFFFF)); a.t1 = un((unsigned)((p >> 16) & 0xFFFF)); a.t2 = un((unsigned)((p >> 32) & 0xFFFF)); a.t3 = un((unsigned)(p >> 48));
   }
   if (a.t0 == -2 || a.t1 == -2 || a.t2 == -2 || a.t3 == -2) {  // rare: the general search for those pairs
     const int nsrc = src->n_cells;
