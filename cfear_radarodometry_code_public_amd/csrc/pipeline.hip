@@ -72,6 +72,9 @@ struct OdoParams {
   int phase_detail;        // also accumulate the evaluation / controller times of every LM command (three clock reads per command:
                            // the registration kernel runs at half speed with them)
   int seq0;  // first sequence of this launch (sub-batches run on their own streams)
+  // the scan slots of all sequences are one allocation, slot j of sequence q at scans_base + scan_stride * (q * (submap + 1) + j):
+  // computed, not fetched from the pointer table (a memory round trip at the start of both kernels)
+  unsigned char* scans_base; size_t scan_stride;
 };
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   const int q = OP.seq0 + blockIdx.x;
   const SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
-  ScanDev* cur = scan_slots[(size_t)q * (OP.submap + 1) + st->free_slot];
+  ScanDev* cur = reinterpret_cast<ScanDev*>(OP.scans_base + OP.scan_stride * ((size_t)q * (OP.submap + 1) + st->free_slot));
   const Aff2 TprevMot = st->Tmot;  // :146
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
   if (TIMED) pt.mark();
@@ -254,11 +257,14 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
   SeqState* st = &states[q];
   const BlockScratch B = scratch[q];
   const int nslots = OP.submap + 1;
-  ScanDev* const* my_slots = scan_slots + (size_t)q * nslots;
+  auto slot_ptr = [&](int j) -> ScanDev* { return reinterpret_cast<ScanDev*>(OP.scans_base + OP.scan_stride * ((size_t)q * nslots + j)); };
   const int cur_slot = st->free_slot;
-  ScanDev* cur = my_slots[cur_slot];
+  ScanDev* cur = slot_ptr(cur_slot);
   const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
   const int nkf = st->nkf;
+  // this thread's keyframe (threads below nkf), read with the rest of the state: one round trip, before the barrier
+  const int my_ring = st->ring[tid < MAX_SCANS ? tid : 0];
+  const Aff2 my_kf_pose = st->kf_pose[tid < MAX_SCANS ? tid : 0];
   PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
   pt.acc = (TIMED && OP.phase_times && OP.phase_detail) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
   pt.acc2 = (TIMED && OP.phase_times && OP.phase_detail == 2) ? OP.phase_times + (size_t)q * 32 : nullptr;  // (over the feature kernel's stamps)
@@ -283,8 +289,8 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
   double* poses = poses_work + (size_t)q * MAX_SCANS * 3;
   const int ns = nkf + 1;
   if (tid < nkf) {
-    sp[tid] = my_slots[st->ring[tid]];
-    double v[3]; aff_to_xyt(st->kf_pose[tid], v);
+    sp[tid] = slot_ptr(my_ring);
+    double v[3]; aff_to_xyt(my_kf_pose, v);
     poses[3 * tid] = v[0]; poses[3 * tid + 1] = v[1]; poses[3 * tid + 2] = v[2];
   }
   if (tid == 0) {
@@ -448,6 +454,7 @@ struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, pair_cap = 0;
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
   ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
+  size_t scan_stride = 0;              // bytes between consecutive scan slots of d_scans
   unsigned char* d_scratch = nullptr;  // B scratch blocks
   BlockScratch* d_scratch_hdr = nullptr;
   SeqState* d_states = nullptr;
@@ -1070,6 +1077,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc odometry state"); }
+  o->scan_stride = SL.total;
   std::vector<ScanDev*> ptrs((size_t)B * o->nslots);
   std::vector<BlockScratch> hdrs((size_t)B);
   std::vector<ScanDev> scan_hdrs((size_t)B * o->nslots);  // all headers built on the host, uploaded with one strided copy
@@ -1126,6 +1134,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   OP.phase_times = o->wg_only ? nullptr : o->d_phase_times; OP.phase_detail = o->phase_detail;
   OP.wg_times = o->wg_only ? o->d_phase_times : nullptr;
   OP.seq0 = 0;
+  OP.scans_base = o->d_scans; OP.scan_stride = o->scan_stride;
   const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
   hipStream_t sf = o->overlap ? o->sf : ctx->stream;
   int rc = CFEAR_OK;
