@@ -286,7 +286,7 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
   }
   // FormatScans (:478-494)
   ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
-  double* poses = poses_work + (size_t)q * MAX_SCANS * 3;
+  double* poses = reinterpret_cast<double*>(lds + RegLds::par);  // the registration's parameter array itself: the poses never go through memory
   const int ns = nkf + 1;
   if (tid < nkf) {
     sp[tid] = slot_ptr(my_ring);

@@ -1175,6 +1175,11 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
   const RegIo& io = sh->rio;
   const bool master = (tid >> 6) == 0;
+  // the last pose as passed in (what a failed registration hands back): read before the normalisation below, which works in
+  // place when the caller keeps its poses in par_lds (the step kernel does: no trip through memory for them)
+  // (read by the controller wave, which also holds the thread that normalises that entry - n <= 64 - so program order is enough)
+  double last_in0 = 0, last_in1 = 0, last_in2 = 0;
+  if (master) { last_in0 = poses[3 * (n - 1)]; last_in1 = poses[3 * (n - 1) + 1]; last_in2 = poses[3 * (n - 1) + 2]; }
   // Affine3dToVectorXYeZ(Tsrc[i]) (:88-92): theta -> atan2(sin, cos)
   for (int i = tid; i < n; i += CFEAR_REG_BLOCK) {
     const Aff2 T = aff_from_xyt(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]);
@@ -1209,7 +1214,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
       sh->prior_on = 1;
     }
     sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2];
-    sh->tsrc_last[0] = poses[L]; sh->tsrc_last[1] = poses[L + 1]; sh->tsrc_last[2] = poses[L + 2];
+    sh->tsrc_last[0] = last_in0; sh->tsrc_last[1] = last_in1; sh->tsrc_last[2] = last_in2;
     sh->prev_score = 1.7976931348623157e308;
     sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1; sh->nrec = 0;
     sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
