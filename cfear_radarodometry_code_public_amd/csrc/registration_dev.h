@@ -73,6 +73,15 @@ __device__ __forceinline__ double div_well_scaled(double num, double den) {
   return __builtin_fma(__builtin_fma(-den, q, num), r, q);
 }
 __device__ inline double similarity(double x, double y) { return div_well_scaled(2 * fmin(x, y), x + y); }  // registration.h:96
+// square root of a well-scaled non-negative number (norms of steps and poses): hardware reciprocal square root, two Newton
+// steps, one correction of the root; half the instructions of the IEEE sequence, within an ulp or two of it
+__device__ __forceinline__ double sqrt_well_scaled(double s) {
+  double y = __builtin_amdgcn_rsq(s > 0.0 ? s : 1.0);
+  y = y * __builtin_fma(-0.5 * s, y * y, 1.5);
+  y = y * __builtin_fma(-0.5 * s, y * y, 1.5);
+  const double r = s * y;
+  return s > 0.0 ? __builtin_fma(0.5 * y, __builtin_fma(-r, r, s), r) : 0.0;
+}
 __device__ inline double get_weight(int opt, double n1, double n2, double sim, double p1, double p2) {  // registration.cpp:67-76
   switch (opt) {
     case 0: return 1.0;
@@ -378,6 +387,30 @@ __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, in
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
 // generic pointer every partial sum was a flat load the running sum had to wait for (2.8 us per evaluation).
+__device__ __forceinline__ NormalEq gather_partials_regs(const double* red_lds) {
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  lds_cdouble* red = (lds_cdouble*)red_lds;
+  double r[10];
+#pragma unroll
+  for (int h = 0; h < 10; h += 5) {  // five quantities at a time: 20 loads in flight
+    double p[5][CFEAR_EVAL_WAVES];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+      for (int j = 0; j < CFEAR_EVAL_WAVES; j++) p[i][j] = red[(h + i) * CFEAR_RED_STRIDE + j];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      double t = 0;
+#pragma unroll
+      for (int j = 0; j < CFEAR_EVAL_WAVES; j++) t += p[i][j];
+      r[h + i] = t;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  NormalEq e;  // field order: cost g0 g1 g2 h00 h01 h02 h11 h12 h22
+  e.cost = r[0]; e.g0 = r[1]; e.g1 = r[2]; e.g2 = r[3]; e.h00 = r[4]; e.h01 = r[5]; e.h02 = r[6]; e.h11 = r[7]; e.h12 = r[8]; e.h22 = r[9];
+  return e;
+}
 __device__ __forceinline__ void gather_partials(const double* red_lds, LNormalEq* out) {
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   lds_cdouble* red = (lds_cdouble*)red_lds;
@@ -997,7 +1030,7 @@ __device__ __forceinline__ int ctl_lm_next_body(LRegShared* sh) {
       sh->dg2 = fmin(fmax(Hs[5], min_lm_diagonal), max_lm_diagonal);
     }
     // D^T D of the LM diagonal D = sqrt(diag / radius): the square root is squared again, so it is left out
-    const double inv_radius = 1.0 / sh->radius;
+    const double inv_radius = div_well_scaled(1.0, sh->radius);  // radius in [1e-32, 1e16]
     const double Am[6] = {Hs[0] + sh->dg0 * inv_radius, Hs[1], Hs[2], Hs[3] + sh->dg1 * inv_radius, Hs[4], Hs[5] + sh->dg2 * inv_radius};
     const double rhs[3] = {-gs[0], -gs[1], -gs[2]};
     double y[3];
@@ -1059,11 +1092,10 @@ __device__ __noinline__ int ctl_after_build(LRegShared* sh) {
 
 __device__ __forceinline__ int ctl_after_it0_body(LRegShared* sh) {
   const double gradient_tolerance = 1e-10;
-  gather_partials(sh->rw.red, &sh->G);
-  NormalEq E = neq_load(&sh->G);
+  NormalEq E = gather_partials_regs(sh->rw.red);  // (in registers: stored once, as the current point's equations)
   if (sh->prior_on) E = add_prior(sh, E, sh->x[0], sh->x[1], sh->x[2]);
   neq_store(&sh->E, E); sh->x_cost = E.cost;
-  sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+  sh->x_norm = sqrt_well_scaled(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
   const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
   if (gmax <= gradient_tolerance) { sh->ss.termination = 0; return CTL_LM_DONE; }
@@ -1077,24 +1109,24 @@ __device__ __forceinline__ int ctl_after_candidate_body(LRegShared* sh) {
   const auto& P = sh->rp;
   const double min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double max_radius = 1e16;
-  gather_partials(sh->rw.red, &sh->G);
-  NormalEq C = neq_load(&sh->G);
+  NormalEq C = gather_partials_regs(sh->rw.red);
   if (sh->prior_on) C = add_prior(sh, C, sh->x[0], sh->x[1], sh->x[2]);
   const double cand_cost = C.cost;
   const double d0 = sh->xcur[0] - sh->xc[0], d1 = sh->xcur[1] - sh->xc[1], d2 = sh->xcur[2] - sh->xc[2];
-  const double step_norm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  const double step_norm = sqrt_well_scaled(d0 * d0 + d1 * d1 + d2 * d2);
   if (step_norm <= parameter_tolerance * (sh->x_norm + parameter_tolerance)) { sh->ss.termination = 0; return CTL_LM_DONE; }
   const double cost_change = sh->x_cost - cand_cost;
   if (fabs(cost_change) <= function_tolerance * sh->x_cost) { sh->ss.termination = 0; return CTL_LM_DONE; }
-  const double relative_decrease = cost_change / sh->model_cost_change;
+  const double mcc = sh->model_cost_change;  // > 0 (ctl_lm_next); the short quotient unless it is next to the denormals
+  const double relative_decrease = mcc > 1e-290 ? div_well_scaled(cost_change, mcc) : cost_change / mcc;
   sh->ss.num_iterations++;
   sh->ss.last_relative_decrease = relative_decrease;
   if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
     sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2]; sh->cur_c = sh->c; sh->cur_s = sh->s;
-    sh->x_norm = sqrt(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
+    sh->x_norm = sqrt_well_scaled(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
     neq_store(&sh->E, C); sh->x_cost = cand_cost;
     const double t = 2.0 * relative_decrease - 1.0;
-    sh->radius = sh->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    sh->radius = div_well_scaled(sh->radius, fmax(1.0 / 3.0, 1.0 - t * t * t));  // divisor in [1/3, 1]
     sh->radius = fmin(max_radius, sh->radius);
     sh->decrease_factor = 2.0; sh->reuse_diagonal = 0;
     if (sh->x_cost < sh->ss.final_cost) sh->ss.final_cost = sh->x_cost;
