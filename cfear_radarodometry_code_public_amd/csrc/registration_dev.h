@@ -1281,7 +1281,11 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     if (pt && (pt->acc || acc2) && tid == 0) t1 = (long long)wall_clock64();
     __syncthreads();  // results visible to the controller
     if (acc2 && cmd != REG_CMD_BUILD) { const long long t = (long long)wall_clock64(); acc2[0] += tb - t0c; acc2[1] += t1 - tb; acc2[2] += t - t1; acc2[3] += 1; }
-    if (master) ctl_step(ls, (cmd != REG_CMD_BUILD) ? acc2 : nullptr);
+    if (master) {
+      __builtin_amdgcn_s_setprio(3);  // the serial chain of the workgroup: ahead of the other workgroups' waves on this SIMD
+      ctl_step(ls, (cmd != REG_CMD_BUILD) ? acc2 : nullptr);
+      __builtin_amdgcn_s_setprio(0);
+    }
     if (pt && pt->acc && tid == 0 && cmd != REG_CMD_BUILD) {  // tools: time in evaluations (incl. the barrier before) and in the controller
       const long long t2 = (long long)wall_clock64();
       pt->acc[0] += t1 - t0c; pt->acc[1] += t2 - t1; pt->acc[2] += 1;
