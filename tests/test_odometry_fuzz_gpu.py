@@ -46,11 +46,14 @@ def sequences():
     return out
 
 
-SEQS = sequences()
+@pytest.fixture(scope="module")
+def seqs():
+    return sequences()
 
 
 @pytest.mark.parametrize("cost", [1, 2])
-def test_pathological_sweeps_match_the_oracle_fuser(oracle, cost):
+def test_pathological_sweeps_match_the_oracle_fuser(oracle, seqs, cost):
+    SEQS = seqs
     names = sorted(SEQS)
     kw = dict(cost=cost, regularization=0.1, covar_scale=1.0)
     po, pg = mk(oracle, **kw), mk(capi, **kw)
