@@ -3,8 +3,8 @@
 # counter group per pass, each pass under its own timeout
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "FETCH_SIZE WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do  # one counter per pass (together they abort rocprofv3 on this pool)
   i=$((i+1))
   ODO_FRAMES=14 ODO_CFG="0,1536" timeout 150 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_odo_mem$i -o odo -- python $R/tools/gpu_odo_streams.py > $R/gpurun_out/pmc_odo_mem$i.log 2>&1
-  (cd $R; python tools/rocpd_summary.py $(find /tmp/pmc_odo_mem$i -name "*.db" | head -1) | grep -E "step_kernel \||kstrongest_kernel<4, 8> \|" | grep -v "| [0-9]* | [0-9.]* | [0-9.]* |")
+  (cd $R; python tools/rocpd_summary.py $(find /tmp/pmc_odo_mem$i -name "*.db" | head -1) | grep -E "(step_kernel<false>|kstrongest_kernel<4, 7>) \| [A-Z]")
 done
