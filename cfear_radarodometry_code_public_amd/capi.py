@@ -57,6 +57,11 @@ class RegSummary(C.Structure):
     ]
 
 
+# cfear_sweep_record (include/cfear_hip.h): what a caller of pointcloudCallback sees after every sweep of a replay
+SWEEP_RECORD_DTYPE = np.dtype([("pose", "f8", 3), ("final_cost", "f8"), ("outer_iterations", "i4"), ("num_residuals", "i4"),
+                               ("n_keyframes", "i4"), ("n_cells", "i4"), ("inner_iterations", "i4", 8)])
+assert SWEEP_RECORD_DTYPE.itemsize == 80
+
 EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
     "cfear_set_params", "cfear_synchronize", "cfear_tune", "cfear_kstrongest_device", "cfear_kstrongest_host",
@@ -65,6 +70,7 @@ EXPORTS = [
     "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
+    "cfear_odometry_replay_host", "cfear_host_alloc", "cfear_host_free",
     "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
 
@@ -128,6 +134,9 @@ def lib():
         "cfear_odometry_step_device": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_step_host": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
+        "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
+        "cfear_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+        "cfear_host_free": (None, [vp, vp]),
         "cfear_odometry_summary": (C.c_int, [vp, vp, C.c_int, C.POINTER(RegSummary), C.POINTER(C.c_int),
                                              C.POINTER(C.c_int)]),
         "cfear_odometry_profile": (C.c_int, [vp, vp, C.c_int]),
@@ -182,6 +191,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ptr in list(getattr(self, "_pinned", {}).values()):
+                self._L.cfear_host_free(self._h, ptr)
+            self._pinned = {}
             self._L.cfear_destroy(self._h)
             self._h = None
 
@@ -339,6 +351,23 @@ class Context:
                                                   costs.ctypes.data), "cfear_cov_by_sampling")
         return bool(ok.value), cov.reshape(6, 6), costs
 
+    def pinned(self, shape, dtype=np.uint8):
+        """Page-locked host array (cfear_host_alloc): copies from it overlap with kernels. Freed by pinned_free(arr) or when
+        the context closes."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self._check(self._L.cfear_host_alloc(self._h, nbytes, C.byref(ptr)), "cfear_host_alloc")
+        buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = ptr.value
+        return arr
+
+    def pinned_free(self, arr):
+        ptr = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if ptr is not None and self._h:
+            self._L.cfear_host_free(self._h, ptr)
+
     def odometry(self, n_sequences, overlap=None):
         """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
         sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams"""
@@ -445,6 +474,19 @@ class Odometry:
         assert polar.shape == (self.B, self._ctx.A, self._ctx.R)
         self._ctx._check(self._ctx._L.cfear_odometry_step_host(self._ctx._h, self._h, polar.ctypes.data),
                          "cfear_odometry_step_host")
+
+    def replay_host(self, frames, records=True):
+        """frames: uint8 [n, B, A, R] (or [n, A, R] for one sequence), e.g. a view of Context.pinned(). Runs the n sweeps with
+        no host round trip in between; -> structured array [n, B] of SWEEP_RECORD_DTYPE (or None)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 3:
+            frames = frames[:, None]
+        assert frames.shape[1:] == (self.B, self._ctx.A, self._ctx.R), frames.shape
+        n = frames.shape[0]
+        rec = np.zeros((n, self.B), dtype=SWEEP_RECORD_DTYPE) if records else None
+        self._ctx._check(self._ctx._L.cfear_odometry_replay_host(self._ctx._h, self._h, frames.ctypes.data, n,
+                                                                 rec.ctypes.data if records else None), "cfear_odometry_replay_host")
+        return rec
 
     def profile(self, enable):
         self._ctx._check(self._ctx._L.cfear_odometry_profile(self._ctx._h, self._h, int(enable)), "cfear_odometry_profile")

@@ -35,6 +35,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
   v += dpp_pull<0x143, 0xC>(0, v);  // row_bcast31 -> rows 2, 3
   return v;
 }
+__device__ __forceinline__ unsigned wave_inclusive_scan_u(unsigned v) {  // the same modulo 2^32 (packed counters that use bit 31)
+  v += (unsigned)dpp_pull<0x111, 0xF>(0, (int)v);
+  v += (unsigned)dpp_pull<0x112, 0xF>(0, (int)v);
+  v += (unsigned)dpp_pull<0x114, 0xF>(0, (int)v);
+  v += (unsigned)dpp_pull<0x118, 0xF>(0, (int)v);
+  v += (unsigned)dpp_pull<0x142, 0xA>(0, (int)v);
+  v += (unsigned)dpp_pull<0x143, 0xC>(0, (int)v);
+  return v;
+}
 __device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63); }
 #define CFEAR_DPP_FLOAT_REDUCE(NAME, OP)                                                          \
   __device__ __forceinline__ float NAME(float v) {                                                \
@@ -138,6 +147,27 @@ __device__ __forceinline__ int block_exclusive_scan_1b(int v, int* scratch, int 
     tot += s;
   }
   *total = tot;
+  return base + inc - v;
+}
+
+// The one-barrier scan over unsigned values with a block-wide OR of a per-thread flag riding along (entries 8..15 of the slot:
+// at most 8 waves): *any = some thread of the block raised its flag.
+__device__ __forceinline__ unsigned block_exclusive_scan_1b_flag(unsigned v, bool flag, int* scratch, int slot, unsigned* total, bool* any) {
+  auto* sl = CFEAR_LDS_PTR(int, scratch) + 16 * slot;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const unsigned inc = wave_inclusive_scan_u(v);
+  const bool wf = __ballot(flag) != 0ull;
+  if (lane == 63) { sl[w] = (int)inc; sl[8 + w] = wf ? 1 : 0; }
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+  int f = 0;
+  for (int i = 0; i < nw; i++) {
+    const unsigned s = (unsigned)sl[i];
+    if (i < w) base += s;
+    tot += s;
+    f |= sl[8 + i];
+  }
+  *total = tot; *any = f != 0;
   return base + inc - v;
 }
 

@@ -322,12 +322,19 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
                                // list alone (the epilogue then visits every sample), with the chunk size doubled until it fits
       int cnt = 0, act = 0;
       for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) / C; act += t > 0 ? 1 : 0; }
-      int tot2;
-      const int ex = block_exclusive_scan_1b(cnt | (act << 16), W.red_i, it & 1, &tot2);  // both counts < 32768: one scan for the two
-      o = ex & 0xFFFF; oa = ex >> 16; NC = tot2 & 0xFFFF; NA = tot2 >> 16;
-      if (NC + NA <= ccap) break;
+      // one scan for the two counts: chunks in bits 0..18, active samples (<= nv <= 4864) in bits 19..31. A dense cloud with a
+      // large downsample_factor has far more than 2^19 chunks of 16 (hundreds of voxels that each see thousands of candidates):
+      // a thread's count is clamped to 1023 (512 x 1023 < 2^19, the fields cannot run into each other) and a clamped thread
+      // raises a flag that travels with the partial sums - the chunk size is doubled then, as for any list that does not fit
+      const bool big = cnt > 1023;
+      cnt = big ? 1023 : cnt;
+      unsigned tot2;
+      bool any_big;
+      const unsigned ex = block_exclusive_scan_1b_flag((unsigned)cnt | ((unsigned)act << 19), big, W.red_i, it & 1, &tot2, &any_big);
+      o = (int)(ex & 0x7FFFFu); oa = (int)(ex >> 19); NC = (int)(tot2 & 0x7FFFFu); NA = (int)(tot2 >> 19);
+      if (!any_big && NC + NA <= ccap) break;
       listed = false;
-      if (NC <= ccap) break;  // (an active sample has a chunk, so NC >= NA; NC -> NA <= nv <= ccap as the chunks grow)
+      if (!any_big && NC <= ccap) break;  // (an active sample has a chunk, so NC >= NA; NC -> NA <= nv <= ccap as the chunks grow)
       C <<= 1;
     }
     for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk, active samples in order

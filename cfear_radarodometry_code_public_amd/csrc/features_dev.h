@@ -241,7 +241,9 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   if (tabbed && RC <= CFEAR_PT && k < 65536 && items < 65536) {  // block-uniform: every reference configuration
     // Wave w takes the slots [w * RC * 64, (w + 1) * RC * 64) round after round, lane <-> slot: coalesced loads, and the
     // kept points of the wave are contiguous in the cloud, in register order (see PointRegs).
-    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)k - 1u) / (unsigned)k);  // t / k = umulhi(t, magic) for t, k < 65536
+    // t / k = umulhi(t, magic) for t < 65536 and 2 <= k < 65536 (checked exhaustively for the supported k = 2..64); for k = 1 the
+    // magic number would be 2^32, which does not fit: the quotient is t itself
+    const unsigned magic = k > 1 ? (unsigned)((0x100000000ull + (unsigned)k - 1u) / (unsigned)k) : 0u;
     uint32_t sv[CFEAR_PT];
 #pragma unroll
     for (int r = 0; r < CFEAR_PT; r++) {  // the slots are on their way from memory while the table is built
@@ -283,7 +285,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       const bool on = preg_on(PR, r);
       const int range = CFEAR_SLOT_RANGE(s);
       const int t = (wv * RC + r) * 64 + ln;
-      const int bb = min((int)__umulhi((unsigned)t, magic), A - 1);
+      const int bb = min(k > 1 ? (int)__umulhi((unsigned)t, magic) : t, A - 1);
       const double cb = ltab[6 * bb + 4], sb = ltab[6 * bb + 5];
       const double rad = range_res_half + range_res * range;
       float x = (float)(rad * cb);  // :329

@@ -75,6 +75,7 @@ struct OdoParams {
   // the scan slots of all sequences are one allocation, slot j of sequence q at scans_base + scan_stride * (q * (submap + 1) + j):
   // computed, not fetched from the pointer table (a memory round trip at the start of both kernels)
   unsigned char* scans_base; size_t scan_stride;
+  cfear_sweep_record* records;  // optional [B]: this sweep's record of every sequence (cfear_odometry_replay_host)
 };
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -281,6 +282,12 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
       sum->success = 0; sum->usable = 0; sum->outer_iterations = 0; sum->num_residuals = 0; sum->num_residual_blocks = 0;
       double v[3]; aff_to_xyt(st->Tcurrent, v);
       poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
+      if (OP.records) {
+        cfear_sweep_record* r = OP.records + q;
+        r->pose[0] = v[0]; r->pose[1] = v[1]; r->pose[2] = v[2]; r->final_cost = 0;
+        r->outer_iterations = 0; r->num_residuals = 0; r->n_keyframes = 1; r->n_cells = cur->n_cells;
+        for (int i = 0; i < 8; i++) r->inner_iterations[i] = 0;
+      }
     }
     return;
   }
@@ -341,6 +348,12 @@ __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP,
     st->frames++; st->last_slot = cur_slot;
     double v[3]; aff_to_xyt(Tcurrent, v);
     poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
+    if (OP.records) {  // what a caller of pointcloudCallback sees after this sweep, kept per sweep (no host round trip in a replay)
+      cfear_sweep_record* r = OP.records + q;
+      r->pose[0] = v[0]; r->pose[1] = v[1]; r->pose[2] = v[2]; r->final_cost = sum->final_cost;
+      r->outer_iterations = sum->outer_iterations; r->num_residuals = sum->num_residuals; r->n_keyframes = st->nkf; r->n_cells = cur->n_cells;
+      for (int i = 0; i < 8; i++) r->inner_iterations[i] = sum->inner_iterations[i];
+    }
     if (!TIMED && OP.wg_times) OP.wg_times[(size_t)q * 32 + 15] = (long long)wall_clock64();
   }
 }
@@ -464,6 +477,16 @@ struct cfear_odometry {
   double* d_poses_out = nullptr;
   uint32_t* d_slots[2] = {nullptr, nullptr};  // filter output, double-buffered: the filter runs one sweep ahead
   uint8_t* d_polar = nullptr;  // staging for step_host
+  // cfear_odometry_replay_host: chunks of sweeps are copied and filtered on a stream of their own (rp_stream), two chunks
+  // in flight (staging + slots double-buffered), while the context stream runs features -> registration sweep after sweep
+  hipStream_t rp_stream = nullptr;
+  uint8_t* rp_polar[2] = {nullptr, nullptr};
+  uint32_t* rp_slots[2] = {nullptr, nullptr};
+  hipEvent_t rp_filt[2] = {nullptr, nullptr}, rp_used[2] = {nullptr, nullptr};  // chunk filtered / chunk consumed by the odometry kernels
+  bool rp_used_pending[2] = {false, false};
+  int rp_chunk = 0;            // sweeps per chunk the buffers are sized for
+  cfear_sweep_record* d_records = nullptr;
+  size_t records_cap = 0;      // records
   long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
   int phase_detail = 1;
   bool wg_only = false;  // the table only receives the workgroups' start / end clocks, from the production kernels
@@ -517,6 +540,36 @@ static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
     }
   }
   return CFEAR_OK;
+}
+
+// the kernel parameters of one odometry step of `o` under the context's current settings
+static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
+  OdoParams OP;
+  OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
+  OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
+  OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
+  OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
+  OP.phase_times = o->wg_only ? nullptr : o->d_phase_times; OP.phase_detail = o->phase_detail;
+  OP.wg_times = o->wg_only ? o->d_phase_times : nullptr;
+  OP.seq0 = 0;
+  OP.scans_base = o->d_scans; OP.scan_stride = o->scan_stride;
+  OP.records = nullptr;
+  return OP;
+}
+// features -> registration of one sweep of every sequence on `st`, from the filter's slots
+static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoParams& P, const uint32_t* d_slots, int seq_count, hipStream_t st) {
+  if (P.phase_times)
+    hipLaunchKernelGGL(features_step_kernel<true>, dim3(seq_count), dim3(BLOCK_F), 0, st, d_slots, ctx->d_trig, P, o->d_states,
+                       o->d_scan_ptrs, o->d_scratch_hdr);
+  else
+    hipLaunchKernelGGL(features_step_kernel<false>, dim3(seq_count), dim3(BLOCK_F), 0, st, d_slots, ctx->d_trig, P, o->d_states,
+                       o->d_scan_ptrs, o->d_scratch_hdr);
+  if (P.phase_times)
+    hipLaunchKernelGGL(register_step_kernel<true>, dim3(seq_count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  else
+    hipLaunchKernelGGL(register_step_kernel<false>, dim3(seq_count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
+                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
 }
 
 // per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
@@ -1024,8 +1077,17 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
     }
     (void)hipStreamSynchronize(ctx->stream);
   }
+  if (ctx && o->rp_stream) {
+    (void)hipStreamSynchronize(o->rp_stream);
+    for (size_t i = 0; i < ctx->aux_streams.size(); i++)
+      if (ctx->aux_streams[i] == o->rp_stream) { ctx->aux_streams.erase(ctx->aux_streams.begin() + i); break; }
+    (void)hipStreamSynchronize(ctx->stream);
+  }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
-                  o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times};
+                  o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times,
+                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records};
+  for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1]}) if (e) (void)hipEventDestroy(e);
+  if (o->rp_stream) (void)hipStreamDestroy(o->rp_stream);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : o->pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : {o->ev_in, o->ev_copied, o->ev_filt[0], o->ev_filt[1]}) if (e) (void)hipEventDestroy(e);
@@ -1126,15 +1188,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  OdoParams OP;
-  OP.fp = feature_params(ctx); OP.rp = reg_params(ctx);
-  OP.A = ctx->A; OP.k = ctx->par.k_strongest; OP.compensate = ctx->par.compensate; OP.ccw = ctx->par.radar_ccw;
-  OP.use_keyframe = ctx->par.use_keyframe; OP.submap = ctx->par.submap_scan_size;
-  OP.min_keyframe_dist = ctx->par.min_keyframe_dist; OP.min_keyframe_rot_deg = ctx->par.min_keyframe_rot_deg;
-  OP.phase_times = o->wg_only ? nullptr : o->d_phase_times; OP.phase_detail = o->phase_detail;
-  OP.wg_times = o->wg_only ? o->d_phase_times : nullptr;
-  OP.seq0 = 0;
-  OP.scans_base = o->d_scans; OP.scan_stride = o->scan_stride;
+  const OdoParams OP = odo_params(ctx, o);
   const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
   hipStream_t sf = o->overlap ? o->sf : ctx->stream;
   int rc = CFEAR_OK;
@@ -1281,6 +1335,100 @@ int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h
   const int rc = cfear_odometry_step_device(ctx, o, o->d_polar);
   CFEAR_HIP_CHECK(ctx, hipEventSynchronize(o->ev_copied));
   return rc;
+}
+
+// ---- replay of a recording without a host round trip per sweep (offline_odometry.cpp:103-125) -----------------------
+int cfear_host_alloc(cfear_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "host_alloc: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  *out = nullptr;
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipHostMalloc");
+  return CFEAR_OK;
+}
+void cfear_host_free(cfear_ctx* ctx, void* p) {
+  if (!p) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
+
+static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, size_t n_records) {
+  if (!o->rp_stream) {
+    CFEAR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->rp_stream, hipStreamNonBlocking));
+    ctx->aux_streams.push_back(o->rp_stream);
+    for (hipEvent_t* e : {&o->rp_filt[0], &o->rp_filt[1], &o->rp_used[0], &o->rp_used[1]})
+      CFEAR_HIP_CHECK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  }
+  if (chunk > o->rp_chunk) {
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(o->rp_stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2; i++) {
+      if (o->rp_polar[i]) (void)hipFree(o->rp_polar[i]);
+      if (o->rp_slots[i]) (void)hipFree(o->rp_slots[i]);
+      o->rp_polar[i] = nullptr; o->rp_slots[i] = nullptr;
+      o->rp_used_pending[i] = false;
+    }
+    o->rp_chunk = 0;
+    const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
+    for (int i = 0; i < 2; i++) {
+      if (hipMalloc(&o->rp_polar[i], sweep * chunk + 64) != hipSuccess || hipMalloc(&o->rp_slots[i], sizeof(uint32_t) * slots * chunk) != hipSuccess)
+        return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay staging");
+    }
+    o->rp_chunk = chunk;
+  }
+  if (n_records > o->records_cap) {
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (o->d_records) (void)hipFree(o->d_records);
+    o->d_records = nullptr; o->records_cap = 0;
+    if (hipMalloc(&o->d_records, sizeof(cfear_sweep_record) * n_records) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc sweep records");
+    o->records_cap = n_records;
+  }
+  return CFEAR_OK;
+}
+
+int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h_frames, int n_sweeps, cfear_sweep_record* records) {
+  if (!ctx || !o || !h_frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay_host: bad argument");
+  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest changed after odometry_create");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+  const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
+  // chunk: enough sweeps for the filter to run at its streaming rate (>= ~16 k azimuth rows per launch) and for the copy of the
+  // next chunk to hide behind the odometry kernels of this one, at most 256 MB of staging per buffer
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)64, ((size_t)256 << 20) / sweep));
+  chunk = std::min(chunk, n_sweeps);
+  chunk = std::max(chunk, o->rp_chunk > n_sweeps ? 1 : std::min(o->rp_chunk, n_sweeps));  // (buffers of an earlier call are at least as good)
+  int rc = replay_ensure(ctx, o, chunk, records ? (size_t)n_sweeps * o->B : 0);
+  if (rc != CFEAR_OK) return rc;
+  chunk = std::min(o->rp_chunk, n_sweeps);
+  const int nchunks = (n_sweeps + chunk - 1) / chunk;
+  OdoParams OP = odo_params(ctx, o);
+  auto stage = [&](int c) -> int {  // copy + filter of chunk c on the replay stream
+    const int b = c & 1, t0 = c * chunk, cnt = std::min(chunk, n_sweeps - t0);
+    if (o->rp_used_pending[b]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(o->rp_stream, o->rp_used[b], 0));  // its slots were consumed
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->rp_polar[b], h_frames + sweep * (size_t)t0, sweep * (size_t)cnt, hipMemcpyHostToDevice, o->rp_stream));
+    const int frc = cfear_launch_kstrongest(ctx, o->rp_polar[b], cnt * o->B, o->rp_slots[b], o->rp_stream);  // radar_driver.cpp:58, pose-independent
+    if (frc != CFEAR_OK) return frc;
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_filt[b], o->rp_stream));
+    return CFEAR_OK;
+  };
+  rc = stage(0);
+  if (rc != CFEAR_OK) return rc;
+  for (int c = 0; c < nchunks; c++) {
+    const int b = c & 1, t0 = c * chunk, cnt = std::min(chunk, n_sweeps - t0);
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->rp_filt[b], 0));
+    for (int t = 0; t < cnt; t++) {  // odometrykeyframefuser.cpp:143-259 sweep after sweep, nothing but launches
+      OP.records = records ? o->d_records + (size_t)(t0 + t) * o->B : nullptr;
+      odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
+    }
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_used[b], ctx->stream));
+    o->rp_used_pending[b] = true;
+    o->step_no += cnt;
+    if (c + 1 < nchunks && (rc = stage(c + 1)) != CFEAR_OK) return rc;  // (queued after this chunk's launches: a copy from pageable memory blocks the host)
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (records) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(records, o->d_records, sizeof(cfear_sweep_record) * (size_t)n_sweeps * o->B, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
 }
 
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {

@@ -13,6 +13,7 @@
  */
 #ifndef CFEAR_HIP_H
 #define CFEAR_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -243,6 +244,30 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt)
 /* Last Register() summary / cell count / keyframe count of one sequence (debug + parity tests). */
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);
+
+/* ---- Replay of a recording: the loop of offline_odometry.cpp:103-125 (read a sweep, radarDriver::CallbackOffline,
+ * OdometryKeyframeFuser::pointcloudCallback, keep the pose) for n_sweeps consecutive sweeps without a host round trip per
+ * sweep. h_frames: n_sweeps x n_sequences x A x R bytes (sweep-major: sweep t of every sequence, then sweep t + 1). The sweeps
+ * are copied and filtered in chunks on a stream of their own, two chunks in flight (the filter needs nothing but its input,
+ * radar_driver.cpp:58), while features -> registration run sweep after sweep on the context stream; what a caller of
+ * pointcloudCallback could observe after every sweep is kept on the device and comes back once, at the end. The state of
+ * `odo` carries over between calls (and to / from cfear_odometry_step_*): a long recording may be handed over in pieces.
+ * Synchronous: returns when the last sweep is done. Copies from pinned memory (cfear_host_alloc) overlap with the kernels;
+ * from pageable memory the call still works, each chunk's copy then holds the calling thread. */
+typedef struct cfear_sweep_record {
+  double pose[3];             /* Tcurrent after the sweep (x, y, theta) */
+  double final_cost;          /* summary_.final_cost of the sweep's Register() (0 for the first sweep) */
+  int32_t outer_iterations;   /* as cfear_reg_summary */
+  int32_t num_residuals;
+  int32_t n_keyframes;        /* keyframes after the sweep (odometrykeyframefuser.cpp:470-476) */
+  int32_t n_cells;            /* oriented surface points of the sweep's scan */
+  int32_t inner_iterations[8];/* summary_.iterations.size() of the first 8 outer iterations */
+} cfear_sweep_record;
+int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_frames, int n_sweeps,
+                               cfear_sweep_record* records /* n_sweeps x n_sequences, or NULL */);
+/* Page-locked host memory for the sweeps of a replay (hipHostMalloc / hipHostFree). */
+int cfear_host_alloc(cfear_ctx* ctx, size_t bytes, void** out);
+void cfear_host_free(cfear_ctx* ctx, void* p);
 
 /* Filter-kernel timing with HIP events (bench.py roofline leg): enable, run steps, read. filter_seconds is the sum
  * of the durations of the filter launches, each measured on the stream it ran on. The events come from a pool created

@@ -1,0 +1,36 @@
+"""BASELINE configs[4] at its stated length and on driving-like motion (offline_odometry.cpp:73-141 replays ~10 k sweeps of one
+car recording): a 10 000-sweep synthetic drive at the Oxford shape (400 x 3768, range_res 0.0438) through a yard of buildings -
+stops of 20-40 sweeps (no new keyframe, zero-motion compensation), crawling at 0.2 m/sweep, ramps up to 3.5 m/sweep (a keyframe
+every sweep), corners at up to 0.15 rad/sweep, reversing - plus shorter drives through a street canyon (>= 500 oriented surface
+points per sweep, several echoes per azimuth) and an open field (marginal registrations). The recording goes through
+cfear_odometry_replay_host (no host round trip per sweep) and through the oracle's fuser: keyframe count, outer / inner
+iteration counts, residual count and cell count of EVERY sweep, every pose (1e-4 m / 1e-5 rad) and the KITTI drift (1e-6) must
+agree (odometrykeyframefuser.cpp:62-94,143-259)."""
+import os
+
+import numpy as np
+import pytest
+
+import drive_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind,sweeps,min_cells", [("blocks", 10000, 150), ("canyon", 2000, 500), ("field", 2000, 0)])
+def test_drive_replay_matches_oracle_at_every_sweep(oracle, kind, sweeps, min_cells):
+    T = int(os.environ.get("CFEAR_DRIVE_SWEEPS_" + kind.upper(), str(sweeps)))
+    out = drive_parity.run(oracle, T, kind)
+    reg = drive_parity.regimes(out["motions"])
+    if T >= 2000:  # the schedule really visits every regime
+        assert reg["stopped"].sum() >= 100 and reg["reverse"].sum() >= 50 and reg["fast"].sum() >= 50 and reg["turn"].sum() >= 30 and reg["crawl"].sum() >= 50
+    m = out["mismatches"]
+    assert not m, "%d sweeps disagree; first (sweep, what, device, oracle): %r" % (len(m), m[:3])
+    assert np.median(out["cells"]) >= min_cells
+    d, c = out["drift_dev"], out["drift_cpu"]
+    assert d["segments"] == c["segments"]
+    if d["segments"]:
+        assert abs(d["translation_percent"] - c["translation_percent"]) < 1e-6
+        assert abs(d["rotation_deg_per_100m"] - c["rotation_deg_per_100m"]) < 1e-6
+    if kind != "field":  # known answer: the odometry follows the ground truth (the open field is allowed to drift)
+        err = np.linalg.norm(out["poses_cpu"][:, :2] - out["gt"][:, :2], axis=1)
+        assert err.max() < 0.02 * np.abs(out["motions"][:, 0]).sum() + 2.0

@@ -71,3 +71,23 @@ def test_awkward_clouds_give_the_oracles_cells(oracle, name, res, df, wi):
         q = co["mean"][rng.integers(0, len(co), 100)] + rng.normal(0, 1.5, (100, 2))
         assert np.array_equal(sg.closest(q, 2.0), np.array([so.closest(x, y, 2.0) for x, y in q]))
     ctx.close()
+
+
+@pytest.mark.parametrize("df", [6.0, 10.0, 16.0])
+def test_dense_blob_with_a_large_downsample_factor(oracle, df):
+    """Hundreds of voxels that each see thousands of candidates: more than 2^16 chunks of 16 candidates. The chunk count
+    and the active-sample count used to share one packed scan with 16 bits each; the chunk count carried into the other
+    field and the chunk list ran past its array. Now the packed scan flags the overflow and the chunk size is doubled."""
+    rng = np.random.default_rng(11)
+    n = 4800
+    xyi = np.column_stack([rng.uniform(10.0, 13.0, n), rng.uniform(-4.0, -1.0, n), rng.integers(61, 256, n)]).astype(np.float32)
+    po, pg = mk(oracle, res=3.0, downsample_factor=df), mk(capi, res=3.0, downsample_factor=df)
+    ctx = capi.Context(pg, 400, 3360)
+    so = oracle.Scan(xyi, po)
+    sg = ctx.scan_create(ctx.cloud_upload(xyi))
+    co, cg = so.cells(), sg.cells()
+    assert len(cg) == len(co) and len(co) > 50, (len(cg), len(co))
+    for f in ("mean", "cov", "normal", "lambda_min", "lambda_max", "scale", "sum_intensity", "avg_intensity"):
+        assert np.allclose(cg[f], co[f], rtol=1e-9, atol=1e-9), f
+    assert np.array_equal(cg["nsamples"], co["nsamples"])
+    ctx.close()

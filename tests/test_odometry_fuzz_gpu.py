@@ -80,3 +80,32 @@ def test_pathological_sweeps_match_the_oracle_fuser(oracle, seqs, cost):
     assert strict["world"]
     odo.release()
     ctx.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 64])
+def test_batched_odometry_at_the_ends_of_the_k_range(oracle, k):
+    """k_strongest = 1 used to map every slot of the batched cloud pass to bearing 0 (the reciprocal of the slot -> bearing
+    division is 2^32 for k = 1 and did not fit); the per-call path divides and never showed it. Clouds (through the cell counts),
+    keyframes and poses of the batched path against the oracle's fuser at both ends of the supported range."""
+    imgs, _ = synth.world_sequence(6, seed=5, world_seed=77)
+    kw = dict(k_strongest=k, res=3.5)
+    po, pg = mk(oracle, **kw), mk(capi, **kw)
+    ctx = capi.Context(pg, 400, 3360)
+    odo = ctx.odometry(2)
+    fus = [oracle.Fuser(po), oracle.Fuser(po)]
+    streams = [imgs, imgs[::-1].copy()]
+    for t in range(6):
+        odo.step_host(np.stack([s[t] for s in streams]))
+        got = odo.poses()
+        for q in range(2):
+            exp = fus[q].process_polar(streams[q][t])
+            S, nc, nk = odo.summary(q)
+            So = fus[q].last_summary()
+            assert nc == len(fus[q].last_cells()), (k, t, q, nc, len(fus[q].last_cells()))
+            if t > 0 and So.num_residuals >= 30 and max(So.inner_iterations[:8]) <= 20:
+                assert (nk, S.outer_iterations, S.num_residuals) == (fus[q].num_keyframes, So.outer_iterations, So.num_residuals), (k, t, q)
+                assert np.all(np.abs(got[q][:2] - exp[:2]) < 1e-4) and abs(got[q][2] - exp[2]) < 1e-5, (k, t, q, got[q], exp)
+    if k > 1:
+        assert len(fus[0].last_cells()) > 20
+    odo.release()
+    ctx.close()
