@@ -65,8 +65,8 @@ struct cfear_cloud {  // pcl::PointCloud<pcl::PointXYZI> on the device
 };
 
 // cabi.hip
-extern "C" int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
+extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
 // pipeline.hip
-extern "C" int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);
+extern "C" __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);
 // kstrongest.hip
-int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);
+__attribute__((visibility("hidden"))) int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);

@@ -590,7 +590,7 @@ static int ensure_ctx_scratch(cfear_ctx* ctx, int cap_points, int pair_cap) {
 extern "C" {
 
 // ---- clouds ------------------------------------------------------------------------------------
-int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out) {
+__attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out) {
   cfear_cloud* c = new (std::nothrow) cfear_cloud();
   if (!c) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "cloud alloc");
   c->cap = cap > 0 ? cap : 1;
@@ -918,58 +918,54 @@ int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double
 
 // ---- cost-sampling covariance (odometrykeyframefuser.cpp:261-380) ------------------------------------
 namespace {
-// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 10): A = V diag(w) V^T
-void jacobi_sym(int n, double* A, double* V, double* w) {
+// Minimum-norm least squares of A c = b (A: m x 10), what Eigen's bdcSvd().solve() returns (odometrykeyframefuser.cpp:337), by a
+// one-sided Jacobi (Hestenes) singular value decomposition: plane rotations from the right make the columns of W = A V
+// mutually orthogonal; then the singular values are the column norms, U = W / sigma, and c = V diag(1 / sigma) U^T b over the
+// singular values above the rank threshold (Eigen's default: max(m, n) * epsilon * sigma_max). Works on A itself - no normal
+// equations - so nothing is lost to squaring the condition number (the yaw column is ~1e-5 of the others).
+static void lstsq10_svd(int m, const double* A, const double* b, double c[10]) {
+  const int n = 10;
+  std::vector<double> W((size_t)m * n);
+  double V[100];
+  for (int i = 0; i < m * n; i++) W[i] = A[i];
   for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; sweep++) {
-    double off = 0;
-    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n; p++)
+    bool rotated = false;
+    for (int p = 0; p < n - 1; p++)
       for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-        for (int k = 0; k < n; k++) { const double x = A[k * n + p], y = A[k * n + q]; A[k * n + p] = c * x - sn * y; A[k * n + q] = sn * x + c * y; }
-        for (int k = 0; k < n; k++) { const double x = A[p * n + k], y = A[q * n + k]; A[p * n + k] = c * x - sn * y; A[q * n + k] = sn * x + c * y; }
-        for (int k = 0; k < n; k++) { const double x = V[k * n + p], y = V[k * n + q]; V[k * n + p] = c * x - sn * y; V[k * n + q] = sn * x + c * y; }
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < m; i++) { const double x = W[(size_t)i * n + p], y = W[(size_t)i * n + q]; al += x * x; be += y * y; ga += x * y; }
+        if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+        rotated = true;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < m; i++) {
+          const double x = W[(size_t)i * n + p], y = W[(size_t)i * n + q];
+          W[(size_t)i * n + p] = cs * x - sn * y; W[(size_t)i * n + q] = sn * x + cs * y;
+        }
+        for (int i = 0; i < n; i++) {
+          const double x = V[i * n + p], y = V[i * n + q];
+          V[i * n + p] = cs * x - sn * y; V[i * n + q] = sn * x + cs * y;
+        }
       }
+    if (!rotated) break;
   }
-  for (int i = 0; i < n; i++) w[i] = A[i * n + i];
-}
-// minimum-norm least squares of A c = b (A: m x 10), what Eigen's bdcSvd().solve() returns (:337): unit-norm columns,
-// eigen-decomposition of the scaled normal matrix, pseudo-inverse
-void lstsq10(int m, const double* A, const double* b, double c[10]) {
-  double scale[10], N[100], V[100], w[10], rhs[10], y[10];
-  for (int j = 0; j < 10; j++) {
+  double sig[10], smax = 0;
+  for (int j = 0; j < n; j++) {
     double q = 0;
-    for (int i = 0; i < m; i++) q += A[i * 10 + j] * A[i * 10 + j];
-    scale[j] = q > 0 ? 1.0 / sqrt(q) : 0.0;
+    for (int i = 0; i < m; i++) q += W[(size_t)i * n + j] * W[(size_t)i * n + j];
+    sig[j] = sqrt(q);
+    if (sig[j] > smax) smax = sig[j];
   }
-  for (int j = 0; j < 10; j++) {
-    for (int k = 0; k < 10; k++) {
-      double q = 0;
-      for (int i = 0; i < m; i++) q += A[i * 10 + j] * A[i * 10 + k];
-      N[j * 10 + k] = q * scale[j] * scale[k];
-    }
+  const double thr = (double)(m > n ? m : n) * 2.220446049250313e-16 * smax;
+  for (int k = 0; k < n; k++) c[k] = 0.0;
+  for (int j = 0; j < n; j++) {
+    if (!(sig[j] > thr)) continue;
     double q = 0;
-    for (int i = 0; i < m; i++) q += A[i * 10 + j] * b[i];
-    rhs[j] = q * scale[j];
-  }
-  jacobi_sym(10, N, V, w);
-  double wmax = 0;
-  for (int j = 0; j < 10; j++) if (w[j] > wmax) wmax = w[j];
-  for (int j = 0; j < 10; j++) {
-    double q = 0;
-    for (int k = 0; k < 10; k++) q += V[k * 10 + j] * rhs[k];
-    y[j] = (w[j] > 1e-12 * wmax) ? q / w[j] : 0.0;
-  }
-  for (int k = 0; k < 10; k++) {
-    double q = 0;
-    for (int j = 0; j < 10; j++) q += V[k * 10 + j] * y[j];
-    c[k] = q * scale[k];
+    for (int i = 0; i < m; i++) q += W[(size_t)i * n + j] * b[i];  // sigma_j * (u_j . b)
+    q /= sig[j] * sig[j];
+    for (int k = 0; k < n; k++) c[k] += V[k * n + j] * q;
   }
 }
 static void linspace(double start, double end, int num, std::vector<double>& v) {  // odometrykeyframefuser.cpp:497-524
@@ -1041,20 +1037,22 @@ int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const
   for (int i = 0; i < m; i++) { if (nres[i] >= 0) last = costs[i]; costs[i] = last; }
   if (sample_costs) memcpy(sample_costs, costs.data(), sizeof(double) * m);
   double c[10];
-  lstsq10(m, A.data(), costs.data(), c);
-  double H[9] = {2 * c[0], c[3], c[5], c[3], 2 * c[1], c[4], c[5], c[4], 2 * c[2]};  // :340-343
-  double V[9], w[3];
-  jacobi_sym(3, H, V, w);
-  if (!(w[0] > 0.0 && w[1] > 0.0 && w[2] > 0.0)) return CFEAR_OK;  // not convex: sampling not used for this scan (:355-358)
+  lstsq10_svd(m, A.data(), costs.data(), c);
+  const double H[9] = {2 * c[0], c[3], c[5], c[3], 2 * c[1], c[4], c[5], c[4], 2 * c[2]};  // :340-343
+  // "all eigenvalues positive" (:355-358) of a symmetric matrix = positive definite = all leading principal minors positive
+  // (Sylvester); the inverse by cofactors, as Eigen's Matrix3d::inverse() (:363)
+  const double C00 = H[4] * H[8] - H[5] * H[7], C01 = H[5] * H[6] - H[3] * H[8], C02 = H[3] * H[7] - H[4] * H[6];
+  const double det = H[0] * C00 + H[1] * C01 + H[2] * C02;
+  const double minor2 = H[0] * H[4] - H[1] * H[3];
+  if (!(H[0] > 0.0 && minor2 > 0.0 && det > 0.0)) return CFEAR_OK;  // not convex: sampling not used for this scan
   if (num_residuals - 3 == 0) return CFEAR_OK;                      // GetCovarianceScaler false (n_scan_normal.cpp:435-441)
   const double score_scale = final_cost / (double)(num_residuals - 3);
+  const double id = 1.0 / det;
+  const double Hi[9] = {C00 * id, (H[2] * H[7] - H[1] * H[8]) * id, (H[1] * H[5] - H[2] * H[4]) * id,
+                        C01 * id, (H[0] * H[8] - H[2] * H[6]) * id, (H[2] * H[3] - H[0] * H[5]) * id,
+                        C02 * id, (H[1] * H[6] - H[0] * H[7]) * id, minor2 * id};
   double C3[9];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) {
-      double q = 0;
-      for (int t = 0; t < 3; t++) q += V[i * 3 + t] * V[j * 3 + t] / w[t];
-      C3[i * 3 + j] = 2.0 * q * score_scale * covariance_scaler;  // :363
-    }
+  for (int i = 0; i < 9; i++) C3[i] = 2.0 * Hi[i] * score_scale * covariance_scaler;  // :363
   for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0;  // :366-373
   cov6[0] = C3[0]; cov6[1] = C3[1]; cov6[6] = C3[3]; cov6[7] = C3[4];
   cov6[35] = C3[8]; cov6[5] = C3[2]; cov6[11] = C3[5]; cov6[30] = C3[6]; cov6[31] = C3[7];

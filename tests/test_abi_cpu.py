@@ -22,6 +22,11 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for n in names:
         assert hasattr(hip_lib, n), "missing export %s" % n
     assert set(capi.EXPORTS) == set(names)
+    # and nothing else: internal helpers (cross-file launchers, least squares) stay out of the dynamic symbol table
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.lib_path()]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_pod_layouts_and_defaults_match_oracle(hip_lib, oracle):

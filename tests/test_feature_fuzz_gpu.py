@@ -73,7 +73,7 @@ def test_awkward_clouds_give_the_oracles_cells(oracle, name, res, df, wi):
     ctx.close()
 
 
-@pytest.mark.parametrize("df", [6.0, 10.0, 16.0])
+@pytest.mark.parametrize("df", [6.0, 16.0, 24.0])
 def test_dense_blob_with_a_large_downsample_factor(oracle, df):
     """Hundreds of voxels that each see thousands of candidates: more than 2^16 chunks of 16 candidates. The chunk count
     and the active-sample count used to share one packed scan with 16 bits each; the chunk count carried into the other
@@ -86,7 +86,7 @@ def test_dense_blob_with_a_large_downsample_factor(oracle, df):
     so = oracle.Scan(xyi, po)
     sg = ctx.scan_create(ctx.cloud_upload(xyi))
     co, cg = so.cells(), sg.cells()
-    assert len(cg) == len(co) and len(co) > 50, (len(cg), len(co))
+    assert len(cg) == len(co) and len(co) > 30, (len(cg), len(co))
     for f in ("mean", "cov", "normal", "lambda_min", "lambda_max", "scale", "sum_intensity", "avg_intensity"):
         assert np.allclose(cg[f], co[f], rtol=1e-9, atol=1e-9), f
     assert np.array_equal(cg["nsamples"], co["nsamples"])
