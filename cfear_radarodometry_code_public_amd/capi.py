@@ -172,7 +172,7 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP = 1, 2, 3
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX = 1, 2, 3, 4
 
 
 class Context:

@@ -16,102 +16,9 @@
 #include <new>
 
 #include "common.h"
-#include "registration_dev.h"
-#include "features_compact_dev.h"
-
-using namespace cfear_dev;
+#include "odometry_step_dev.h"
 
 namespace {
-
-constexpr int BLOCK_F = 512;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
-constexpr int BLOCK_R = 256;   // registration kernels: 4 waves = one per SIMD
-static_assert(BLOCK_R == CFEAR_REG_BLOCK, "registration_dev.h is compiled for this workgroup size");
-static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
-constexpr int MAX_SCANS = 64;  // keyframes + current
-static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit");
-struct RegLds {  // registration kernels
-  static constexpr size_t red_d = 0;                                  // 10 sums x CFEAR_RED_STRIDE waves
-  static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*MAX_SCANS doubles
-  static constexpr size_t red_i = par + 3 * MAX_SCANS * sizeof(double);  // 64 ints
-  static constexpr size_t scanptr = red_i + 64 * sizeof(int);        // MAX_SCANS pointers
-  static constexpr size_t regsh = scanptr + MAX_SCANS * sizeof(void*);  // RegShared
-  static constexpr size_t total = (regsh + sizeof(RegShared) + 15) / 16 * 16;
-};
-
-static_assert(RegLds::total + sizeof(double) * 8 * CFEAR_MATCH_LDS_CAP <= 53760,
-              "registration kernels: more than 53,760 B of LDS costs the third workgroup per compute unit");
-
-// Global per-sequence working memory (also one per context for the per-call API).
-struct BlockScratch {
-  uint64_t* keys; float* spts; int* order; int* vstart; int* vlist;  // big-cloud fallbacks of the LDS arrays
-  int* vcur;        // [GRID_CAP + 2]
-  int* rng;         // [cap_points][8] candidate row ranges per sample point
-  double* part;     // [7][cap_points] partial cell moments per candidate chunk
-  int* tmpi;        // [2 * cap_points + 16]
-  float* samples;   // [cap_points * 3]
-  double* match;    // [8][pair_cap]
-  int* assoc;       // [pair_cap]
-  int cap_points, p2cap, pair_cap;
-};
-
-struct SeqState {  // OdometryKeyframeFuser members (odometrykeyframefuser.h:203-260) for one sequence
-  Aff2 T_prev, Tmot, Tcurrent;
-  int nkf, free_slot, frames, last_slot;
-  int ring[MAX_SCANS];
-  Aff2 kf_pose[MAX_SCANS];
-};
-
-struct OdoParams {
-  FeatureParams fp;
-  RegParams rp;
-  int A, k, compensate, ccw, use_keyframe, submap;
-  double min_keyframe_dist, min_keyframe_rot_deg;
-  long long* phase_times;  // optional [B][32] wall_clock64 ticks (tools/)
-  long long* wg_times;     // optional [B][32]: start / end clock of every workgroup of the PRODUCTION kernels (slots 0, 1 features;
-                           // 14, 15 registration) - two clock reads per workgroup, off the critical path
-  int phase_detail;        // also accumulate the evaluation / controller times of every LM command (three clock reads per command:
-                           // the registration kernel runs at half speed with them)
-  int seq0;  // first sequence of this launch (sub-batches run on their own streams)
-  // the scan slots of all sequences are one allocation, slot j of sequence q at scans_base + scan_stride * (q * (submap + 1) + j):
-  // computed, not fetched from the pointer table (a memory round trip at the start of both kernels)
-  unsigned char* scans_base; size_t scan_stride;
-  cfear_sweep_record* records;  // optional [B]: this sweep's record of every sequence (cfear_odometry_replay_host)
-};
-
-__device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
-
-// working memory of one feature build: global arrays of the general path (clouds beyond the compact path's limits) + the two
-// LDS reduction arrays
-__device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, unsigned char* lds) {
-  FeatureScratch W;
-  W.keys = B.keys; W.spts = B.spts; W.order = B.order; W.vstart = B.vstart; W.vlist = B.vlist;
-  W.vcur = B.vcur; W.lds = false; W.tab_voxels = 0;
-  W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
-  W.cap = B.cap_points;
-  W.samples = B.samples;
-  W.red_i = reinterpret_cast<int*>(lds + FeatLdsC::red_i);
-  W.red_f = reinterpret_cast<float*>(lds + FeatLdsC::red_f);
-  return W;
-}
-// byte_intensities: every intensity of the cloud is an integer in 0..255 (block-uniform; always true for clouds made from
-// the filter's slots) - the compact path keeps them as bytes
-__device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
-                                                  unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities,
-                                                  const PointRegs& PR) {
-  const FeatureScratch W = make_fscratch(B, lds);
-  if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR)) return;
-  features_block(S, n, P, W, next_pow2(n), pt, bounds);
-}
-__device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
-  RegScratch W;
-  const size_t c = (size_t)B.pair_cap;
-  W.tmx = B.match; W.tmy = B.match + c; W.a0 = B.match + 2 * c; W.a1 = B.match + 3 * c; W.a2 = B.match + 4 * c;
-  W.sx = B.match + 5 * c; W.sy = B.match + 6 * c; W.w = B.match + 7 * c;
-  W.assoc = B.assoc; W.cap = B.pair_cap;
-  W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
-  W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
-  return W;
-}
 
 // ---- per-call kernels -------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK_F) void cloud_kernel(const uint32_t* slots, int A, int k, const double* trig, float rr,
@@ -212,150 +119,22 @@ __global__ __launch_bounds__(BLOCK_R, 3) void get_cost_samples_kernel(ScanDev* c
                  costs + b, nullptr, 0, n_res + b);
 }
 
-// ---- batched odometry: OdometryKeyframeFuser::processFrame (odometrykeyframefuser.cpp:143-259) with all
-// state on the device, split after the feature build (:161) ------------------------------------------
+// ---- batched odometry: one launch per stage and sweep (bodies: odometry_step_dev.h) ----
 // TIMED: per-phase timestamps (tools/); the production instantiation carries no timer at all
 template <bool TIMED>
 __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_t* slots_all, const double* trig, OdoParams OP,
                                                                    const SeqState* states, ScanDev* const* scan_slots,
                                                                    const BlockScratch* scratch) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
-  const int q = OP.seq0 + blockIdx.x;
-  const SeqState* st = &states[q];
-  const BlockScratch B = scratch[q];
-  ScanDev* cur = reinterpret_cast<ScanDev*>(OP.scans_base + OP.scan_stride * ((size_t)q * (OP.submap + 1) + st->free_slot));
-  const Aff2 TprevMot = st->Tmot;  // :146
-  PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 : nullptr; pt.n = 0; pt.cap = 14; pt.acc = nullptr;
-  if (TIMED) pt.mark();
-  if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32] = (long long)wall_clock64();
-  // the voxel bitmap starts all-zero (cleared here: the barriers of the cloud pass publish it)
-  {
-    uint32_t* z = reinterpret_cast<uint32_t*>(lds + FeatLdsC::bm);
-    for (int i = threadIdx.x; i < (int)((FeatLdsC::bmp - FeatLdsC::bm) / 4); i += BLOCK_F) z[i] = 0u;
-  }
-  // stage 1 (second half) + 1.5: slots -> cloud (radar_driver.cpp:59), motion compensation (:147-150), bounding box
-  double mot[3]; aff_to_xyt(TprevMot, mot);
-  float bounds[4];
-  PointRegs PR;
-  const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
-                                 cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
-                                 reinterpret_cast<int*>(lds + FeatLdsC::red_i), reinterpret_cast<float*>(lds + FeatLdsC::red_f),
-                                 reinterpret_cast<double*>(lds + FeatLdsC::pxy),  // 6 doubles per bearing where the sorted points go later
-                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds, PR);
-  if (TIMED) { pt.mark(); pt.mark(); }
-  CFEAR_STOP_AT(1, );
-  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR);  // :161
-  if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
+  features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
-
 template <bool TIMED>
 __global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  const int q = OP.seq0 + blockIdx.x, tid = threadIdx.x;
-  SeqState* st = &states[q];
-  const BlockScratch B = scratch[q];
-  const int nslots = OP.submap + 1;
-  auto slot_ptr = [&](int j) -> ScanDev* { return reinterpret_cast<ScanDev*>(OP.scans_base + OP.scan_stride * ((size_t)q * nslots + j)); };
-  const int cur_slot = st->free_slot;
-  ScanDev* cur = slot_ptr(cur_slot);
-  const Aff2 T_prev = st->T_prev, TprevMot = st->Tmot;
-  const int nkf = st->nkf;
-  // this thread's keyframe (threads below nkf), read with the rest of the state: one round trip, before the barrier
-  const int my_ring = st->ring[tid < MAX_SCANS ? tid : 0];
-  const Aff2 my_kf_pose = st->kf_pose[tid < MAX_SCANS ? tid : 0];
-  PhaseTimer pt; pt.t = (TIMED && OP.phase_times) ? OP.phase_times + (size_t)q * 32 + 14 : nullptr; pt.n = 0; pt.cap = 15;
-  pt.acc = (TIMED && OP.phase_times && OP.phase_detail) ? OP.phase_times + (size_t)q * 32 + 29 : nullptr;
-  pt.acc2 = (TIMED && OP.phase_times && OP.phase_detail == 2) ? OP.phase_times + (size_t)q * 32 : nullptr;  // (over the feature kernel's stamps)
-  if (TIMED && pt.acc2 && tid == 0) for (int i = 0; i < 8; i++) pt.acc2[i] = 0;
-  if (TIMED) pt.mark();
-  if (!TIMED && OP.wg_times && tid == 0) OP.wg_times[(size_t)q * 32 + 14] = (long long)wall_clock64();
-  const Aff2 Tguess = aff_mul(T_prev, TprevMot);  // :166
-  cfear_reg_summary* sum = &summaries[q];
-  __syncthreads();  // every thread has read the state before thread 0 rewrites it
-  if (nkf == 0) {  // :171-177
-    if (tid == 0) {
-      st->ring[0] = cur_slot; st->kf_pose[0] = aff_identity(); st->nkf = 1; st->free_slot = (cur_slot + 1) % nslots;
-      st->frames++; st->last_slot = cur_slot;
-      sum->success = 0; sum->usable = 0; sum->outer_iterations = 0; sum->num_residuals = 0; sum->num_residual_blocks = 0;
-      double v[3]; aff_to_xyt(st->Tcurrent, v);
-      poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
-      if (OP.records) {
-        cfear_sweep_record* r = OP.records + q;
-        r->pose[0] = v[0]; r->pose[1] = v[1]; r->pose[2] = v[2]; r->final_cost = 0;
-        r->outer_iterations = 0; r->num_residuals = 0; r->n_keyframes = 1; r->n_cells = cur->n_cells;
-        for (int i = 0; i < 8; i++) r->inner_iterations[i] = 0;
-      }
-    }
-    return;
-  }
-  // FormatScans (:478-494)
-  ScanDev** sp = reinterpret_cast<ScanDev**>(lds + RegLds::scanptr);
-  double* poses = reinterpret_cast<double*>(lds + RegLds::par);  // the registration's parameter array itself: the poses never go through memory
-  const int ns = nkf + 1;
-  if (tid < nkf) {
-    sp[tid] = slot_ptr(my_ring);
-    double v[3]; aff_to_xyt(my_kf_pose, v);
-    poses[3 * tid] = v[0]; poses[3 * tid + 1] = v[1]; poses[3 * tid + 2] = v[2];
-  }
-  if (tid == 0) {
-    sp[ns - 1] = cur;
-    double v[3]; aff_to_xyt(Tguess, v);
-    poses[3 * (ns - 1)] = v[0]; poses[3 * (ns - 1) + 1] = v[1]; poses[3 * (ns - 1) + 2] = v[2];
-  }
-  __syncthreads();
-  const RegScratch RW = make_rscratch(B, lds);
-  register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),
-                 reinterpret_cast<RegShared*>(lds + RegLds::regsh), sum, TIMED ? &pt : nullptr);  // :186 (result ignored, :184-186)
-  __syncthreads();
-  if (TIMED) pt.mark();
-  if (tid == 0) {
-    Aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]);  // :195
-    const Aff2 Tpi = aff_inv(T_prev);
-    const Aff2 Tmot_current = aff_mul(Tpi, Tcurrent);
-    {  // AccelerationVelocitySanityCheck (:76-94)
-      const double dt = 0.25, lim = 200;
-      const double vel = sqrt(Tmot_current.t0 * Tmot_current.t0 + Tmot_current.t1 * Tmot_current.t1) / dt;
-      const double ax = (Tmot_current.t0 - TprevMot.t0) / (dt * dt), ay = (Tmot_current.t1 - TprevMot.t1) / (dt * dt);
-      const double acc = sqrt(ax * ax + ay * ay);
-      if (acc > lim || vel > lim) Tcurrent = Tguess;  // :198-199
-    }
-    st->Tmot = aff_mul(Tpi, Tcurrent);  // :200
-    st->Tcurrent = Tcurrent;
-    const Aff2 Tkeydiff = aff_mul(aff_inv(st->kf_pose[nkf - 1]), Tcurrent);  // :227
-    bool fuse = true;
-    if (OP.use_keyframe) {  // KeyFrameBasedFuse (:62-73)
-      const double tn = sqrt(Tkeydiff.t0 * Tkeydiff.t0 + Tkeydiff.t1 * Tkeydiff.t1);
-      const double rot = fabs(atan2(Tkeydiff.l2, Tkeydiff.l3));
-      fuse = (tn > OP.min_keyframe_dist) || (rot > OP.min_keyframe_rot_deg * 3.14159265358979323846 / 180.0);
-    }
-    if (fuse) {  // AddToReference (:470-476)
-      int m = nkf;
-      st->ring[m] = cur_slot; st->kf_pose[m] = Tcurrent; m++;
-      int freed;
-      if (m > OP.submap) {
-        freed = st->ring[0];
-        for (int i = 0; i + 1 < m; i++) { st->ring[i] = st->ring[i + 1]; st->kf_pose[i] = st->kf_pose[i + 1]; }
-        m--;
-      } else {
-        freed = m;  // slots are handed out in increasing order until the ring is full
-      }
-      st->nkf = m; st->free_slot = freed;
-    }
-    st->T_prev = Tcurrent;  // :257
-    st->frames++; st->last_slot = cur_slot;
-    double v[3]; aff_to_xyt(Tcurrent, v);
-    poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
-    if (OP.records) {  // what a caller of pointcloudCallback sees after this sweep, kept per sweep (no host round trip in a replay)
-      cfear_sweep_record* r = OP.records + q;
-      r->pose[0] = v[0]; r->pose[1] = v[1]; r->pose[2] = v[2]; r->final_cost = sum->final_cost;
-      r->outer_iterations = sum->outer_iterations; r->num_residuals = sum->num_residuals; r->n_keyframes = st->nkf; r->n_cells = cur->n_cells;
-      for (int i = 0; i < 8; i++) r->inner_iterations[i] = sum->inner_iterations[i];
-    }
-    if (!TIMED && OP.wg_times) OP.wg_times[(size_t)q * 32 + 15] = (long long)wall_clock64();
-  }
+  register_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
 }
 
 // ---- host-side helpers ---------------------------------------------------------------------------
@@ -541,6 +320,12 @@ static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
   }
   return CFEAR_OK;
 }
+
+// replay.hip: features -> registration of `cnt` consecutive sweeps of every sequence in one launch (a persistent workgroup per
+// sequence); odo_params points at an OdoParams (the struct is local to each translation unit, same definition)
+__attribute__((visibility("hidden"))) void cfear_launch_replay_chunk(const uint32_t* d_slots, int cnt, int B, const double* d_trig, const void* odo_params,
+                                                                    void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
+                                                                    double* poses_out, cfear_sweep_record* records, hipStream_t stream);
 
 // the kernel parameters of one odometry step of `o` under the context's current settings
 static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
@@ -1400,6 +1185,7 @@ int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   chunk = std::min(o->rp_chunk, n_sweeps);
   const int nchunks = (n_sweeps + chunk - 1) / chunk;
   OdoParams OP = odo_params(ctx, o);
+  const bool persistent = o->B <= ctx->tune_replay_persistent_max && !OP.phase_times && !OP.wg_times;
   auto stage = [&](int c) -> int {  // copy + filter of chunk c on the replay stream
     const int b = c & 1, t0 = c * chunk, cnt = std::min(chunk, n_sweeps - t0);
     if (o->rp_used_pending[b]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(o->rp_stream, o->rp_used[b], 0));  // its slots were consumed
@@ -1414,9 +1200,17 @@ int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   for (int c = 0; c < nchunks; c++) {
     const int b = c & 1, t0 = c * chunk, cnt = std::min(chunk, n_sweeps - t0);
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->rp_filt[b], 0));
-    for (int t = 0; t < cnt; t++) {  // odometrykeyframefuser.cpp:143-259 sweep after sweep, nothing but launches
-      OP.records = records ? o->d_records + (size_t)(t0 + t) * o->B : nullptr;
-      odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
+    // odometrykeyframefuser.cpp:143-259 sweep after sweep. Few sequences: one persistent workgroup per sequence walks the whole
+    // chunk (no launch in between; a workgroup needs a compute unit's LDS to itself, so this pays while the sequences fit the
+    // chip at one per compute unit). Many sequences: the batched kernels, two launches per sweep, whose occupancy is what counts.
+    if (persistent) {
+      cfear_launch_replay_chunk(o->rp_slots[b], cnt, o->B, ctx->d_trig, &OP, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries,
+                                o->d_poses_out, records ? o->d_records + (size_t)t0 * o->B : nullptr, ctx->stream);
+    } else {
+      for (int t = 0; t < cnt; t++) {
+        OP.records = records ? o->d_records + (size_t)(t0 + t) * o->B : nullptr;
+        odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
+      }
     }
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_used[b], ctx->stream));
     o->rp_used_pending[b] = true;

@@ -134,9 +134,11 @@ struct SolveSummary { int num_iterations; int termination; double final_cost; do
 #define CFEAR_REG_MAX_SCANS 64
 #define CFEAR_RED_STRIDE 8  // partial sums of up to 8 waves per quantity (W.red)
 #define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
-#define CFEAR_REG_BLOCK 256 // threads of every workgroup that runs this code (pipeline.hip BLOCK_R): a compile-time constant,
+#ifndef CFEAR_REG_BLOCK
+#define CFEAR_REG_BLOCK 256 // threads of every workgroup that runs this code (pipeline.hip BLOCK_R; replay.hip compiles it for 512): a compile-time constant,
                             // because blockDim.x is a load from the dispatch packet - a round trip to memory wherever an
                             // out-of-line function asks for it (the evaluation did, thirteen times per registration)
+#endif
 
 enum { REG_CMD_BUILD = 1, REG_CMD_EVAL = 2, REG_CMD_DONE = 3 };
 enum { REG_ST_BUILD = 0, REG_ST_LM_IT0 = 1, REG_ST_LM_CAND = 2, REG_ST_COV = 3 };

@@ -81,8 +81,11 @@ int cfear_synchronize(cfear_ctx* ctx);
  * filter wave (default 4); ODOMETRY_OVERLAP = n (0..8): batched odometry objects created afterwards run the filter of a sweep
  * on a low-priority stream of their own, one sweep ahead, and the features / registration kernels of n contiguous ranges of
  * the sequences on n high-priority streams (0 = the three kernels strictly in turn on the context stream; DESIGN.md has the
- * measurements). */
-enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3 };
+ * measurements). REPLAY_PERSISTENT_MAX (default 256): cfear_odometry_replay_host runs up to this many sequences as persistent
+ * workgroups that walk a whole chunk of sweeps in one launch; more sequences (or 0) take the two launches per sweep of the
+ * batched step. */
+enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
+       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

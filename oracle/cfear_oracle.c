@@ -941,8 +941,11 @@ static void jacobi_sym(int n, double* A, double* V, double* w) {
   for (int i = 0; i < n; i++) w[i] = A[i * n + i];
 }
 
-/* minimum-norm least-squares solution of A c = b (A: m x 10), [3P] what Eigen's bdcSvd().solve() returns:
- * columns are scaled to unit norm, the scaled normal matrix is eigen-decomposed and pseudo-inverted */
+/* minimum-norm least-squares solution of A c = b (A: m x 10), [3P] what Eigen's bdcSvd().solve() returns. The columns differ
+ * by six orders of magnitude (yaw^2 ~ 5e-6 next to 1), so they are scaled to unit norm D before the normal matrix of A D is
+ * eigen-decomposed and pseudo-inverted: y0 = (A D)^+ b, c0 = D y0 is A least-squares solution. When A is rank deficient
+ * (samples_per_axis = 2: x^2, y^2, yaw^2 and 1 are parallel columns) the minimum-norm one is c0 + B z with B = D N, N the null
+ * space of A D, and z from the small problem min |c0 + B z| (normal equations B^T B z = -B^T c0, Gaussian elimination). */
 static void lstsq10(int m, const double* A, const double* b, double c[10]) {
   double scale[10], N[100], V[100], w[10], rhs[10];
   for (int j = 0; j < 10; j++) {
@@ -964,15 +967,43 @@ static void lstsq10(int m, const double* A, const double* b, double c[10]) {
   double wmax = 0;
   for (int j = 0; j < 10; j++) if (w[j] > wmax) wmax = w[j];
   double y[10];
+  int nullcol[10], p = 0;
   for (int j = 0; j < 10; j++) {
     double s = 0;
     for (int k = 0; k < 10; k++) s += V[k * 10 + j] * rhs[k];
-    y[j] = (w[j] > 1e-12 * wmax) ? s / w[j] : 0.0;
+    if (w[j] > 1e-12 * wmax) y[j] = s / w[j];
+    else { y[j] = 0.0; nullcol[p++] = j; }
   }
   for (int k = 0; k < 10; k++) {
     double s = 0;
     for (int j = 0; j < 10; j++) s += V[k * 10 + j] * y[j];
     c[k] = s * scale[k];
+  }
+  if (p > 0) { /* rank deficient: move along the null space to the shortest solution */
+    double B[100], M[100], g[10], z[10];
+    for (int k = 0; k < 10; k++) for (int a = 0; a < p; a++) B[k * 10 + a] = scale[k] * V[k * 10 + nullcol[a]];
+    for (int a = 0; a < p; a++) {
+      for (int q = 0; q < p; q++) { double s = 0; for (int k = 0; k < 10; k++) s += B[k * 10 + a] * B[k * 10 + q]; M[a * 10 + q] = s; }
+      double s = 0; for (int k = 0; k < 10; k++) s += B[k * 10 + a] * c[k];
+      g[a] = -s;
+    }
+    for (int a = 0; a < p; a++) { /* elimination with partial pivoting; a null direction made of all-zero columns drops out */
+      int piv = a;
+      for (int r = a + 1; r < p; r++) if (fabs(M[r * 10 + a]) > fabs(M[piv * 10 + a])) piv = r;
+      if (piv != a) { for (int q = 0; q < p; q++) { const double t = M[a * 10 + q]; M[a * 10 + q] = M[piv * 10 + q]; M[piv * 10 + q] = t; } const double t = g[a]; g[a] = g[piv]; g[piv] = t; }
+      if (fabs(M[a * 10 + a]) < 1e-300) continue;
+      for (int r = a + 1; r < p; r++) {
+        const double f = M[r * 10 + a] / M[a * 10 + a];
+        for (int q = a; q < p; q++) M[r * 10 + q] -= f * M[a * 10 + q];
+        g[r] -= f * g[a];
+      }
+    }
+    for (int a = p - 1; a >= 0; a--) {
+      double s = g[a];
+      for (int q = a + 1; q < p; q++) s -= M[a * 10 + q] * z[q];
+      z[a] = fabs(M[a * 10 + a]) < 1e-300 ? 0.0 : s / M[a * 10 + a];
+    }
+    for (int k = 0; k < 10; k++) { double s = 0; for (int a = 0; a < p; a++) s += B[k * 10 + a] * z[a]; c[k] += s; }
   }
 }
 

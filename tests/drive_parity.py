@@ -18,7 +18,7 @@ def regimes(motions):
     return {"stopped": v == 0, "crawl": (np.abs(v) > 0) & (np.abs(v) < 0.4), "reverse": v < 0, "fast": v > 3.0, "turn": np.abs(w) > 0.1}
 
 
-def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0, procs=None, log=None):
+def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0, procs=None, log=None, persistent_max=None):
     """-> dict(mismatches=[(sweep, what, device, oracle)], poses_dev, poses_cpu, gt, cells, seconds...)"""
     kw = dict(BASE)
     kw.update(params or {})
@@ -26,6 +26,8 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
     poses_w, motions, gt = synth.drive_plan(T, world, seed)
     fu = oracle.Fuser(oracle.default_params(**kw))
     ctx = capi.Context(capi.default_params(**kw), A, R, device=device)
+    if persistent_max is not None:
+        ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
     odo = ctx.odometry(1)
     buf = ctx.pinned((piece, 1, A, R))
     mism, dev_poses, cpu_poses, cells = [], [], [], []

@@ -67,6 +67,19 @@ def test_cov_by_sampling_matches_oracle(oracle, steps, xy, yaw, cost):
     assert ok_g == ok_o
     if ok_o:
         assert np.allclose(cov_g, cov_o, rtol=1e-5, atol=1e-12)
+    # independent statement of odometrykeyframefuser.cpp:277-373 in numpy on the device's own sampled costs (the library's least
+    # squares is a one-sided Jacobi SVD, the oracle's an eigen-decomposition of the normal matrix: neither is numpy's)
+    xs, ths = np.linspace(-xy / 2, xy / 2, steps), np.linspace(-yaw / 2, yaw / 2, steps)
+    rows = [[x * x, y * y, z * z, x * y, y * z, z * x, x, y, z, 1.0] for z in ths for x in xs for y in xs]
+    c = np.linalg.lstsq(np.array(rows), costs_g, rcond=None)[0]
+    H = np.array([[2 * c[0], c[3], c[5]], [c[3], 2 * c[1], c[4]], [c[5], c[4], 2 * c[2]]])
+    convex = bool(np.all(np.linalg.eigvalsh(H) > 0))
+    assert ok_g == (convex and S.num_residuals - 3 != 0)
+    if ok_g:
+        C3 = 2.0 * np.linalg.inv(H) * (S.final_cost / (S.num_residuals - 3)) * 4.0
+        exp = np.eye(6)
+        exp[:2, :2] = C3[:2, :2]; exp[5, 5] = C3[2, 2]; exp[0, 5] = C3[0, 2]; exp[1, 5] = C3[1, 2]; exp[5, 0] = C3[2, 0]; exp[5, 1] = C3[2, 1]
+        assert np.allclose(cov_g, exp, rtol=1e-6, atol=1e-14)
     ctx.close()
 
 

@@ -12,7 +12,9 @@ def main():
     import drive_parity
     from oracle import binding
     kind, T = sys.argv[1], int(sys.argv[2])
-    out = drive_parity.run(binding, T, kind, log=lambda s: print(s, flush=True))
+    pm = os.environ.get("CFEAR_REPLAY_PERSISTENT_MAX")
+    out = drive_parity.run(binding, T, kind, log=lambda s: print(s, flush=True), persistent_max=int(pm) if pm else None,
+                           piece=int(os.environ.get("CFEAR_REPLAY_PIECE", "250")))
     reg = drive_parity.regimes(out["motions"])
     bad = sorted(set(m[0] for m in out["mismatches"]))
     rep = {"kind": kind, "sweeps": T, "disagreeing_sweeps": len(bad), "first": [list(map(str, m)) for m in out["mismatches"][:20]],
