@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <fstream>
 
-#include "cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"
 
 using namespace CFEAR_Radarodometry;
 
@@ -66,6 +66,10 @@ int main(int argc, char** argv) {
     std::vector<Affine3d> T2 = T; std::vector<Matrix6d> cov2(3);
     for (int a = 0; a < 6; a++) cov2[2](a, a) = 0.05 * 0.05;
     const bool ok_soft = reg.Register(scans, T2, cov2, true);
+    // the two calls of odometrykeyframefuser.cpp that used to need an #if 0 (:191 summary_.FullReport(), :210 MapPointNormal::PublishMap)
+    const std::string report = reg.summary_.FullReport();
+    MapPointNormal::PublishMap("/current_normals", m, T1[2], "sensor_est", -1, 0.5);
+    if (report.find("outer iterations") == std::string::npos) throw std::runtime_error("FullReport is empty");
     std::printf("{\"points\": [%zu, %zu, %zu], \"cfar_points\": %zu, \"cfar_peaks\": %zu, \"cells\": [%zu, %zu, %zu], "
                 "\"cell0\": [%.12g, %.12g, %.12g, %.12g], \"closest_self\": %d, \"rel_time0\": %.12g, "
                 "\"tcell0\": [%.12g, %.12g, %.12g, %.12g, %.12g], "

@@ -3,7 +3,7 @@
 // usage: eval_kitti <gt.txt> <est.txt>
 #include <cstdio>
 
-#include "kitti_metric.hpp"
+#include "cfear_hip/kitti_metric.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: %s <gt.txt> <est.txt>\n", argv[0]); return 2; }

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"
 
 using namespace CFEAR_Radarodometry;
 
@@ -30,7 +30,9 @@ int main(int argc, char** argv) {
            "       [--min_distance 2.5] [--submap_scan_size 3] [--weight_intensity 1] [--k_strongest 12] [--z-min 65]\n"
            "       [--radar_ccw 0] [--disable_compensate 0] [--cost_type P2L] [--loss_type Huber] [--loss_limit 0.1]\n"
            "       [--covar_scale 1] [--regularization 1] [--weight_option 0] [--registered_min_keyframe_dist 1.5]\n"
-           "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR]\n");
+           "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR]\n"
+           "       [--replay 1]   whole recording through cfear_odometry_replay_host (pieces of 256 sweeps in pinned memory, no\n"
+           "                      host round trip per sweep) instead of one CallbackOffline + pointcloudCallback per sweep\n");
     return argc < 2;
   }
   const std::string frames = arg(argc, argv, "--frames", "");
@@ -70,6 +72,51 @@ int main(int argc, char** argv) {
   p.submap_scan_size = par.submap_scan_size;
   try {
     DevicePtr dev(new Device(p, A, R, atoi(arg(argc, argv, "--device", "0"))));
+    if (atoi(arg(argc, argv, "--replay", "0"))) {
+      // maximum-rate replay: the same parameters the two classes would apply, set once; the loop of offline_odometry.cpp:103-125
+      // runs on the device sweep after sweep, the poses of a piece come back together
+      cfear_params q = p;
+      q.z_min = rad_par.z_min; q.range_res = rad_par.range_res; q.min_distance = rad_par.min_distance; q.k_strongest = rad_par.k_strongest;
+      q.res = par.res; q.weight_intensity = par.weight_intensity_ ? 1 : 0; q.submap_scan_size = par.submap_scan_size;
+      const cost_metric cm = Str2Cost(par.cost_type);
+      q.cost = cm == P2L ? CFEAR_COST_P2L : (cm == P2D ? CFEAR_COST_P2D : CFEAR_COST_P2P);
+      q.loss = (int)Str2loss(par.loss_type_); q.loss_limit = par.loss_limit_; q.weight_opt = (int)par.weight_opt;
+      q.covar_scale = par.covar_scale_; q.regularization = par.regularization_;
+      q.compensate = par.compensate ? 1 : 0; q.radar_ccw = par.radar_ccw ? 1 : 0; q.min_keyframe_dist = par.min_keyframe_dist_;
+      dev->set_params(q);
+      cfear_odometry* odo = nullptr;
+      dev->check(cfear_odometry_create(dev->ctx(), 1, &odo), "cfear_odometry_create");
+      const int piece = 256;
+      const size_t sweep = (size_t)A * R;
+      void* pinned = nullptr;
+      dev->check(cfear_host_alloc(dev->ctx(), sweep * piece, &pinned), "cfear_host_alloc");
+      std::vector<cfear_sweep_record> rec(piece);
+      std::ofstream est(est_dir + "/est_00.txt");
+      est << std::fixed; est.precision(6);
+      int n = 0;
+      double t_dev = 0;
+      const auto t_start = std::chrono::steady_clock::now();
+      for (;;) {
+        in.read(static_cast<char*>(pinned), (std::streamsize)(sweep * piece));
+        const int got = (int)((size_t)in.gcount() / sweep);
+        if (got <= 0) break;
+        const auto t0 = std::chrono::steady_clock::now();
+        dev->check(cfear_odometry_replay_host(dev->ctx(), odo, static_cast<const uint8_t*>(pinned), got, rec.data()), "cfear_odometry_replay_host");
+        t_dev += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int i = 0; i < got; i++) {
+          const double c = std::cos(rec[i].pose[2]), sn = std::sin(rec[i].pose[2]);
+          est << c << " " << -sn << " 0.000000 " << rec[i].pose[0] << " " << sn << " " << c << " 0.000000 " << rec[i].pose[1] << " "
+              << "0.000000 0.000000 1.000000 0.000000\n";
+        }
+        n += got;
+        const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        std::cout << "Frame: " << n << ", avg: " << n / tot << " Hz (device part alone: " << n / t_dev << " Hz)" << std::endl;  // :125
+      }
+      std::cout << "frames " << n << std::endl;
+      cfear_host_free(dev->ctx(), pinned);
+      cfear_odometry_destroy(dev->ctx(), odo);
+      return 0;
+    }
     radarDriver driver(dev, rad_par, true);
     OdometryKeyframeFuser fuser(dev, par, true);
     std::vector<uint8_t> img((size_t)A * R);

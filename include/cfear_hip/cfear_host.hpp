@@ -20,10 +20,11 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <sstream>
 #include <string>
 #include <vector>
 
-#include "../../include/cfear_hip.h"
+#include "../cfear_hip.h"
 // The ROS / PCL / Eigen / OpenCV types crossing these interfaces come from one of two headers defining the same names and
 // adapter functions: include/cfear_radarodometry/cfear_types_ros.h (real types; included first by the drop-in headers of
 // that directory) or, in this image, the POD stand-ins:
@@ -291,6 +292,10 @@ class MapPointNormal {
   }
   ~MapPointNormal() { if (scan_) cfear_scan_release(dev_->ctx(), scan_); }
   MapPointNormal(const MapPointNormal&) = delete;
+  // RViz marker publisher of the reference (pointnormal.h:235, pointnormal.cpp:299-...): visualisation only, off the path - kept
+  // as a no-op so that odometrykeyframefuser.cpp:210 compiles unchanged
+  static void PublishMap(const std::string& topic, CFEAR_SHARED_PTR<MapPointNormal> map, const Affine3d& T, const std::string& frame_id,
+                         const int value = 0, float alpha = 1.0) { (void)topic; (void)map; (void)T; (void)frame_id; (void)value; (void)alpha; }
   size_t GetSize() { int n = 0; dev_->check(cfear_scan_size(dev_->ctx(), scan_, &n), "cfear_scan_size"); return (size_t)n; }
   std::vector<cell> GetCells() { fetch(); return cells_; }
   cell& GetCell(const size_t i) { fetch(); return cells_[i]; }
@@ -397,6 +402,27 @@ class MapPointNormal {
 };
 inline double MapPointNormal::downsample_factor = 1;
 
+// What reference code reads of ceres::Solver::Summary through n_scan_normal_reg::summary_ (registration.h:110):
+// final_cost, num_residuals, iterations, and - at odometrykeyframefuser.cpp:191 - FullReport() for the failure message.
+struct RegSummary : cfear_reg_summary {
+  RegSummary() : cfear_reg_summary() {}
+  bool IsSolutionUsable() const { return usable != 0; }
+  std::string BriefReport() const {
+    std::ostringstream o;
+    o << "CFEAR-HIP report: outer iterations " << outer_iterations << ", residuals " << num_residuals << " in " << num_residual_blocks
+      << " blocks, final cost " << final_cost << ", " << (usable ? "usable" : "NOT usable");
+    return o.str();
+  }
+  std::string FullReport() const {
+    std::ostringstream o;
+    o << "\n" << BriefReport() << "\nouter  inner  termination  cost  pose\n";
+    for (int i = 0; i < outer_iterations - 1 && i < CFEAR_MAX_OUTER; i++)
+      o << i + 1 << "  " << inner_iterations[i] << "  " << (termination[i] == 0 ? "CONVERGENCE" : (termination[i] == 1 ? "NO_CONVERGENCE" : "FAILURE")) << "  "
+        << outer_cost[i] << "  (" << outer_pose[i][0] << ", " << outer_pose[i][1] << ", " << outer_pose[i][2] << ")\n";
+    return o.str();
+  }
+};
+
 // ---- n_scan_normal_reg (n_scan_normal.h:27-85) ----------------------------------------------------------
 class n_scan_normal_reg {
  public:
@@ -457,7 +483,7 @@ class n_scan_normal_reg {
   void getScore(double& score, int& num_residuals) { score = score_; num_residuals = summary_.num_residuals; }  // n_scan_normal.h:51
   bool GetCovarianceScaler(double& cov_scale) {  // n_scan_normal.cpp:435-441
     if (summary_.num_residuals - 3 == 0) return false; cov_scale = summary_.final_cost / (summary_.num_residuals - 3); return true; }
-  cfear_reg_summary summary_ {};  // stands in for ceres::Solver::Summary (registration.h:110)
+  RegSummary summary_;  // stands in for ceres::Solver::Summary (registration.h:110): a cfear_reg_summary with FullReport()
   size_t itr_ = 0;
   // device and parameter snapshot of this object (cfear_cov_by_sampling runs under them as well)
   DevicePtr device(const std::vector<MapNormalPtr>& scans) { if (!dev_) dev_ = scans.empty() ? Device::Default() : scans.back()->device(); return dev_; }

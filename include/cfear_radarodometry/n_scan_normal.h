@@ -5,7 +5,7 @@
 // include/cfear_hip.h. NOT compiled in this repository's image (no ROS / PCL / Eigen / OpenCV there).
 #pragma once
 #include "cfear_radarodometry/cfear_types_ros.h"
-#include "../../cfear_radarodometry_code_public_amd/host/cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"  // (this repository's include/ directory is on the include path: installed as include/cfear_hip/)
 // n_scan_normal.h:27-85 class n_scan_normal_reg: both constructors (:33,:35), Register (:37), GetCost (:41), getScore (:47,:51),
 // GetCovarianceScaler (:49), SetD2dPar (:53), SetParameters (:55), public summary_ / itr_ (registration.h:107-110).
 // RegisterTimeContinuous and GetSurface (off by default) are not provided.

@@ -5,7 +5,7 @@
 // include/cfear_hip.h. NOT compiled in this repository's image (no ROS / PCL / Eigen / OpenCV there).
 #pragma once
 #include "cfear_radarodometry/cfear_types_ros.h"
-#include "../../cfear_radarodometry_code_public_amd/host/cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"  // (this repository's include/ directory is on the include path: installed as include/cfear_hip/)
 // pointnormal.h:45-105 class cell, :110-243 class MapPointNormal (both constructors :118,:120; GetCells, GetCell, GetClosest,
 // GetClosestIdx, GetCellRelTimeStamp, TransformCells, TransformMap, GetMean2d / GetCov2d / GetNormal2d, GetScan, GetSize,
 // static downsample_factor). Boost serialization of cells and maps keeps the reference's archive layout (the .sgh export of types.cpp:103-130

@@ -5,7 +5,7 @@
 // include/cfear_hip.h. NOT compiled in this repository's image (no ROS / PCL / Eigen / OpenCV there).
 #pragma once
 #include "cfear_radarodometry/cfear_types_ros.h"
-#include "../../cfear_radarodometry_code_public_amd/host/cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"  // (this repository's include/ directory is on the include path: installed as include/cfear_hip/)
 // radar_driver.h:24-30,32-120: filtertype, Filter2str, Str2filter, class radarDriver with
 //   radarDriver(const Parameters& pars, bool disable_callback = false);                                            (:86)
 //   void CallbackOffline(const sensor_msgs::ImageConstPtr&, pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud, ...Ptr& cloud_peaks);  (:90)

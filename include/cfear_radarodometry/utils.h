@@ -5,5 +5,5 @@
 // include/cfear_hip.h. NOT compiled in this repository's image (no ROS / PCL / Eigen / OpenCV there).
 #pragma once
 #include "cfear_radarodometry/cfear_types_ros.h"
-#include "../../cfear_radarodometry_code_public_amd/host/cfear_host.hpp"
+#include "cfear_hip/cfear_host.hpp"  // (this repository's include/ directory is on the include path: installed as include/cfear_hip/)
 // utils.h:47-51: Compensate(cloud, mot | Tmotion, ccw), Affine3dToVectorXYeZ; registration.h: vectorToAffine3d.

@@ -56,3 +56,17 @@ def test_single_rank_dry_run_needs_no_launcher():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert r["n_gpus"] == 1 and r["config"]["sequences_per_gpu"] == 5
+
+
+def test_eight_rank_preflight_dry_run():
+    """The shape of the round-end scaling run (BASELINE configs[3]: 8 ranks, one per GPU): launcher -> 8 gloo ranks -> sharding ->
+    barrier / max-over-ranks timing -> SUM / MAX reduction -> one line from rank 0, on a CPU-only host."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--sequences", "3",
+                          "--dry-run"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["sequences_per_gpu"] == 3 and r["config"]["sweeps_per_step"] == 24
+    assert r["config"]["first_sequences_rank0"] == [0, 8, 16]
+    assert abs(r["value"] - 8 * 3 * 3 / (r["ms_per_step"] * 3 / 1e3)) < 1e-6 * r["value"]

@@ -41,3 +41,40 @@ def test_single_process_passthrough():
     from cfear_radarodometry_code_public_amd.dist import reduce_throughput, shard_sequences
     assert reduce_throughput(5, 2.5) == (5.0, 2.5)
     assert shard_sequences(4, 0, 1) == [0, 1, 2, 3]
+
+
+def _stream_worker(rank, world, port, cache, q):
+    import sys
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CFEAR_SYNTH_CACHE"] = cache
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    before = set(os.listdir(cache))
+    st = bench.make_streams(2, 1, rank, world, barrier=dist.barrier, procs=1)
+    q.put((rank, st.shape, int(np.asarray(st, dtype=np.uint64).sum()), sorted(set(os.listdir(cache)) - before)))
+    dist.destroy_process_group()
+
+
+def test_ranks_share_one_generated_stream_set(tmp_path):
+    """bench.make_streams: rank r generates the streams u with u % world == r, after the barrier every rank maps all of them
+    (8 ranks under a 16-CPU quota generate 1/8 of the sweeps each instead of a full set each)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stream_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == (2, 1, 400, 3360)
+    assert res[0][2] == res[1][2]  # the same sweeps on both ranks
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".npy")]) == 2  # one file per stream, nobody generated twice

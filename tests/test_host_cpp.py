@@ -54,6 +54,28 @@ def test_offline_odometry_matches_oracle(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_offline_odometry_replay_mode_gives_the_per_sweep_trajectory(tmp_path):
+    """--replay 1 (cfear_odometry_replay_host from C++: pieces of the recording in pinned memory, no host round trip per sweep)
+    writes the trajectory the per-sweep route through the mirror classes writes."""
+    exe = build_harness()
+    imgs, gt = synth.world_sequence(12, seed=21)
+    f = tmp_path / "sweeps.u8"
+    imgs.tofile(f)
+    est = {}
+    for mode in ("0", "1"):
+        d = tmp_path / ("m" + mode)
+        d.mkdir()
+        args = [exe, "--frames", str(f), "--range-res", "0.0595238", "--res", "3.0", "--submap_scan_size", "4", "--z-min", "60",
+                "--weight_option", "4", "--est_directory", str(d), "--replay", mode]
+        r = subprocess.run(args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Hz" in r.stdout
+        est[mode] = np.loadtxt(d / "est_00.txt")
+    assert est["0"].shape == est["1"].shape == (12, 12)
+    assert np.allclose(est["0"], est["1"], rtol=0, atol=2e-6)  # 6-decimal text
+
+
+@pytest.mark.gpu
 def test_offline_odometry_with_ca_cfar_filter_matches_oracle(oracle, tmp_path):
     """filter_type CA-CFAR (radar_driver.cpp:52-56): detections -> fuser, through the C++ mirror classes. The harness
     reuses options like the reference's sweeps do (offline_odometry.cpp:260-265)."""

@@ -70,3 +70,40 @@ def test_bench_two_ranks_through_the_launcher_on_one_gpu():
     assert len(r["per_rank_scans_per_s"]) == 2 and all(v > 0 for v in r["per_rank_scans_per_s"])
     assert abs(r["value"] - 2 * 64 * 6 / (r["ms_per_step"] * 6 / 1e3)) < 1e-6 * r["value"]
     assert r["state"]["replicas_bit_identical"] is True
+
+
+@pytest.mark.parametrize("B,persistent_max", [(1, 256), (1, 0), (3, 256), (3, 0)])
+def test_replay_host_equals_step_host(B, persistent_max):
+    """cfear_odometry_replay_host (chunks copied and filtered ahead on a second stream; a persistent workgroup per sequence or the
+    two launches per sweep of the batched step) gives bit-identical poses, iteration counts and cell counts to one
+    cfear_odometry_step_host per sweep, for one sequence and for several in lockstep, in one call or in pieces, and its state
+    carries over to the per-sweep entry points."""
+    from cfear_radarodometry_code_public_amd import capi, synth
+    RR = np.float32(0.0595238)
+    T = 70  # more than one chunk of 64 sweeps
+    imgs, _ = synth.world_sequence(T // 2, seed=31, world_seed=55)
+    imgs = np.concatenate([imgs, imgs[::-1]])  # forwards, then backwards: a consistent trajectory twice as long
+    frames = np.stack([np.roll(imgs, q, axis=1) if q else imgs for q in range(B)], axis=1)  # [T, B, A, R]: sequence q sees the world rotated
+    p = capi.default_params(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4)
+    ctx = capi.Context(p, 400, 3360)
+    ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
+    a, b, c = ctx.odometry(B), ctx.odometry(B), ctx.odometry(B)
+    exp = []
+    for t in range(T):
+        a.step_host(frames[t])
+        P = a.poses()
+        exp.append([(P[q].copy(),) + tuple(int(v) for v in (a.summary(q)[0].outer_iterations, a.summary(q)[0].num_residuals, a.summary(q)[2], a.summary(q)[1])) for q in range(B)])
+    pinned = ctx.pinned(frames.shape)
+    pinned[:] = frames
+    rec = b.replay_host(pinned)  # one call
+    rec2 = np.concatenate([c.replay_host(frames[:5]), c.replay_host(frames[5:6]), c.replay_host(pinned[6:T - 1])])  # pieces, pageable and pinned
+    c.step_host(frames[T - 1])  # the state carries over
+    for t in range(T):
+        for q in range(B):
+            e = exp[t][q]
+            for r in ([rec[t, q]] + ([rec2[t, q]] if t < T - 1 else [])):
+                assert np.array_equal(r["pose"], e[0]), (t, q)
+                assert (int(r["outer_iterations"]), int(r["num_residuals"]), int(r["n_keyframes"]), int(r["n_cells"])) == e[1:], (t, q)
+    assert np.array_equal(c.poses(), np.array([exp[T - 1][q][0] for q in range(B)]))
+    assert np.array_equal(b.poses(), c.poses())
+    ctx.close()
