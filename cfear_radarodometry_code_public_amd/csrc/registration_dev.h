@@ -175,6 +175,7 @@ struct RegShared {
                // function travels through per-thread scratch, a round trip to memory on the controller's serial chain
   double x_cost, x_norm, sc0, sc1, sc2, radius, decrease_factor, dg0, dg1, dg2, xc[3], model_cost_change;
   int reuse_diagonal, num_invalid, iteration, nrec;  // nrec: outer iterations recorded in orec
+  int moved, pad_m;  // the current solve has accepted a step (the pose differs from the one its problem was built at)
   // per-outer-iteration summary (cfear_reg_summary::inner_iterations ...) of the first CFEAR_OUTER_LDS iterations, written to
   // memory once at the end: a store to memory in an out-of-line controller function is a memory round trip on the serial
   // chain (the calling convention waits for it at the return) - 1.8 us per outer iteration
@@ -972,44 +973,58 @@ __device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNo
 enum { CTL_WAIT = 0, CTL_LM_NEXT, CTL_LM_DONE, CTL_BUILD, CTL_FINISH_E, CTL_FINISH_G, CTL_FINISH_NONE, CTL_EVAL_CAND, CTL_IT0 };
 
 // end of one ceres::Solve: the body of the association loop after SolveOptimizationProblem (:117-151)
+//
+// Exact repeats are not recomputed. A solve that accepted no step (the first candidate already meets a tolerance: the usual
+// end of a registration) leaves the pose bit-identical to the one its problem was built at. The next outer iteration of the
+// reference then re-associates at the same pose with the same radius (itr >= 2), gets the same residual blocks, the same normal
+// equations, the same candidate and the same convergence decision: its summary equals this one's, field by field. So when
+// `moved` is clear the loop below takes the bookkeeping of that next iteration (record, score comparison, break rules,
+// itr) from the unchanged solver summary instead of running build + evaluations again; the match array and the normal
+// equations at xcur (what the covariance needs) are still those of the last problem built, as they would be. Typical
+// registrations end [.., .., 1, 1] inner iterations: the fourth outer iteration costs nothing.
 __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
   const auto& io = sh->rio;
   const auto& P = sh->rp;
-  const int itr = sh->itr;
-  sh->success = (sh->ss.termination != 2);
-  if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
-  if (itr - 1 < CFEAR_OUTER_LDS) {  // (every lane stores the same values)
-    auto& rec = sh->orec[itr - 1];
-    rec.inner = sh->ss.num_iterations; rec.term = sh->ss.termination; rec.cost = sh->ss.final_cost;
-    rec.pose[0] = sh->xcur[0]; rec.pose[1] = sh->xcur[1]; rec.pose[2] = sh->xcur[2];
-    sh->nrec = itr;
-  } else if (lane_id() == 0 && io.out && itr - 1 < CFEAR_MAX_OUTER) {
-    io.out->inner_iterations[itr - 1] = sh->ss.num_iterations; io.out->termination[itr - 1] = sh->ss.termination;
-    io.out->outer_cost[itr - 1] = sh->ss.final_cost;
-    io.out->outer_pose[itr - 1][0] = sh->xcur[0]; io.out->outer_pose[itr - 1][1] = sh->xcur[1]; io.out->outer_pose[itr - 1][2] = sh->xcur[2];
-  }
-  const double current_score = sh->ss.final_cost;
-  const double rel_improvement = (sh->prev_score - current_score) / sh->prev_score;
-  bool brk = false, reverted = false;
-  if (itr > P.min_itr) {  // :134-149
-    if (sh->prev_score < current_score) {
-      sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; sh->cur_c = sh->prev_c; sh->cur_s = sh->prev_s;
-      brk = true; reverted = true;
+  for (;;) {
+    const int itr = sh->itr;
+    sh->success = (sh->ss.termination != 2);
+    if (sh->success) { sh->tsrc_last[0] = sh->xcur[0]; sh->tsrc_last[1] = sh->xcur[1]; sh->tsrc_last[2] = sh->xcur[2]; }
+    if (itr - 1 < CFEAR_OUTER_LDS) {  // (every lane stores the same values)
+      auto& rec = sh->orec[itr - 1];
+      rec.inner = sh->ss.num_iterations; rec.term = sh->ss.termination; rec.cost = sh->ss.final_cost;
+      rec.pose[0] = sh->xcur[0]; rec.pose[1] = sh->xcur[1]; rec.pose[2] = sh->xcur[2];
+      sh->nrec = itr;
+    } else if (lane_id() == 0 && io.out && itr - 1 < CFEAR_MAX_OUTER) {
+      io.out->inner_iterations[itr - 1] = sh->ss.num_iterations; io.out->termination[itr - 1] = sh->ss.termination;
+      io.out->outer_cost[itr - 1] = sh->ss.final_cost;
+      io.out->outer_pose[itr - 1][0] = sh->xcur[0]; io.out->outer_pose[itr - 1][1] = sh->xcur[1]; io.out->outer_pose[itr - 1][2] = sh->xcur[2];
     }
-    else if (rel_improvement < 0.00001) brk = true;
-    else if (sh->ss.last_relative_decrease < 0.00001 || sh->ss.num_iterations == 1) brk = true;
+    const double current_score = sh->ss.final_cost;
+    const double rel_improvement = (sh->prev_score - current_score) / sh->prev_score;
+    bool brk = false, reverted = false;
+    if (itr > P.min_itr) {  // :134-149
+      if (sh->prev_score < current_score) {
+        sh->xcur[0] = sh->prev_par[0]; sh->xcur[1] = sh->prev_par[1]; sh->xcur[2] = sh->prev_par[2]; sh->cur_c = sh->prev_c; sh->cur_s = sh->prev_s;
+        brk = true; reverted = true;
+      }
+      else if (rel_improvement < 0.00001) brk = true;
+      else if (sh->ss.last_relative_decrease < 0.00001 || sh->ss.num_iterations == 1) brk = true;
+    }
+    if (!brk) {
+      sh->prev_score = current_score;
+      sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2]; sh->prev_c = sh->cur_c; sh->prev_s = sh->cur_s;
+      sh->itr = itr + 1;  // for-loop increment (:102)
+      if (sh->itr <= P.max_outer && sh->success) {
+        if (!sh->moved && itr >= 2) continue;  // the next outer iteration is an exact repeat of this one (see above)
+        return CTL_BUILD;
+      }
+    }
+    // loop left: covariance of the last built problem at the final parameters if the solution is usable (:164-183). The LM
+    // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
+    // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
+    if (sh->success && reverted) { ctl_publish_eval_cur(sh, REG_ST_COV); return CTL_WAIT; }
+    return sh->success ? CTL_FINISH_E : CTL_FINISH_NONE;
   }
-  if (!brk) {
-    sh->prev_score = current_score;
-    sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2]; sh->prev_c = sh->cur_c; sh->prev_s = sh->cur_s;
-    sh->itr = itr + 1;  // for-loop increment (:102)
-    if (sh->itr <= P.max_outer && sh->success) return CTL_BUILD;
-  }
-  // loop left: covariance of the last built problem at the final parameters if the solution is usable (:164-183). The LM
-  // state already holds the normal equations of that problem at xcur (every accepted step stores them) unless the
-  // parameters were just reverted to the previous outer iteration's: only then is another evaluation needed.
-  if (sh->success && reverted) { ctl_publish_eval_cur(sh, REG_ST_COV); return CTL_WAIT; }
-  return sh->success ? CTL_FINISH_E : CTL_FINISH_NONE;
 }
 
 // trust-region step(s) until a candidate needs evaluating or the solve ends
@@ -1099,6 +1114,7 @@ __device__ __forceinline__ int ctl_after_it0_body(LRegShared* sh) {
   neq_store(&sh->E, E); sh->x_cost = E.cost;
   sh->x_norm = sqrt_well_scaled(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
   sh->ss.num_iterations = 1; sh->ss.final_cost = E.cost; sh->ss.last_relative_decrease = 0.0; sh->ss.termination = 1;
+  sh->moved = 0;
   const double gmax = fmax(fabs(E.g0), fmax(fabs(E.g1), fabs(E.g2)));
   if (gmax <= gradient_tolerance) { sh->ss.termination = 0; return CTL_LM_DONE; }
   sh->sc0 = 1.0 / (1.0 + sqrt(E.h00)); sh->sc1 = 1.0 / (1.0 + sqrt(E.h11)); sh->sc2 = 1.0 / (1.0 + sqrt(E.h22));
@@ -1125,6 +1141,7 @@ __device__ __forceinline__ int ctl_after_candidate_body(LRegShared* sh) {
   sh->ss.last_relative_decrease = relative_decrease;
   if (relative_decrease > min_relative_decrease) {  // HandleSuccessfulStep
     sh->xcur[0] = sh->xc[0]; sh->xcur[1] = sh->xc[1]; sh->xcur[2] = sh->xc[2]; sh->cur_c = sh->c; sh->cur_s = sh->s;
+    sh->moved = 1;
     sh->x_norm = sqrt_well_scaled(sh->xcur[0] * sh->xcur[0] + sh->xcur[1] * sh->xcur[1] + sh->xcur[2] * sh->xcur[2]);
     neq_store(&sh->E, C); sh->x_cost = cand_cost;
     const double t = 2.0 * relative_decrease - 1.0;
