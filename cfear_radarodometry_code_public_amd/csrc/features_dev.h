@@ -23,7 +23,7 @@ struct ScanDev {
   float* xyi;         // [cap_points][3]
   cfear_cell* cells;  // [cap_cells]
   float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
-  int* gstart;        // [cap_grid + 4], followed by the three-row records uint2[cap_grid + 4] (grid_rows3)
+  int* gstart;        // [cap_grid + 4] 32-bit bucket offsets (scans of more than CFEAR_GRID16_MAX cells), followed by the 16-bit offsets (grid_off16)
   float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
   // registration views of the cells (the association is bound by the number of scattered load instructions,
   // so the fields it needs are packed): mean x, mean y, normal x, normal y, nsamples, scale
@@ -31,8 +31,14 @@ struct ScanDev {
   double* rtar;       // [cap_cells][8] 64-byte records: read at random cell indices when the scan is a target
 };
 #define CFEAR_GRID_CAP (128 * 128)  // buckets per scan (ScanDev::cap_grid)
-__device__ __forceinline__ uint2* grid_rows3(int* gstart) { return reinterpret_cast<uint2*>(gstart + CFEAR_GRID_CAP + 4); }
-__device__ __forceinline__ const uint2* grid_rows3(const int* gstart) { return reinterpret_cast<const uint2*>(gstart + CFEAR_GRID_CAP + 4); }
+// Scans of up to CFEAR_GRID16_MAX cells (every scan the odometry builds) keep their bucket offsets as 16-bit values in the
+// region behind gstart: off16[g] = cells in buckets < g for g = 0 .. G, followed by 2 * gw more entries equal to off16[G] (the
+// 1-NN search reads the offsets of bucket g, g + gw and g + 2 gw - three rows of its window - without clamping). A scan of
+// ~200 cells spreads over ~10 000 buckets: 20 KB instead of the 120 KB of 32-bit offsets plus 8-byte three-row records.
+// Bigger scans (per-call API only) keep 32-bit offsets in gstart itself.
+#define CFEAR_GRID16_MAX 0xFFF0
+__device__ __forceinline__ unsigned short* grid_off16(int* gstart) { return reinterpret_cast<unsigned short*>(gstart + CFEAR_GRID_CAP + 4); }
+__device__ __forceinline__ const unsigned short* grid_off16(const int* gstart) { return reinterpret_cast<const unsigned short*>(gstart + CFEAR_GRID_CAP + 4); }
 
 struct FeatureParams {
   float range_res, min_distance;
@@ -199,12 +205,29 @@ __device__ __forceinline__ void point_regs_from_global(const float* __restrict__
   }
 }
 
+// registers -> cloud in memory (for a consumer that reads S->xyi after a cloud pass that kept it in registers only); block-collective
+__device__ __forceinline__ void point_regs_to_global(const PointRegs& R, float* __restrict__ xyi) {
+  __attribute__((address_space(1))) float* const g = (__attribute__((address_space(1))) float*)xyi;
+  // (scalar stores: built as a vector, the optimizer widens the reads of R.x[r] / R.y[r] into loads that span the next element,
+  // which moves the whole register array to scratch memory - for every user of PointRegs in the kernel)
+#pragma unroll
+  for (int r = 0; r < CFEAR_PT; r++) {
+    const int o = 3 * preg_idx(R, r);
+    const float x = R.x[r], y = R.y[r], w = (float)preg_w(R, r);
+    if (preg_on(R, r)) { g[o] = x; g[o + 1] = y; g[o + 2] = w; }
+  }
+  __syncthreads();
+}
+
 // slots of one sweep -> compensated cloud (getPeaksFilteredPointCloud, radar_filters.cpp:309-337, + Compensate, utils.cpp:96-107)
 // in S->xyi AND in the registers of the block (PR), with the bounding box. Returns the number of points.
 __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A, int k, const double* __restrict__ trig,
                                        float range_res_f, float min_distance_f, float* __restrict__ xyi, int cap, int compensate,
                                        double m0, double m1, double m2, int ccw, int* red_i, float* red_f, double* tab,
-                                       int tab_bearings, float bounds[4], PointRegs& PR) {
+                                       int tab_bearings, float bounds[4], PointRegs& PR, bool store = true) {
+  // store = false: the caller can do without the cloud in S->xyi when the points are handed over in registers - 58 KB per
+  // sweep that the compact feature path never reads back (the general branch below always writes it);
+  // point_regs_to_global writes it later for a caller that turns out to need it.
   // the sweep's slots, the trigonometric table and the cloud are global arrays: global-typed pointers give global_load /
   // global_store instead of flat instructions (which also count against the LDS counter)
   const __attribute__((address_space(1))) uint32_t* const g_slots = (const __attribute__((address_space(1))) uint32_t*)slots;
@@ -307,7 +330,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
       const int o = preg_idx_from_ballots(PR, r);
       PR.x[r] = x; PR.y[r] = y; PR.wi[r] = (int)CFEAR_SLOT_INTENSITY(s) | (o << 8);
       if (on) {
-        {  // one 12-byte store
+        if (store) {  // one 12-byte store (block-uniform condition)
           typedef float f32x3 __attribute__((ext_vector_type(3)));
           typedef f32x3 __attribute__((aligned(4))) f32x3u;
           *(__attribute__((address_space(1))) f32x3u*)(g_xyi + 3 * o) = f32x3{x, y, (float)CFEAR_SLOT_INTENSITY(s)};
@@ -424,7 +447,6 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
   g_f32* const g_mean = (g_f32*)S->mean_f;
   g_i32* const g_gstart = (g_i32*)S->gstart;
   __attribute__((address_space(1))) f32x4* const g_gpts = (__attribute__((address_space(1))) f32x4*)S->gpts;
-  __attribute__((address_space(1))) u32x2* const g_rows3 = (__attribute__((address_space(1))) u32x2*)grid_rows3(S->gstart);
   float gx0 = 3.4e38f, gx1 = -3.4e38f, gy0 = 3.4e38f, gy1 = -3.4e38f;
   for (int i = tid; i < nc; i += nt) {
     const float x = lm_ok ? lmr[2 * i] : g_mean[2 * i], y = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
@@ -449,10 +471,10 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
     }
   }
   const int G = gw * gh;
-  // bucket bounds of three consecutive rows in one 8-byte record (16-bit offsets, grid_rows3): the association reads
-  // the bounds of its whole window with two loads
-  bool rows3_done = false;
-  if (W.lds && G + 1 <= W.tab_voxels / 2) {
+  typedef __attribute__((address_space(1))) unsigned short g_u16;
+  g_u16* const g_off16 = (g_u16*)grid_off16(S->gstart);
+  const bool small = nc <= CFEAR_GRID16_MAX;  // block-uniform: 16-bit offsets (see grid_off16)
+  if (W.lds && G + 1 <= W.tab_voxels / 2 && small) {
     // bucket counters / cursors in LDS (the key region: the staged points are not needed any more)
     int* gc = reinterpret_cast<int*>(W.keys);
     for (int g = tid; g <= G; g += nt) gc[g] = 0;
@@ -471,21 +493,12 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
       for (int g = i0; g < i1; g++) cnt += gc[g + 1];
       int tot;
       int o = block_exclusive_scan(cnt, W.red_i, &tot);
-      // a copy of the offsets stays in LDS for the three-row records below when the key region has room for it
-      int* gl = gc + (G + 1);
-      rows3_done = 2 * (G + 1) <= W.tab_voxels / 2;
-      for (int g = i0; g < i1; g++) {  // cursor / end offset
-        const int c = gc[g + 1]; gc[g + 1] = o; g_gstart[g + 1] = o + c; o += c;
-        if (rows3_done) gl[g + 1] = o;
+      for (int g = i0; g < i1; g++) {  // cursor in LDS; the offset of the next bucket goes out as 16 bits
+        const int c = gc[g + 1]; gc[g + 1] = o; o += c; g_off16[g + 1] = (unsigned short)o;
       }
-      if (tid == 0) { g_gstart[0] = 0; if (rows3_done) gl[0] = 0; }
+      if (tid == 0) g_off16[0] = 0;
+      for (int g = G + 1 + tid; g <= G + 2 * gw; g += nt) g_off16[g] = (unsigned short)nc;  // the padding behind the last bucket
       __syncthreads();
-      if (rows3_done) {
-        for (int g = tid; g <= G; g += nt) {
-          const unsigned a = (unsigned)gl[g], b = (unsigned)gl[min(g + gw, G)], c = (unsigned)gl[min(g + 2 * gw, G)];
-          g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
-        }
-      }
     }
     for (int i = tid; i < nc; i += nt) {
       const float mx = lm_ok ? lmr[2 * i] : g_mean[2 * i], my = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
@@ -521,12 +534,9 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
     const int pos = atomicAdd(&W.vcur[cy * gw + cx], 1);
     g_gpts[pos] = f32x4{g_mean[2 * i], g_mean[2 * i + 1], __int_as_float(i), 0.f};
   }
+  if (small) {  // the 16-bit copy every reader of a small scan uses (the offsets in gstart are final since the barrier before the scatter)
+    for (int g = tid; g <= G + 2 * gw; g += nt) g_off16[g] = (unsigned short)g_gstart[min(g, G)];
   }
-  if (!rows3_done) {  // from the offsets in global memory (final at the barrier before the scatter)
-    for (int g = tid; g <= G; g += nt) {
-      const unsigned a = (unsigned)g_gstart[g], b = (unsigned)g_gstart[min(g + gw, G)], c = (unsigned)g_gstart[min(g + 2 * gw, G)];
-      g_rows3[g] = u32x2{(a & 0xFFFFu) | (b << 16), c & 0xFFFFu};
-    }
   }
   if (tid == 0) { S->gminx = gx0; S->gminy = gy0; S->gcell = gcell; S->gw = gw; S->gh = gh; }
   __syncthreads();
@@ -861,22 +871,18 @@ __device__ inline int scan_closest(const GridView& S, double px, double py, doub
   gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, gw - 1); gy1 = min(gy1, gh - 1);
   if (gx0 > gx1 || gy0 > gy1) return -1;
   const int* __restrict__ gs = S.gs;
+  const unsigned short* __restrict__ g16 = grid_off16(S.gs);
+  const bool small = S.n_cells <= CFEAR_GRID16_MAX;  // 16-bit offsets (grid_off16), else 32-bit ones in gstart
   const float4* __restrict__ gp = S.gp;
   int best = -1;
   float bd = 3.4e38f;
-  struct __attribute__((packed, aligned(4))) Int3 { int a, b, c; };
-  const bool narrow = gx1 - gx0 <= 1;  // the usual case (bucket size = window size): both bounds of a row in one 12-byte load
   for (int gy = gy0; gy <= gy1; gy += 3) {  // three rows at a time: all bucket bounds in flight together
     int ra[3], rb[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
       const int row = min(gy + r, gy1);
-      if (narrow) {
-        const Int3 v = *reinterpret_cast<const Int3*>(gs + row * gw + gx0);  // gstart has two spare entries at the end
-        ra[r] = v.a; rb[r] = (gx1 == gx0) ? v.b : v.c;
-      } else {
-        ra[r] = gs[row * gw + gx0]; rb[r] = gs[row * gw + gx1 + 1];
-      }
+      if (small) { ra[r] = (int)g16[row * gw + gx0]; rb[r] = (int)g16[row * gw + gx1 + 1]; }
+      else { ra[r] = gs[row * gw + gx0]; rb[r] = gs[row * gw + gx1 + 1]; }
       if (gy + r > gy1) rb[r] = ra[r];
     }
 #pragma unroll

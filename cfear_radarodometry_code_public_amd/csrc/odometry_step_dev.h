@@ -81,11 +81,14 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
 }
 // byte_intensities: every intensity of the cloud is an integer in 0..255 (block-uniform; always true for clouds made from
 // the filter's slots) - the compact path keeps them as bytes
+// (the batched cloud pass leaves the cloud in registers only: the general path needs it in memory and writes it first)
 __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const FeatureParams& P, const BlockScratch& B,
                                                   unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities,
-                                                  const PointRegs& PR) {
+                                                  const PointRegs& PR, bool registers_only = false) {
   const FeatureScratch W = make_fscratch(B, lds);
   if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR)) return;
+  // registers_only (a constant of the call site): the cloud pass may have left the cloud in registers only (byte intensities)
+  if (registers_only && PR.rounds > 0) point_regs_to_global(PR, S->xyi);  // block-uniform
   features_block(S, n, P, W, next_pow2(n), pt, bounds);
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
@@ -121,14 +124,15 @@ __device__ __forceinline__ void features_step_body(unsigned char* lds /* FeatLds
   double mot[3]; aff_to_xyt(TprevMot, mot);
   float bounds[4];
   PointRegs PR;
+  // (the compact feature path works from the registers: the 58 KB of the cloud are only written when somebody reads them)
   const int n = cloud_step_block(slots_all + (size_t)q * OP.A * OP.k, OP.A, OP.k, trig, OP.fp.range_res, OP.fp.min_distance,
                                  cur->xyi, cur->cap_points, OP.compensate, mot[0], mot[1], mot[2], OP.ccw,
                                  reinterpret_cast<int*>(lds + FeatLdsC::red_i), reinterpret_cast<float*>(lds + FeatLdsC::red_f),
                                  reinterpret_cast<double*>(lds + FeatLdsC::pxy),  // 6 doubles per bearing where the sorted points go later
-                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds, PR);
+                                 (int)(CFEAR_CPT_CAP * 8 / (6 * sizeof(double))), bounds, PR, false);
   if (TIMED) { pt.mark(); pt.mark(); }
   CFEAR_STOP_AT(1, );
-  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR);  // :161
+  features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR, true);  // :161
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 

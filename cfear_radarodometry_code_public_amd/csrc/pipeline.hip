@@ -167,7 +167,7 @@ ScanLayout scan_layout(int cap_points) {
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
-  L.gstart = o; o = align_up(o + (sizeof(int) + sizeof(uint2)) * (GRID_CAP + 4), 256);  // offsets + three-row records (grid_rows3)
+  L.gstart = o; o = align_up(o + (sizeof(int) + sizeof(uint2)) * (GRID_CAP + 4), 256);  // 32-bit offsets + the region of the 16-bit ones (grid_off16)
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);

