@@ -172,7 +172,7 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX = 1, 2, 3, 4
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS = 1, 2, 3, 4, 5
 
 
 class Context:
@@ -368,11 +368,13 @@ class Context:
         if ptr is not None and self._h:
             self._L.cfear_host_free(self._h, ptr)
 
-    def odometry(self, n_sequences, overlap=None):
+    def odometry(self, n_sequences, overlap=None, filter_cus=None):
         """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
         sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams"""
         if overlap is not None:
             self.tune(TUNE_ODOMETRY_OVERLAP, int(overlap))
+        if filter_cus is not None:
+            self.tune(TUNE_FILTER_CUS, int(filter_cus))
         return Odometry(self, n_sequences)
 
 

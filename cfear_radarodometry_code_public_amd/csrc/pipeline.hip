@@ -946,10 +946,31 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   if (ok && o->overlap) {
     int least = 0, greatest = 0;  // numerically lower = higher priority
     ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-    ok = ok && hipStreamCreateWithPriority(&o->sf, hipStreamNonBlocking, least) == hipSuccess;
+    // CFEAR_TUNE_FILTER_CUS = F: the filter gets F compute units of its own, the odometry streams the others: the HBM-bound
+    // kernel and the latency-bound ones stop competing for a unit's registers and LDS. What the mask bits select was measured
+    // (tools/cu_mask_probe.py): the unit of masking on this GPU is a group of 8 consecutive bits - any bit set enables the
+    // whole group, 32 groups in all - so F is rounded to groups, and the groups are taken in a spread order (0, 4, 8, ...,
+    // then 2, 6, ..., then the odd ones) so that every quarter of the bit range contributes alike.
+    std::vector<uint32_t> mask_f, mask_o;
+    int ncu = 0;
+    if (ctx->tune_filter_cus > 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && ncu >= 16) {
+      const int ngroups = ncu / 8;
+      const int gf = std::max(1, std::min(ngroups - 1, (ctx->tune_filter_cus + 4) / 8));
+      std::vector<int> order;
+      for (int phase : {0, 2, 1, 3}) for (int g = phase; g < ngroups; g += 4) order.push_back(g);
+      mask_f.assign((size_t)(ncu + 31) / 32, 0u); mask_o.assign((size_t)(ncu + 31) / 32, 0u);
+      for (int r = 0; r < ngroups; r++) {
+        std::vector<uint32_t>& m = r < gf ? mask_f : mask_o;
+        for (int b = 0; b < 8; b++) { const int i = order[(size_t)r] * 8 + b; m[(size_t)i / 32] |= 1u << (i % 32); }
+      }
+      for (int i = ngroups * 8; i < ncu; i++) mask_o[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    if (!mask_f.empty()) ok = ok && hipExtStreamCreateWithCUMask(&o->sf, (uint32_t)mask_f.size(), mask_f.data()) == hipSuccess;
+    else ok = ok && hipStreamCreateWithPriority(&o->sf, hipStreamNonBlocking, least) == hipSuccess;
     for (int i = 0; ok && i < o->overlap; i++) {
       hipStream_t st = nullptr;
-      ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) == hipSuccess;
+      if (!mask_o.empty()) ok = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask_o.size(), mask_o.data()) == hipSuccess;
+      else ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) == hipSuccess;
       if (ok) o->so.push_back(st);
       for (auto* v : {&o->ev_free[0], &o->ev_free[1], &o->ev_done}) {
         hipEvent_t e = nullptr;

@@ -83,9 +83,11 @@ int cfear_synchronize(cfear_ctx* ctx);
  * the sequences on n high-priority streams (0 = the three kernels strictly in turn on the context stream; DESIGN.md has the
  * measurements). REPLAY_PERSISTENT_MAX (default 256): cfear_odometry_replay_host runs up to this many sequences as persistent
  * workgroups that walk a whole chunk of sweeps in one launch; more sequences (or 0) take the two launches per sweep of the
- * batched step. */
+ * batched step. FILTER_CUS = F (with ODOMETRY_OVERLAP >= 1): the filter stream is created with a compute-unit mask of F units spread
+ * evenly over the chip and the odometry streams with the complement (hipExtStreamCreateWithCUMask), so that the HBM-bound filter
+ * of sweep t + 1 and the latency-bound odometry kernels of sweep t run side by side without sharing a unit's registers and LDS. */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
-       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4 };
+       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------
