@@ -109,6 +109,8 @@ def lib():
     L.cfo_fuser_last_scan.argtypes = [C.c_void_p]
     L.cfo_fuser_last_scan.restype = C.c_void_p
     L.cfo_fuser_timers.argtypes = [C.c_void_p, f64p]
+    L.cfo_fuser_set_cov_sampling.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]
+    L.cfo_fuser_last_cov.argtypes = [C.c_void_p, f64p]
     _LIB = L
     return L
 
@@ -280,6 +282,16 @@ class Fuser:
         if rc != 0:
             raise RuntimeError("cfo_fuser_process_cloud rc=%d" % rc)
         return pose
+
+    def set_cov_sampling(self, enable=True, xy_range=0.4, yaw_range=0.0043625, steps=3, scaler=4.0):
+        """Parameters::estimate_cov_by_sampling and its companions (odometrykeyframefuser.h:104-110)"""
+        lib().cfo_fuser_set_cov_sampling(self._h, int(enable), float(xy_range), float(yaw_range), int(steps), float(scaler))
+
+    def last_cov(self):
+        """cov_current after the last sweep, 6 x 6"""
+        c = np.zeros(36)
+        lib().cfo_fuser_last_cov(self._h, _ptr(c, C.c_double))
+        return c.reshape(6, 6)
 
     @property
     def num_keyframes(self):

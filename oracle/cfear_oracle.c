@@ -1184,6 +1184,9 @@ struct cfo_fuser {
   cfo_reg_summary last;
   double timers[4];
   long frames;
+  /* cov_current (odometrykeyframefuser.h:204) and the cost-sampling option (Parameters::estimate_cov_by_sampling and friends, :104-110) */
+  double cov_current[36];
+  int cov_sampling, cov_steps; double cov_xy_range, cov_yaw_range, cov_scaler;
 };
 
 static aff2 aff_identity(void) { aff2 T; T.l[0] = 1; T.l[1] = 0; T.l[2] = 0; T.l[3] = 1; T.t[0] = T.t[1] = 0; return T; }
@@ -1202,6 +1205,12 @@ void cfo_fuser_free(cfo_fuser* f) {
   free(f);
 }
 int cfo_fuser_num_keyframes(const cfo_fuser* f) { return f->nkf; }
+/* par.estimate_cov_by_sampling, cov_sampling_xy_range, cov_sampling_yaw_range, cov_sampling_samples_per_axis, cov_sampling_covariance_scaler */
+void cfo_fuser_set_cov_sampling(cfo_fuser* f, int enable, double xy_range, double yaw_range, int steps, double scaler) {
+  f->cov_sampling = enable; f->cov_xy_range = xy_range; f->cov_yaw_range = yaw_range; f->cov_steps = steps; f->cov_scaler = scaler;
+}
+/* cov_current as pointcloudCallback(..., Covariance& cov_curr) hands it back (odometrykeyframefuser.cpp:397-411): 36 doubles row-major */
+void cfo_fuser_last_cov(const cfo_fuser* f, double cov6[36]) { memcpy(cov6, f->cov_current, sizeof(double) * 36); }
 const cfo_reg_summary* cfo_fuser_last_summary(const cfo_fuser* f) { return &f->last; }
 const cfo_scan* cfo_fuser_last_scan(const cfo_fuser* f) { return f->last_scan; }
 void cfo_fuser_timers(const cfo_fuser* f, double t[4]) { for (int i = 0; i < 4; i++) t[i] = f->timers[i]; }
@@ -1242,7 +1251,15 @@ int cfo_fuser_process_cloud(cfo_fuser* f, float* xyi, int n, double pose_xyt[3])
   const int ns = f->nkf + 1;
   for (int i = 0; i < f->nkf; i++) { scans[i] = f->kf_scan[i]; aff_to_xyt(&f->kf_pose[i], &poses[3 * i]); }
   scans[ns - 1] = cur; aff_to_xyt(&Tguess, &poses[3 * (ns - 1)]);
+  for (int i = 0; i < 36; i++) cov6[i] = (i % 7 == 0) ? 1.0 : 0.0; /* FormatScans: cov_vek entries are Identity66 (:486-490) */
   cfo_register(scans, ns, poses, cov6, p, 0, &f->last); /* result ignored: shadowed 'success' (:184-186) */
+  memcpy(f->cov_current, cov6, sizeof(cov6)); /* :196 cov_current = cov_vek.back() */
+  if (f->cov_sampling) { /* :202-208; the samples are GetCost calls of radar_reg, whose itr_ is what Register left */
+    double cs[36];
+    if (cfo_cov_by_sampling(scans, ns, poses, p, f->last.outer_iterations, 0, f->cov_xy_range, f->cov_yaw_range, f->cov_steps, f->cov_scaler,
+                            f->last.final_cost, f->last.num_residuals, cs, NULL))
+      memcpy(f->cov_current, cs, sizeof(cs));
+  }
   double t3 = now_s();
   f->timers[3] += t3 - t2;
   aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]); /* :195 */

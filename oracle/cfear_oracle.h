@@ -155,6 +155,8 @@ void cfo_fuser_free(cfo_fuser* f);
 int cfo_fuser_process_polar(cfo_fuser* f, const uint8_t* img, int A, int R, double pose_xyt[3]);
 /* pointcloudCallback on an already filtered (uncompensated) cloud. */
 int cfo_fuser_process_cloud(cfo_fuser* f, float* xyi, int n, double pose_xyt[3]);
+void cfo_fuser_set_cov_sampling(cfo_fuser* f, int enable, double xy_range, double yaw_range, int steps, double scaler);
+void cfo_fuser_last_cov(const cfo_fuser* f, double cov6[36]);
 int cfo_fuser_num_keyframes(const cfo_fuser* f);
 const cfo_reg_summary* cfo_fuser_last_summary(const cfo_fuser* f);
 const cfo_scan* cfo_fuser_last_scan(const cfo_fuser* f);

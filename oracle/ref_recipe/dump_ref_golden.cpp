@@ -17,6 +17,9 @@
 #include "cfear_radarodometry/odometrykeyframefuser.h"
 #include "cfear_radarodometry/radar_driver.h"
 #include "cfear_radarodometry/radar_filters.h"
+#include "cfear_radarodometry/cfar.h"
+#include "cfear_radarodometry/n_scan_normal.h"
+#include "cfear_radarodometry/pointnormal.h"
 
 using namespace CFEAR_Radarodometry;
 
@@ -143,6 +146,66 @@ int main(int argc, char** argv) {
     const std::string tag = pass == 0 ? "p2l" : "p2d";
     w.f64("traj_" + tag, traj, {8, 3}); w.i32("outer_" + tag, outer, {8}); w.i32("last_inner_" + tag, last_inner, {8});
     w.f64("final_cost_" + tag, cost, {8}); w.i32("num_residuals_" + tag, nres, {8}); w.i32("keyframes_" + tag, nkf, {8});
+  }
+  // ---- 3. n_scan_normal_reg called directly (not through the fuser): Register -> poses, itr_, summary_, reg_cov.back()
+  //         (GetCovariance, n_scan_normal.cpp:392-433), then GetCost at the registered poses (residual vector + score,
+  //         n_scan_normal.cpp:188-213) - for every cost and for the losses the fuser run above does not use
+  {
+    const double* rp = reinterpret_cast<const double*>(in["reg_poses"].data.data());  // 4 x (x, y, theta): the first guesses
+    std::vector<MapNormalPtr> scans;
+    for (int t = 0; t < 4; t++) scans.push_back(MapNormalPtr(new MapPointNormal(clouds[t], (float)wp[4], Eigen::Vector2d(0, 0), true, false)));
+    struct Cfg { const char* tag; cost_metric cost; loss_type loss; double limit; };
+    const Cfg cfgs[] = {{"p2l_huber", P2L, Huber, 0.1}, {"p2l_cauchy", P2L, Cauchy, 0.2}, {"p2l_tukey", P2L, Tukey, 0.5}, {"p2d_huber", P2D, Huber, 0.1},
+                        {"p2p_huber", P2P, Huber, 0.1}, {"p2l_softlone", P2L, SoftLOne, 0.1}, {"p2l_none", P2L, None, 0.1}};
+    for (const Cfg& c : cfgs) {
+      n_scan_normal_reg reg(c.cost, c.loss, c.limit, weightoption::Combined_weights);
+      reg.SetD2dPar(1.0, 0.1);  // covar_scale, regularization of the fixture
+      std::vector<Eigen::Affine3d> T;
+      for (int t = 0; t < 4; t++) T.push_back(vectorToAffine3d(rp[3 * t], rp[3 * t + 1], 0, 0, 0, rp[3 * t + 2]));
+      std::vector<Matrix6d> cov(4, Matrix6d::Identity());
+      const bool ok = reg.Register(scans, T, cov, false);
+      std::vector<double> poses, cv(36), info = {ok ? 1.0 : 0.0, (double)reg.itr_, (double)reg.summary_.iterations.size(), reg.summary_.final_cost,
+                                                (double)reg.summary_.num_residuals, reg.getScore()};
+      for (int t = 0; t < 4; t++) { std::vector<double> v; Affine3dToVectorXYeZ(T[t], v); poses.insert(poses.end(), v.begin(), v.end()); }
+      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) cv[6 * a + b] = cov.back()(a, b);
+      const std::string tag = c.tag;
+      w.f64("reg_poses_" + tag, poses, {4, 3}); w.f64("reg_info_" + tag, info, {6}); w.f64("reg_cov_" + tag, cv, {6, 6});
+      double score = 0; std::vector<double> residuals;
+      const bool cost_ok = reg.GetCost(scans, T, score, residuals);  // itr_ of the object is what Register left (radius 2 m unless 1)
+      residuals.push_back(0.0);  // (never an empty record)
+      w.f64("getcost_score_" + tag, {cost_ok ? 1.0 : 0.0, score}, {2});
+      w.f64("getcost_residuals_" + tag, residuals, {(uint32_t)residuals.size()});
+    }
+  }
+  // ---- 4. AzimuthCACFAR::getFilteredPointCloud (cfar.cpp:27-87) on sweep 0 with the defaults of radarDriver::Parameters
+  //         (window_size 10, nb_guard_cells 20, false_alarm_rate 0.01, radar_driver.h:43-44) and max_distance 400
+  {
+    const double* cp = reinterpret_cast<const double*>(in["cfar_params"].data.data());  // window guard false_alarm max_distance
+    AzimuthCACFAR filt((int)cp[0], cp[2], (int)cp[1], range_res, z_min, min_distance, cp[3]);
+    pcl::PointCloud<pcl::PointXYZI>::Ptr c(new pcl::PointCloud<pcl::PointXYZI>());
+    filt.getFilteredPointCloud(to_cv(in["sweep_0"]), c);
+    w.cloud("cfar_cloud_0", *c);
+  }
+  // ---- 5. the fuser with the cost-sampling covariance (approximateCovarianceBySampling, odometrykeyframefuser.cpp:261-380, a
+  //         private member: reached through par.estimate_cov_by_sampling and the five-argument pointcloudCallback, which hands
+  //         back cov_current) and, from a second run without it, the registration covariance of every sweep
+  for (int pass = 0; pass < 2; pass++) {
+    OdometryKeyframeFuser::Parameters par;
+    par.cost_type = "P2L"; par.loss_type_ = "Huber"; par.loss_limit_ = wp[6];
+    par.weight_opt = weightoption::Combined_weights; par.submap_scan_size = (int)wp[5]; par.res = wp[4]; par.weight_intensity_ = true;
+    par.compensate = true; par.radar_ccw = false; par.use_guess = true; par.min_keyframe_dist_ = wp[7];
+    par.covar_scale_ = 1.0; par.regularization_ = 0.1;
+    par.estimate_cov_by_sampling = pass == 1; par.cov_samples_to_file_as_well = false;
+    FuserProbe fuser(par);
+    std::vector<double> covs;
+    for (int t = 0; t < 8; t++) {
+      pcl::PointCloud<pcl::PointXYZI>::Ptr c(new pcl::PointCloud<pcl::PointXYZI>(*clouds[t])), p(new pcl::PointCloud<pcl::PointXYZI>(*peaks[t]));
+      Eigen::Affine3d T = Eigen::Affine3d::Identity();
+      Covariance cov = Covariance::Identity();
+      fuser.pointcloudCallback(c, p, T, ros::Time(1.0 + 0.25 * t), cov);
+      for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) covs.push_back(cov(a, b));
+    }
+    w.f64(pass == 0 ? "fuser_reg_cov_p2l" : "fuser_sampled_cov_p2l", covs, {8, 6, 6});
   }
   std::printf("wrote %s\n", argv[2]);
   return 0;

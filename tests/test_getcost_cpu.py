@@ -152,3 +152,27 @@ def test_soft_constraint_prior_limits(oracle):
     retA, PA, covA, SA = oracle.register_soft(scans, poses, C, p)
     assert abs(PA[2, 0] - poses[2, 0]) < 1e-3  # x pinned to its guess
     assert abs(PA[2, 1] - poses[2, 1]) > 0.1 and abs(PA[2, 1] - P0[2, 1]) < 0.1  # y free to move towards the unconstrained solution
+
+
+def test_fuser_cov_current_with_and_without_sampling(oracle):
+    """cov_current of the oracle's fuser (what pointcloudCallback(..., Covariance&) hands back): the registration covariance of
+    the sweep, replaced by the cost-sampling one when estimate_cov_by_sampling is on and the fit is convex
+    (odometrykeyframefuser.cpp:196-208) - the same numbers as Register + cov_by_sampling called by hand."""
+    from cfear_radarodometry_code_public_amd import synth
+    p = oracle.default_params(range_res=RR, z_min=60.0, res=3.0, cost=1, loss=1, loss_limit=0.1, weight_opt=4, weight_intensity=1, submap_scan_size=4)
+    imgs, _ = synth.world_sequence(4, seed=23)
+    fa, fb = oracle.Fuser(p), oracle.Fuser(p)
+    fb.set_cov_sampling(True)
+    n_sampled = 0
+    for t in range(4):
+        fa.process_polar(imgs[t]); fb.process_polar(imgs[t])
+        if t == 0:
+            continue
+        S = fa.last_summary()
+        ca, cb = fa.last_cov(), fb.last_cov()
+        assert ca[0, 0] > 0 and ca[5, 5] > 0 and ca[1, 5] == 0 and ca[5, 1] == 0 and np.allclose(ca[:2, :2], ca[:2, :2].T)  # GetCovariance's layout (q14)
+        assert S.num_residuals > 30
+        if not np.array_equal(ca, cb):
+            n_sampled += 1
+            assert cb[2, 2] == 1.0 and cb[3, 3] == 1.0 and cb[4, 4] == 1.0 and cb[0, 0] > 0 and cb[5, 5] > 0  # identity outside x, y, yaw (:366-373)
+    assert n_sampled >= 1

@@ -54,3 +54,54 @@ def test_trajectory_and_iteration_counts(oracle, ref, tag, cost):
             assert S.inner_iterations[S.outer_iterations - 1] == ref["last_inner_" + tag][t], t         # Ceres LM schedule
             assert S.num_residuals == ref["num_residuals_" + tag][t], t                                 # associations
             assert abs(S.final_cost - ref["final_cost_" + tag][t]) <= 1e-9 * abs(ref["final_cost_" + tag][t]), t
+
+
+REG_CFGS = {"p2l_huber": dict(cost=1, loss=1, loss_limit=0.1), "p2l_cauchy": dict(cost=1, loss=2, loss_limit=0.2), "p2l_tukey": dict(cost=1, loss=5, loss_limit=0.5),
+            "p2d_huber": dict(cost=2, loss=1, loss_limit=0.1), "p2p_huber": dict(cost=0, loss=1, loss_limit=0.1),
+            "p2l_softlone": dict(cost=1, loss=3, loss_limit=0.1), "p2l_none": dict(cost=1, loss=0, loss_limit=0.1)}
+
+
+@pytest.mark.parametrize("tag", sorted(REG_CFGS))
+def test_direct_register_covariance_and_get_cost(oracle, ref, tag):
+    """n_scan_normal_reg::Register / GetCovariance / GetCost called directly (n_scan_normal.cpp:82-213, 392-433) for every cost and
+    the losses the fuser run does not use (registration.cpp:78-97)."""
+    kw = dict(range_res=RR, res=3.0, weight_intensity=1, weight_opt=4, regularization=0.1, covar_scale=1.0)
+    kw.update(REG_CFGS[tag])
+    p = oracle.default_params(**kw)
+    scans = [oracle.Scan(ref["world_cloud_%d" % t], p) for t in range(4)]
+    gold = np.load(GOLD)
+    poses = gold["world_gt"][:4].copy()
+    poses[3] += [0.12, -0.07, 0.004]
+    ok, P, cov, S = oracle.register(scans, poses, p)
+    info = ref["reg_info_" + tag]  # ok, itr_, iterations.size() of the last solve, final_cost, num_residuals, score
+    assert bool(ok) == bool(info[0]) and S.outer_iterations == int(info[1]) and S.inner_iterations[S.outer_iterations - 1] == int(info[2])
+    assert S.num_residuals == int(info[4]) and abs(S.final_cost - info[3]) <= 1e-9 * abs(info[3])
+    assert np.all(np.abs(P[:, :2] - ref["reg_poses_" + tag][:, :2]) < 1e-4) and np.all(np.abs(P[:, 2] - ref["reg_poses_" + tag][:, 2]) < 1e-5)
+    assert np.allclose(cov, ref["reg_cov_" + tag], rtol=1e-6, atol=1e-12)  # 30 * final_cost / dof * (J~^T J~)^-1, (1,5)/(5,1) left 0
+    got = oracle.get_cost(scans, P, p, itr=S.outer_iterations)
+    ok_c, score = ref["getcost_score_" + tag]
+    assert (got is not None) == bool(ok_c)
+    if got is not None:
+        res = ref["getcost_residuals_" + tag][:-1]  # (the recipe appends one 0 so that the record is never empty)
+        assert abs(got[0] - score) <= 1e-9 * abs(score) and len(got[1]) == len(res) and np.allclose(got[1], res, rtol=1e-7, atol=1e-10)
+
+
+def test_ca_cfar_cloud(oracle, ref):
+    """AzimuthCACFAR::getFilteredPointCloud (cfar.cpp:27-87) on sweep 0 of the fixture"""
+    from cfear_radarodometry_code_public_amd import synth
+    imgs, _ = synth.world_sequence(1, 400, 3360, RR, seed=21)
+    got = oracle.cfar(imgs[0], RR, 60.0, 2.5, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0)
+    assert got.shape == ref["cfar_cloud_0"].shape and np.array_equal(got, ref["cfar_cloud_0"])
+
+
+def test_fuser_covariances(oracle, ref):
+    """cov_current of every sweep: the registration covariance (GetCovariance) and, with estimate_cov_by_sampling, the
+    cost-sampling one (approximateCovarianceBySampling, odometrykeyframefuser.cpp:261-380)"""
+    kw = dict(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4, cost=1)
+    for key, sampling in (("fuser_reg_cov_p2l", False), ("fuser_sampled_cov_p2l", True)):
+        f = oracle.Fuser(oracle.default_params(**kw))
+        f.set_cov_sampling(sampling)
+        for t in range(8):
+            f.process_cloud(ref["world_cloud_%d" % t])
+            if t > 0:
+                assert np.allclose(f.last_cov(), ref[key][t], rtol=1e-5, atol=1e-12), (key, t)
