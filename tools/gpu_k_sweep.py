@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 torch.cuda.set_stream(torch.cuda.Stream())
 from cfear_radarodometry_code_public_amd import capi
-B, frames = 256, 14
+B, frames = int(os.environ.get('K_B', '1536')), 14
 streams = bench.make_streams(4, frames, 0)
 d_unique = torch.from_numpy(streams).cuda()
 idx = torch.arange(B, device="cuda") % 4
-for k in (12, 20, 40):
+for k in (1, 4, 12, 13, 20, 40, 64):
     p = bench.params(capi); p.k_strongest = k
     ctx = capi.Context(p, 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
     odo = ctx.odometry(B)

@@ -5,10 +5,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
   K1_N=1536 K1_REPS=2 K1_CONFIGS="7,4" timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_k1_$c -o k1 -- python $R/tools/gpu_time_k1.py > $O/${P}_pmc_k1_$c.log 2>&1
 done
 python $R/tools/pmc_k1_traffic_report.py $(find /tmp/pmc_k1_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_k1_WRITE_SIZE -name "*.db" | head -1) 1536 $O/${P}_k1_traffic.json
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --stream-steps 0 --single-sequence-sweeps 0 --no-isolated > $O/${P}_bench_prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --stream-steps 0 --single-sequence-sweeps 0 --no-isolated --no-presets > $O/${P}_bench_prof.log 2>&1
 python $R/tools/rocpd_summary.py $(find /tmp/prof_bench -name "*.db" | head -1) $O/${P}_bench_kernel_stats.md | head -8
-sed -i '1i rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --stream-steps 0 --single-sequence-sweeps 0 --no-isolated (the command the driver runs, without the legs after the timed region: 25 launches of each kernel, 4608 sequences each)\n' $O/${P}_bench_kernel_stats.md
+sed -i '1i rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --stream-steps 0 --single-sequence-sweeps 0 --no-isolated --no-presets (the command the driver runs, without the legs after the timed regions: 5 repeats x (8 pre-roll + 5 warm-up + 20 timed) = 165 launches of each kernel, 4608 sequences each)\n' $O/${P}_bench_kernel_stats.md
 cd $R && timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${P}_bench.json 2> $O/${P}_bench.err; tail -c 600 $O/${P}_bench.json
 # instruction-mix counters of the step kernels (own pass: --pmc with --kernel-trace only)
 cd /tmp; ODO_FRAMES=14 ODO_CFG="0,1536" timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d /tmp/pmc_odo_r -o odo -- python $R/tools/gpu_odo_streams.py > $O/${P}_pmc_odo.log 2>&1
 cd $R; python tools/rocpd_summary.py $(find /tmp/pmc_odo_r -name "*.db" | head -1) | grep -E "step_kernel|kstrongest" > $O/${P}_odo_pmc.txt
+# HBM traffic of the step kernels (one counter per pass) -> ${P}_odo_mem.txt
+(bash $R/tools/pmc_odo_mem.sh) > $O/${P}_odo_mem.txt 2>&1
+# the k sweep (general cloud / feature paths beyond k = 12) and the driving-like replay parity with its replay rate
+cd $R; timeout 600 python tools/gpu_k_sweep.py > $O/${P}_k_sweep.txt 2>&1
+for k in blocks canyon field; do timeout 600 python tools/gpu_drive_parity.py $k ${DRIVE_SWEEPS:-2000} $O/${P}_drive_$k.json > /dev/null 2>&1; done
