@@ -34,3 +34,23 @@ def test_drive_replay_matches_oracle_at_every_sweep(oracle, kind, sweeps, min_ce
     if kind != "field":  # known answer: the odometry follows the ground truth (the open field is allowed to drift)
         err = np.linalg.norm(out["poses_cpu"][:, :2] - out["gt"][:, :2], axis=1)
         assert err.max() < 0.02 * np.abs(out["motions"][:, 0]).sum() + 2.0
+
+
+@pytest.mark.parametrize("name,kind,sweeps,params", [
+    ("config2_p2d", "blocks", 1500, dict(cost=2, regularization=1.0, covar_scale=1.0)),                       # BASELINE configs[2]
+    ("cfear3_k40_p2p", "blocks", 1000, dict(k_strongest=40, cost=0, submap_scan_size=4, res=3.0)),            # oxford_cfear-3:13-25 (general cloud / feature paths)
+    ("cfear2_p2l", "canyon", 800, dict(cost=1, submap_scan_size=3, res=3.5, weight_intensity=0)),             # oxford_cfear-2
+    ("cauchy_ccw", "field", 800, dict(loss=2, loss_limit=0.2, radar_ccw=1)),
+])
+def test_drive_replay_of_the_other_presets(oracle, name, kind, sweeps, params):
+    """The reference's other presets on driving-like motion (stops, crawling, ramps, corners, reversing): the P2D cost of
+    BASELINE configs[2], the CFEAR-3 preset as shipped (k = 40, P2P), CFEAR-2 (3 keyframes, r = 3.5, unweighted) in the dense
+    street canyon, a Cauchy loss with a counter-clockwise sensor in the open field. Every sweep: counts and poses."""
+    T = int(os.environ.get("CFEAR_DRIVE_SWEEPS_OTHER", str(sweeps)))
+    out = drive_parity.run(oracle, T, kind, world_seed=3, seed=5, params=params)
+    m = out["mismatches"]
+    assert not m, "%s: %d sweeps disagree; first (sweep, what, device, oracle): %r" % (name, len(m), m[:3])
+    d, c = out["drift_dev"], out["drift_cpu"]
+    assert d["segments"] == c["segments"]
+    if d["segments"]:
+        assert abs(d["translation_percent"] - c["translation_percent"]) < 1e-6
