@@ -1,6 +1,6 @@
 """KITTI odometry drift metric (translation %, rotation deg / 100 m) and KITTI-format trajectory I/O.
 
-Python twin of host/kitti_metric.hpp (same segment lengths 100..800 m, a segment start every 10 frames, error
+Python twin of include/cfear_hip/kitti_metric.hpp (same segment lengths 100..800 m, a segment start every 10 frames, error
 = delta_est^-1 * delta_gt per segment). The text format is the one the reference's EvalTrajectory::Write emits
 (eval_trajectory.cpp:169-184 via MatToString, types.cpp:64-73): one 3x4 row-major pose per line, fixed, 6 decimals.
 """
