@@ -70,7 +70,7 @@ EXPORTS = [
     "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
-    "cfear_odometry_replay_host", "cfear_host_alloc", "cfear_host_free",
+    "cfear_odometry_replay_host", "cfear_odometry_replay_device", "cfear_host_alloc", "cfear_host_free",
     "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
 
@@ -135,6 +135,7 @@ def lib():
         "cfear_odometry_step_host": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
+        "cfear_odometry_replay_device": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
         "cfear_host_free": (None, [vp, vp]),
         "cfear_odometry_summary": (C.c_int, [vp, vp, C.c_int, C.POINTER(RegSummary), C.POINTER(C.c_int),
@@ -489,6 +490,12 @@ class Odometry:
         self._ctx._check(self._ctx._L.cfear_odometry_replay_host(self._ctx._h, self._h, frames.ctypes.data, n,
                                                                  rec.ctypes.data if records else None), "cfear_odometry_replay_host")
         return rec
+
+    def replay_device(self, d_frames, n_sweeps, d_records=None):
+        """d_frames: device pointer / torch tensor of n_sweeps x B x A x R bytes; d_records: device buffer of n_sweeps x B x 80 bytes or
+        None. Asynchronous on the context stream."""
+        self._ctx._check(self._ctx._L.cfear_odometry_replay_device(self._ctx._h, self._h, _addr(d_frames), int(n_sweeps),
+                                                                   _addr(d_records) if d_records is not None else None), "cfear_odometry_replay_device")
 
     def profile(self, enable):
         self._ctx._check(self._ctx._L.cfear_odometry_profile(self._ctx._h, self._h, int(enable)), "cfear_odometry_profile")

@@ -262,6 +262,7 @@ struct cfear_odometry {
   uint8_t* rp_polar[2] = {nullptr, nullptr};
   uint32_t* rp_slots[2] = {nullptr, nullptr};
   hipEvent_t rp_filt[2] = {nullptr, nullptr}, rp_used[2] = {nullptr, nullptr};  // chunk filtered / chunk consumed by the odometry kernels
+  hipEvent_t rp_in = nullptr;  // device-resident frames ready on the context stream
   bool rp_used_pending[2] = {false, false};
   int rp_chunk = 0;            // sweeps per chunk the buffers are sized for
   cfear_sweep_record* d_records = nullptr;
@@ -869,7 +870,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times,
                   o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records};
-  for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1]}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1], o->rp_in}) if (e) (void)hipEventDestroy(e);
   if (o->rp_stream) (void)hipStreamDestroy(o->rp_stream);
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : o->pool) (void)hipEventDestroy(e);
@@ -1159,7 +1160,7 @@ static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, size_t n_
   if (!o->rp_stream) {
     CFEAR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->rp_stream, hipStreamNonBlocking));
     ctx->aux_streams.push_back(o->rp_stream);
-    for (hipEvent_t* e : {&o->rp_filt[0], &o->rp_filt[1], &o->rp_used[0], &o->rp_used[1]})
+    for (hipEvent_t* e : {&o->rp_filt[0], &o->rp_filt[1], &o->rp_used[0], &o->rp_used[1], &o->rp_in})
       CFEAR_HIP_CHECK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
   }
   if (chunk > o->rp_chunk) {
@@ -1189,29 +1190,34 @@ static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, size_t n_
   return CFEAR_OK;
 }
 
-int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h_frames, int n_sweeps, cfear_sweep_record* records) {
-  if (!ctx || !o || !h_frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay_host: bad argument");
-  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest changed after odometry_create");
-  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+// frames: n_sweeps x B x A x R bytes on the host (copied chunk by chunk into the staging buffers) or on the device (filtered where
+// they lie); d_records: where the per-sweep records go on the device (null: none)
+static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, bool on_device, int n_sweeps, cfear_sweep_record* d_records) {
   const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
   // chunk: enough sweeps for the filter to run at its streaming rate (>= ~16 k azimuth rows per launch) and for the copy of the
   // next chunk to hide behind the odometry kernels of this one, at most 256 MB of staging per buffer
   int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)64, ((size_t)256 << 20) / sweep));
   chunk = std::min(chunk, n_sweeps);
   chunk = std::max(chunk, o->rp_chunk > n_sweeps ? 1 : std::min(o->rp_chunk, n_sweeps));  // (buffers of an earlier call are at least as good)
-  int rc = replay_ensure(ctx, o, chunk, records ? (size_t)n_sweeps * o->B : 0);
+  int rc = replay_ensure(ctx, o, chunk, 0);
   if (rc != CFEAR_OK) return rc;
   chunk = std::min(o->rp_chunk, n_sweeps);
   const int nchunks = (n_sweeps + chunk - 1) / chunk;
   OdoParams OP = odo_params(ctx, o);
   const bool persistent = o->B <= ctx->tune_replay_persistent_max && !OP.phase_times && !OP.wg_times;
+  if (on_device) {  // the sweeps are ready at this point of the context stream: the replay stream (which reads them) starts there
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_in, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(o->rp_stream, o->rp_in, 0));
+  }
   auto stage = [&](int c) -> int {  // copy + filter of chunk c on the replay stream
     const int b = c & 1, t0 = c * chunk, cnt = std::min(chunk, n_sweeps - t0);
     if (o->rp_used_pending[b]) CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(o->rp_stream, o->rp_used[b], 0));  // its slots were consumed
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->rp_polar[b], h_frames + sweep * (size_t)t0, sweep * (size_t)cnt, hipMemcpyHostToDevice, o->rp_stream));
-    const int frc = cfear_launch_kstrongest(ctx, o->rp_polar[b], cnt * o->B, o->rp_slots[b], o->rp_stream);  // radar_driver.cpp:58, pose-independent
+    const uint8_t* src = frames + sweep * (size_t)t0;
+    if (!on_device) {
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->rp_polar[b], src, sweep * (size_t)cnt, hipMemcpyHostToDevice, o->rp_stream));
+      src = o->rp_polar[b];
+    }
+    const int frc = cfear_launch_kstrongest(ctx, src, cnt * o->B, o->rp_slots[b], o->rp_stream);  // radar_driver.cpp:58, pose-independent
     if (frc != CFEAR_OK) return frc;
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_filt[b], o->rp_stream));
     return CFEAR_OK;
@@ -1226,10 +1232,10 @@ int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
     // chip at one per compute unit). Many sequences: the batched kernels, two launches per sweep, whose occupancy is what counts.
     if (persistent) {
       cfear_launch_replay_chunk(o->rp_slots[b], cnt, o->B, ctx->d_trig, &OP, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries,
-                                o->d_poses_out, records ? o->d_records + (size_t)t0 * o->B : nullptr, ctx->stream);
+                                o->d_poses_out, d_records ? d_records + (size_t)t0 * o->B : nullptr, ctx->stream);
     } else {
       for (int t = 0; t < cnt; t++) {
-        OP.records = records ? o->d_records + (size_t)(t0 + t) * o->B : nullptr;
+        OP.records = d_records ? d_records + (size_t)(t0 + t) * o->B : nullptr;
         odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
       }
     }
@@ -1239,9 +1245,32 @@ int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
     if (c + 1 < nchunks && (rc = stage(c + 1)) != CFEAR_OK) return rc;  // (queued after this chunk's launches: a copy from pageable memory blocks the host)
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, int n_sweeps) {
+  if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
+  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest changed after odometry_create");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return odo_join(ctx, o);
+}
+
+int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h_frames, int n_sweeps, cfear_sweep_record* records) {
+  int rc = replay_check(ctx, o, h_frames, n_sweeps);
+  if (rc != CFEAR_OK) return rc;
+  if (records && (rc = replay_ensure(ctx, o, 0, (size_t)n_sweeps * o->B)) != CFEAR_OK) return rc;
+  rc = replay_impl(ctx, o, h_frames, false, n_sweeps, records ? o->d_records : nullptr);
+  if (rc != CFEAR_OK) return rc;
   if (records) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(records, o->d_records, sizeof(cfear_sweep_record) * (size_t)n_sweeps * o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
+}
+
+int cfear_odometry_replay_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_frames, int n_sweeps, cfear_sweep_record* d_records) {
+  const int rc = replay_check(ctx, o, d_frames, n_sweeps);
+  if (rc != CFEAR_OK) return rc;
+  return replay_impl(ctx, o, d_frames, true, n_sweeps, d_records);  // asynchronous: nothing is waited for
 }
 
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {

@@ -270,6 +270,12 @@ typedef struct cfear_sweep_record {
 } cfear_sweep_record;
 int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_frames, int n_sweeps,
                                cfear_sweep_record* records /* n_sweeps x n_sequences, or NULL */);
+/* The same for sweeps that are already on the device (n_sweeps x n_sequences x A x R bytes, ready at this point of the context
+ * stream), ASYNCHRONOUS: the call returns when everything is queued; d_records (device memory, n_sweeps x n_sequences records, or
+ * NULL) is filled by the kernels, the sweeps are read until the last chunk's filter has run - work queued on the context stream
+ * afterwards (a copy of d_records, the next write into d_frames) is ordered behind all of it. */
+int cfear_odometry_replay_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_frames, int n_sweeps,
+                                 cfear_sweep_record* d_records);
 /* Page-locked host memory for the sweeps of a replay (hipHostMalloc / hipHostFree). */
 int cfear_host_alloc(cfear_ctx* ctx, size_t bytes, void** out);
 void cfear_host_free(cfear_ctx* ctx, void* p);

@@ -107,3 +107,31 @@ def test_replay_host_equals_step_host(B, persistent_max):
     assert np.array_equal(c.poses(), np.array([exp[T - 1][q][0] for q in range(B)]))
     assert np.array_equal(b.poses(), c.poses())
     ctx.close()
+
+
+def test_replay_device_is_asynchronous_and_equals_replay_host():
+    """cfear_odometry_replay_device: the same records from device-resident sweeps, written into a device buffer, nothing waited for
+    inside the call (the records are read after a synchronisation of the context)."""
+    import torch
+    from cfear_radarodometry_code_public_amd import capi, synth
+    RR = np.float32(0.0595238)
+    T, B = 70, 2
+    imgs, _ = synth.world_sequence(T // 2, seed=33, world_seed=56)
+    imgs = np.concatenate([imgs, imgs[::-1]])
+    frames = np.stack([imgs, np.roll(imgs, 5, axis=1)], axis=1)  # [T, B, A, R]
+    p = capi.default_params(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx = capi.Context(p, 400, 3360, stream=st.cuda_stream)
+        a, b = ctx.odometry(B), ctx.odometry(B)
+        rec_h = a.replay_host(frames)
+        d_frames = torch.from_numpy(frames).cuda()
+        d_rec = torch.zeros((T, B, capi.SWEEP_RECORD_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        b.replay_device(d_frames, T, d_rec)
+        d_frames.zero_()  # queued behind the last filter: must not disturb the replay
+        ctx.synchronize(); torch.cuda.synchronize()
+        rec_d = d_rec.cpu().numpy().view(capi.SWEEP_RECORD_DTYPE).reshape(T, B)
+        for f in ("pose", "final_cost", "outer_iterations", "num_residuals", "n_keyframes", "n_cells", "inner_iterations"):
+            assert np.array_equal(rec_d[f], rec_h[f]), f
+        assert np.array_equal(a.poses(), b.poses())
+        ctx.close()
