@@ -3,11 +3,11 @@ thousands of occupied voxels, registrations that find little), saturated and nea
 whose strongest returns are all ties. Cell counts, keyframe counts, poses and iteration counts agree, and a failed
 registration is the same failure.
 
-What is NOT asserted: equal iteration counts once a sequence has gone through an ill-posed registration - fewer than 30
-residuals, or a solve that ran into the iteration limit (a saturated sweep is a ring of points at maximum range: 11 residual
-blocks, rotation unobservable, 21 iterations per solve). There the trust-region decisions sit on rounding noise, and the two
-implementations differ by ulps by construction (summation order); from that sweep on the sequence is only required to keep
-producing the oracle's cell counts (the features do not depend on the pose)."""
+Rounds 1-2 did not assert equal iteration counts once a sequence had gone through an ill-posed registration (fewer than 30
+residuals, or a solve that ran into the iteration limit: a saturated sweep is a ring of points at maximum range, 11 residual
+blocks, rotation unobservable, 21 iterations per solve): one 21-21-21-21-15 against -14 had been seen. Since round 3 every one
+of the 56 ill-posed registrations of these sequences agrees with the oracle in outer and inner iteration counts, residual count,
+keyframe count and pose (tools/gpu_fuzz_report.py lists them), so nothing is exempt any more."""
 import numpy as np
 import pytest
 
@@ -60,7 +60,7 @@ def test_pathological_sweeps_match_the_oracle_fuser(oracle, seqs, cost):
     ctx = capi.Context(pg, 400, 3360)
     odo = ctx.odometry(len(names))
     fus = [oracle.Fuser(po) for _ in names]
-    strict = {n: True for n in names}
+    ill_posed = 0
     for t in range(8):
         odo.step_host(np.stack([SEQS[n][t] for n in names]))
         got = odo.poses()
@@ -70,14 +70,12 @@ def test_pathological_sweeps_match_the_oracle_fuser(oracle, seqs, cost):
             So = fus[q].last_summary()
             assert nc == len(fus[q].last_cells()), (n, t, nc, len(fus[q].last_cells()))
             if t > 0 and (So.num_residuals < 30 or max(So.inner_iterations[:8]) > 20):
-                strict[n] = False  # ill-posed: see the module docstring
-            if not strict[n]:
-                continue
+                ill_posed += 1  # (asserted like every other registration)
             assert nk == fus[q].num_keyframes, (n, t, nk, fus[q].num_keyframes)
             assert (S.usable, S.outer_iterations, list(S.inner_iterations[:8]), S.num_residuals) == \
                    (So.usable, So.outer_iterations, list(So.inner_iterations[:8]), So.num_residuals), (n, t)
             assert np.all(np.abs(got[q][:2] - exp[:2]) < 1e-4) and abs(got[q][2] - exp[2]) < 1e-5, (n, t, got[q], exp)
-    assert strict["world"]
+    assert ill_posed >= 20  # the sequences really are pathological
     odo.release()
     ctx.close()
 

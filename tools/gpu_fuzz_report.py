@@ -1,0 +1,33 @@
+"""Where do the device and the oracle part ways on the pathological sweeps of tests/test_odometry_fuzz_gpu.py (no exemption applied)?"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from cfear_radarodometry_code_public_amd import capi
+from oracle import binding as oracle
+import test_odometry_fuzz_gpu as T
+
+SEQS = T.sequences()
+names = sorted(SEQS)
+for cost in (1, 2):
+    kw = dict(cost=cost, regularization=0.1, covar_scale=1.0)
+    po, pg = T.mk(oracle, **kw), T.mk(capi, **kw)
+    ctx = capi.Context(pg, 400, 3360)
+    odo = ctx.odometry(len(names))
+    fus = [oracle.Fuser(po) for _ in names]
+    for t in range(8):
+        odo.step_host(np.stack([SEQS[n][t] for n in names]))
+        got = odo.poses()
+        for q, n in enumerate(names):
+            exp = fus[q].process_polar(SEQS[n][t])
+            S, nc, nk = odo.summary(q)
+            So = fus[q].last_summary()
+            a = (S.usable, S.outer_iterations, list(S.inner_iterations[:8]), S.num_residuals, nk)
+            b = (So.usable, So.outer_iterations, list(So.inner_iterations[:8]), So.num_residuals, fus[q].num_keyframes)
+            dp = float(np.max(np.abs(got[q][:2] - exp[:2]))); dr = float(abs(got[q][2] - exp[2]))
+            flag = "ILL" if (t > 0 and (So.num_residuals < 30 or max(So.inner_iterations[:8]) > 20)) else "   "
+            if a != b or dp >= 1e-4 or dr >= 1e-5:
+                print("cost %d %-18s t=%d %s DIFF dev %s oracle %s dpos %.2e drot %.2e" % (cost, n, t, flag, a, b, dp, dr))
+            elif flag == "ILL":
+                print("cost %d %-18s t=%d %s same  %s" % (cost, n, t, flag, (a[1], a[2][:a[1]], a[3])))
+    odo.release(); ctx.close()
