@@ -128,8 +128,11 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
+#ifndef CFEAR_REG_MIN_WG
+#define CFEAR_REG_MIN_WG 3  // workgroups per compute unit the registration step kernel is compiled for (tools: A/B builds)
+#endif
 template <bool TIMED>
-__global__ __launch_bounds__(BLOCK_R, 3) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {

@@ -203,7 +203,9 @@ __device__ __forceinline__ void neq_store(LNormalEq* p, const NormalEq& e) {
 // ---- compacted matches: SoA of 8 doubles per residual block, in LDS when they fit -------------------
 // 622 matches x 64 B + the rest of the registration kernels' LDS <= 53,760 B: three workgroups per compute unit need
 // <= 53,760 B each (LDS is handed out in 1,280-byte granules; 53,824 B already drops the kernel to two per CU and +34 % time)
+#ifndef CFEAR_MATCH_LDS_CAP
 #define CFEAR_MATCH_LDS_CAP 622
+#endif
 struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
 __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   MatchPtrs m;
