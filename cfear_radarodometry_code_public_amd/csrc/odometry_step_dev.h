@@ -24,7 +24,7 @@ struct RegLds {  // registration kernels
   static constexpr size_t total = (regsh + sizeof(RegShared) + 15) / 16 * 16;
 };
 
-static_assert(RegLds::total + sizeof(double) * 8 * CFEAR_MATCH_LDS_CAP <= 53760,
+static_assert(RegLds::total + sizeof(double) * CFEAR_MATCH_LDS_DOUBLES <= 53760,
               "registration kernels: more than 53,760 B of LDS costs the third workgroup per compute unit");
 
 // Global per-sequence working memory (also one per context for the per-call API).

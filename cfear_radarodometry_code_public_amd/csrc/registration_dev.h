@@ -151,7 +151,7 @@ struct RegIo {  // where the controller reads/writes the caller-visible data
 struct RegShared {
   // command published by the controller (wave 0) to all waves
   int cmd, itr, M, state;
-  int lds_match, pad_a;  // compacted matches live in the LDS match array (M <= CFEAR_MATCH_LDS_CAP)
+  int lds_match, pad_a;  // compacted matches live in the LDS match array (M <= match_lds_cap(cost))
   double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
   double c, s;  // cos/sin of x[2], computed once by the controller
   double cur_c, cur_s, prev_c, prev_s;  // cos/sin of xcur[2] and prev_par[2]: the values published with the evaluation that produced
@@ -206,6 +206,7 @@ __device__ __forceinline__ void neq_store(LNormalEq* p, const NormalEq& e) {
 #ifndef CFEAR_MATCH_LDS_CAP
 #define CFEAR_MATCH_LDS_CAP 622
 #endif
+#define CFEAR_MATCH_LDS_DOUBLES (8 * CFEAR_MATCH_LDS_CAP)
 struct MatchPtrs { double *tmx, *tmy, *a0, *a1, *a2, *sx, *sy, *w; };
 __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   MatchPtrs m;
@@ -214,8 +215,27 @@ __device__ __forceinline__ MatchPtrs match_ptrs(double* base, size_t cap) {
   return m;
 }
 __device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared array for every user of this header
-  __shared__ double s_match[8 * CFEAR_MATCH_LDS_CAP];
+  __shared__ double s_match[CFEAR_MATCH_LDS_DOUBLES];
   return s_match;
+}
+// The LDS array holds only the quantities the cost metric reads, so that more residual blocks fit: eight arrays for P2D
+// (622 matches), seven for P2L (a2 is never read: 710) and five for P2P (no a0 .. a2: 995). In the synthetic yard 17 % of the
+// registrations build 623-682 blocks: with eight arrays they went to the copy in memory (an evaluation of 3.5-5 us instead
+// of 1.5). q = the canonical array number of match_ptrs() (tmx tmy a0 a1 a2 sx sy w); -1: not kept in LDS for this cost.
+__device__ __forceinline__ constexpr int match_lds_arrays(int cost) { return cost == CFEAR_COST_P2D ? 8 : (cost == CFEAR_COST_P2L ? 7 : 5); }
+__device__ __forceinline__ constexpr int match_lds_cap(int cost) { return CFEAR_MATCH_LDS_DOUBLES / match_lds_arrays(cost); }
+__device__ __forceinline__ constexpr int match_lds_idx(int cost, int q) {
+  return cost == CFEAR_COST_P2D ? q
+       : cost == CFEAR_COST_P2L ? (q < 4 ? q : (q == 4 ? -1 : q - 1))
+                                : (q < 2 ? q : (q < 5 ? -1 : q - 3));
+}
+__device__ __forceinline__ MatchPtrs match_ptrs_lds(int cost) {  // null where the cost does not keep the array
+  double* base = lds_match_base();
+  const size_t cap = (size_t)match_lds_cap(cost);
+  auto at = [&](int q) -> double* { const int i = match_lds_idx(cost, q); return i < 0 ? nullptr : base + (size_t)i * cap; };
+  MatchPtrs m;
+  m.tmx = at(0); m.tmy = at(1); m.a0 = at(2); m.a1 = at(3); m.a2 = at(4); m.sx = at(5); m.sy = at(6); m.w = at(7);
+  return m;
 }
 
 // Robustified cost, gradient and Gauss-Newton matrix over the compacted matches at x = (x0, x1, theta)
@@ -231,7 +251,7 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   struct Rd {
     lds_cdouble* l; const double* g; size_t cap;
-    __device__ __forceinline__ double operator()(int arr, int i) const { return LDS ? l[arr * CFEAR_MATCH_LDS_CAP + i] : g[arr * cap + i]; }
+    __device__ __forceinline__ double operator()(int arr, int i) const { return LDS ? l[match_lds_idx(COST, arr) * match_lds_cap(COST) + i] : g[arr * cap + i]; }
   } rd;
   rd.l = (lds_cdouble*)lds_match_base(); rd.g = ls->rw.tmx; rd.cap = (size_t)ls->rw.cap;
   const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
@@ -499,11 +519,11 @@ __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const Reg
     const double i00 = c11 * id, i10 = -c10 * id, i11 = c00 * id;
     const double l00 = sqrt(i00), l10 = i10 / l00;
     const double l11 = sqrt(i11 - l10 * l10);
-    m.a0[o] = l00; m.a1[o] = l10; m.a2[o] = l11;
+    if (m.a0) m.a0[o] = l00; if (m.a1) m.a1[o] = l10; if (m.a2) m.a2[o] = l11;
   } else {
-    m.a0[o] = Tt[0] * ct.nx + Tt[1] * ct.ny;
-    m.a1[o] = Tt[2] * ct.nx + Tt[3] * ct.ny;
-    m.a2[o] = 0;
+    if (m.a0) m.a0[o] = Tt[0] * ct.nx + Tt[1] * ct.ny;  // (the LDS layout of a cost leaves out what it never reads)
+    if (m.a1) m.a1[o] = Tt[2] * ct.nx + Tt[3] * ct.ny;
+    if (m.a2) m.a2[o] = 0;
   }
 }
 
@@ -543,7 +563,7 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
   const cfear_cell* ctf = (P.cost == CFEAR_COST_P2D) ? &scans[i]->cells[ti] : nullptr;
   const double* Trel = (const double*)sh->Trel[i];  // generic views for the by-pointer interface of write_match
   const double* Ttar = (const double*)sh->Ttar[i];
-  if (use_lds) write_match(match_ptrs(lds_match_base(), CFEAR_MATCH_LDS_CAP), o, P, Trel, Ttar, cs, ct, ctf);
+  if (use_lds) write_match(match_ptrs_lds(P.cost), o, P, Trel, Ttar, cs, ct, ctf);
   else write_match(match_ptrs(W.tmx, (size_t)W.cap), o, P, Trel, Ttar, cs, ct, ctf);
 }
 
@@ -749,7 +769,12 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
     double* gm = sh->rw.tmx + o;
     const size_t gcap = (size_t)sh->rw.cap;
     // array q of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
-    auto put = [&](int q, double val) { if (on) { if (use_lds) lm[q * CFEAR_MATCH_LDS_CAP] = val; else gm[q * gcap] = val; } };
+    auto put = [&](int q, double val) {
+      if (on) {
+        if (use_lds) { const int li = match_lds_idx(cost, q); if (li >= 0) lm[li * match_lds_cap(cost)] = val; }
+        else gm[q * gcap] = val;
+      }
+    };
     const f64x2 r0 = R0[i & 1], r1 = R1[i & 1], r2 = R2[i & 1];
     const auto* T = sh->Trel[ki];
     const auto* Tt = sh->Ttar[ki];
@@ -836,14 +861,14 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= CFEAR_MATCH_LDS_CAP;
+      use_lds = M <= match_lds_cap(sh->rp.cost);
       (void)emit_block(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), use_lds);
     } else {
       unsigned long long T = 0;
       for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, nk, nsrc, itr, b).tb;  // every field <= nsrc <= 4 * blockDim
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= CFEAR_MATCH_LDS_CAP;
+      use_lds = M <= match_lds_cap(sh->rp.cost);
       unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
       for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
     }
@@ -858,7 +883,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       cnt += (ti >= 0) ? 1 : 0;
     }
     int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
-    use_lds = M <= CFEAR_MATCH_LDS_CAP;
+    use_lds = M <= match_lds_cap(sh->rp.cost);
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];
       if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, use_lds);
