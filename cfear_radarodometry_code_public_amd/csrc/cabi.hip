@@ -116,7 +116,7 @@ int cfear_tune(cfear_ctx* ctx, int key, int value) {
   if (!ctx) return CFEAR_ERR_INVALID;
   switch (key) {
     case CFEAR_TUNE_FILTER_OCCUPANCY: ctx->tune_k1_occ = value; return CFEAR_OK;
-    case CFEAR_TUNE_FILTER_ROWS_PER_WAVE: ctx->tune_k1_rows = value > 0 ? value : 1; return CFEAR_OK;
+    case CFEAR_TUNE_FILTER_ROWS_PER_WAVE: ctx->tune_k1_rows = value > 0 ? value : 0; return CFEAR_OK;
     case CFEAR_TUNE_ODOMETRY_OVERLAP: ctx->tune_odo_overlap = value < 0 ? 0 : (value > 8 ? 8 : value); return CFEAR_OK;
     case CFEAR_TUNE_FILTER_CUS: ctx->tune_filter_cus = value < 0 ? 0 : value; return CFEAR_OK;
     case CFEAR_TUNE_REPLAY_PERSISTENT_MAX: ctx->tune_replay_persistent_max = value < 0 ? 0 : value; return CFEAR_OK;

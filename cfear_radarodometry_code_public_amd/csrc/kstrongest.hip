@@ -507,10 +507,13 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const int occ_eff = (R + 27 <= 4 * 1024) ? (ctx->tune_k1_occ >= 7 ? 7 : (ctx->tune_k1_occ <= 5 ? 5 : 6)) : (R + 27 <= 8 * 1024 ? 3 : 2);
   // A wave walks a few consecutive rows (the threshold of one azimuth is the first guess for the next): four rows
   // per wave measured best from 256-scan to 1024-scan launches (shorter: every row pays the cold threshold search;
-  // longer: fewer, longer workgroups balance worse). Small launches spread their rows over the resident slots.
+  // longer: fewer, longer workgroups balance worse), six from 1536 scans up (round 3, inside the bench's timed region at 4608
+  // scans: 1041 -> 1014 us, 0.754 -> 0.774 of the HBM peak; 8 and 12 the same, 16 worse at 1536). Small launches spread their
+  // rows over the resident slots.
   const long long slots_total = 1024LL * occ_eff;
   int rows_per_wave = (int)((n_rows + slots_total - 1) / slots_total);
-  if (rows_per_wave > ctx->tune_k1_rows) rows_per_wave = ctx->tune_k1_rows;
+  const int rows_cap = ctx->tune_k1_rows > 0 ? ctx->tune_k1_rows : (n_rows >= 1536LL * 400 ? 6 : 4);
+  if (rows_per_wave > rows_cap) rows_per_wave = rows_cap;
   if (rows_per_wave < 1) rows_per_wave = 1;
   const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
   const long long blocks = (n_waves + 3) / 4;

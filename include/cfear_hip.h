@@ -78,7 +78,7 @@ int cfear_synchronize(cfear_ctx* ctx);
 
 /* Launch-shape knobs of a context (tuning; an integration never needs them, tools/ and bench.py do). Results do not depend on
  * them. FILTER_OCCUPANCY: 5..7 filter waves per SIMD (default 7); FILTER_ROWS_PER_WAVE: consecutive azimuths walked by one
- * filter wave (default 4); ODOMETRY_OVERLAP = n (0..8): batched odometry objects created afterwards run the filter of a sweep
+ * filter wave (0 = the default: 4, or 6 in launches of 1536 scans and more); ODOMETRY_OVERLAP = n (0..8): batched odometry objects created afterwards run the filter of a sweep
  * on a low-priority stream of their own, one sweep ahead, and the features / registration kernels of n contiguous ranges of
  * the sequences on n high-priority streams (0 = the three kernels strictly in turn on the context stream; DESIGN.md has the
  * measurements). REPLAY_PERSISTENT_MAX (default 256): cfear_odometry_replay_host runs up to this many sequences as persistent
