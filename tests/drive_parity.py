@@ -1,4 +1,4 @@
-"""Helper of tests/test_drive_replay_gpu.py and tools/gpu_drive_parity.py (not a test module): replays a driving-like synthetic
+"""Helper of tests/test_drive_replay_gpu.py and tests/run_drive_parity.py (not a test module): replays a driving-like synthetic
 recording (synth.DriveWorld / drive_plan: stops, crawling, ramps to 3.5 m/sweep, corners at +-0.15 rad/sweep, reversing) through
 cfear_odometry_replay_host on the device and through the oracle's fuser on the CPU, sweep by sweep, and lists every sweep at
 which the two disagree. Test infrastructure: imports oracle/."""

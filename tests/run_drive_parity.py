@@ -1,10 +1,10 @@
-"""Driving-like replay parity (tests/drive_parity.py) with a log of every disagreement: python tools/gpu_drive_parity.py kind sweeps [out.json]"""
+"""Driving-like replay parity (tests/drive_parity.py) with a log of every disagreement: python tests/run_drive_parity.py kind sweeps [out.json]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (a checker script: it lives in tests/ because it runs the oracle)
 
 
 def main():

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (a checker script: it lives in tests/ because it runs the oracle)
 from cfear_radarodometry_code_public_amd import capi
 from oracle import binding as oracle
 import test_odometry_fuzz_gpu as T

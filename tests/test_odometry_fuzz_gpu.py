@@ -7,7 +7,7 @@ Rounds 1-2 did not assert equal iteration counts once a sequence had gone throug
 residuals, or a solve that ran into the iteration limit: a saturated sweep is a ring of points at maximum range, 11 residual
 blocks, rotation unobservable, 21 iterations per solve): one 21-21-21-21-15 against -14 had been seen. Since round 3 every one
 of the 56 ill-posed registrations of these sequences agrees with the oracle in outer and inner iteration counts, residual count,
-keyframe count and pose (tools/gpu_fuzz_report.py lists them), so nothing is exempt any more."""
+keyframe count and pose (tests/run_fuzz_report.py lists them), so nothing is exempt any more."""
 import numpy as np
 import pytest
 

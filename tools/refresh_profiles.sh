@@ -16,4 +16,4 @@ cd $R; python tools/rocpd_summary.py $(find /tmp/pmc_odo_r -name "*.db" | head -
 (bash $R/tools/pmc_odo_mem.sh) > $O/${P}_odo_mem.txt 2>&1
 # the k sweep (general cloud / feature paths beyond k = 12) and the driving-like replay parity with its replay rate
 cd $R; timeout 600 python tools/gpu_k_sweep.py > $O/${P}_k_sweep.txt 2>&1
-for k in blocks canyon field; do timeout 600 python tools/gpu_drive_parity.py $k ${DRIVE_SWEEPS:-2000} $O/${P}_drive_$k.json > /dev/null 2>&1; done
+for k in blocks canyon field; do timeout 600 python tests/run_drive_parity.py $k ${DRIVE_SWEEPS:-2000} $O/${P}_drive_$k.json > /dev/null 2>&1; done
