@@ -71,7 +71,7 @@ EXPORTS = [
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_replay_host", "cfear_odometry_replay_device", "cfear_host_alloc", "cfear_host_free",
-    "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
+    "cfear_odometry_covariances", "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
 
 
@@ -134,6 +134,7 @@ def lib():
         "cfear_odometry_step_device": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_step_host": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
+        "cfear_odometry_covariances": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_odometry_replay_device": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -534,6 +535,12 @@ class Odometry:
         out = np.zeros((self.B, 3))
         self._ctx._check(self._ctx._L.cfear_odometry_poses(self._ctx._h, self._h, out.ctypes.data), "cfear_odometry_poses")
         return out
+
+    def covariances(self):
+        """cov_current of every sequence after the last sweep: [B, 6, 6]"""
+        out = np.zeros((self.B, 36))
+        self._ctx._check(self._ctx._L.cfear_odometry_covariances(self._ctx._h, self._h, out.ctypes.data), "cfear_odometry_covariances")
+        return out.reshape(self.B, 6, 6)
 
     def summary(self, sequence):
         S = RegSummary()

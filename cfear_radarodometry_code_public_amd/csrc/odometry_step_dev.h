@@ -191,6 +191,9 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
     double v[3]; aff_to_xyt(Tguess, v);
     poses[3 * (ns - 1)] = v[0]; poses[3 * (ns - 1) + 1] = v[1]; poses[3 * (ns - 1) + 2] = v[2];
   }
+  // cov_vek.back() as FormatScans leaves it (Identity66, :486-490): what cov_current is when the registration has no usable
+  // solution (it is in/out for register_block); read back through cfear_odometry_covariances
+  if (tid >= 64 && tid < 100) cov_work[(size_t)q * 36 + (tid - 64)] = ((tid - 64) % 7 == 0) ? 1.0 : 0.0;
   __syncthreads();
   const RegScratch RW = make_rscratch(B, lds);
   register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),

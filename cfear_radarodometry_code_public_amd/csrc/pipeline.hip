@@ -896,6 +896,7 @@ int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->d_states, st.data(), sizeof(SeqState) * st.size(), hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_summaries, 0, sizeof(cfear_reg_summary) * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_poses_out, 0, sizeof(double) * 3 * (size_t)o->B, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_cov_work, 0, sizeof(double) * 36 * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }
@@ -1281,6 +1282,15 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, o->d_poses_out, sizeof(double) * 3 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* o, double* cov6) {
+  if (!ctx || !o || !cov6) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_covariances: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6, o->d_cov_work, sizeof(double) * 36 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }

@@ -246,6 +246,11 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_
 int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_polar);
 /* Tcurrent of every sequence as (x, y, theta); synchronises the stream. */
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt);
+/* cov_current of every sequence after the last sweep (the Covariance& of the five-argument pointcloudCallback,
+ * odometrykeyframefuser.cpp:196,397-411): n_sequences x 36 doubles row-major - the registration covariance of the sweep's
+ * Register() (GetCovariance), the identity FormatScans starts from when the registration had no usable solution, zeros before
+ * the second sweep. (The cost-sampling variant, estimate_cov_by_sampling, is the per-call cfear_cov_by_sampling.) Synchronises. */
+int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* odo, double* cov6);
 /* Last Register() summary / cell count / keyframe count of one sequence (debug + parity tests). */
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);

@@ -511,3 +511,27 @@ def test_many_resident_sequences_are_independent_and_deterministic(oracle):
         assert np.all(np.abs(rows[0][:2] - exp[:2]) < POS_TOL) and abs(rows[0][2] - exp[2]) < ROT_TOL
     odo.release()
     ctx.close()
+
+
+def test_batched_odometry_covariances_match_the_oracle_fuser(oracle):
+    """cov_current of the device fuser (cfear_odometry_covariances) = the oracle fuser's, sweep by sweep: the registration covariance
+    30 * final_cost / dof * (J~^T J~)^-1 with its (1,5)/(5,1) quirk (n_scan_normal.cpp:392-433), for P2L and P2D."""
+    imgs, _ = synth.world_sequence(7, seed=29, world_seed=91)
+    for cost in (1, 2):
+        kw = dict(range_res=np.float32(0.0595238), k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4, cost=cost,
+                  regularization=0.1, covar_scale=1.0)
+        ctx = capi.Context(capi.default_params(**kw), 400, 3360)
+        odo = ctx.odometry(2)
+        fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(2)]
+        streams = [imgs, imgs[:, ::-1].copy()]
+        for t in range(7):
+            odo.step_host(np.stack([s[t] for s in streams]))
+            cov = odo.covariances()
+            for q in range(2):
+                fus[q].process_polar(streams[q][t])
+                if t > 0:
+                    e = fus[q].last_cov()
+                    assert np.allclose(cov[q], e, rtol=1e-6, atol=1e-14), (cost, t, q)
+                    assert cov[q][1, 5] == 0 and cov[q][5, 1] == 0 and cov[q][0, 0] > 0
+        odo.release()
+        ctx.close()
