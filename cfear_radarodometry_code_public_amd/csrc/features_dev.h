@@ -165,6 +165,22 @@ __device__ __noinline__ float2 compensate_point_plain(float x, float y, double m
   return make_float2((float)((c1 * px + (-s1) * py) + d * m0), (float)((s1 * px + c1 * py) + d * m1));
 }
 
+// Compensate of a point on bearing b through the per-bearing table row tb = {angle, sin, cos of d_b * m2, d_b, ..} (the
+// expansion described above); cb / sb: cos / sin of the bearing, rad: the point's range
+template <typename TabPtr>
+__device__ __forceinline__ void compensate_point_tabbed(float& x, float& y, TabPtr tb, double cb, double sb, double rad,
+                                                        double m0, double m1, double m2, int ccw) {
+  const double px = (double)x, py = (double)y;
+  const double ab = tb[0], s_b = tb[1], c_b = tb[2], d_b = tb[3];
+  const double a = ab + (py * cb - px * sb) * __builtin_amdgcn_rcp(rad);
+  const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;
+  const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
+  const double e = (d - d_b) * m2;  // ~1e-9 * m2: first order in e is exact to double precision
+  const double s1 = s_b + e * c_b, c1 = c_b - e * s_b;
+  x = (float)((c1 * px + (-s1) * py) + d * m0);
+  y = (float)((s1 * px + c1 * py) + d * m1);
+}
+
 // The points of a block in registers, handed from the cloud pass to the feature build. Wave w holds a contiguous run of the
 // cloud, round after round in index order: the point of lane l in round r has index wbase + (points of the wave's earlier
 // rounds) + (points of lower lanes in round r) - the order the stable counting sort of the feature build relies on.
@@ -317,15 +333,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
         // utils.cpp:96-107 expanded around the bearing (see above). The angle of (x, y) off the bearing's ray - the float
         // rounding of x and y, ~1e-8 rad - is (y c_b - x s_b) / (x c_b + y s_b); its denominator is the range to 1e-8 and two
         // digits of the quotient are plenty (it moves the point by ~1e-9 m): a hardware reciprocal of the range
-        const double px = (double)x, py = (double)y;
-        const double ab = ltab[6 * bb], s_b = ltab[6 * bb + 1], c_b = ltab[6 * bb + 2], d_b = ltab[6 * bb + 3];
-        const double a = ab + (py * cb - px * sb) * __builtin_amdgcn_rcp(rad);
-        const double dd = (a > 0.00001 ? a : (CFEAR_TWO_PI + a)) * CFEAR_INV_TWO_PI;
-        const double d = ccw ? -(dd - 0.5) : (dd - 0.5);
-        const double e = (d - d_b) * m2;  // ~1e-9 * m2: first order in e is exact to double precision
-        const double s1 = s_b + e * c_b, c1 = c_b - e * s_b;
-        x = (float)((c1 * px + (-s1) * py) + d * m0);
-        y = (float)((s1 * px + c1 * py) + d * m1);
+        compensate_point_tabbed(x, y, ltab + 6 * bb, cb, sb, rad, m0, m1, m2, ccw);
       }
       const int o = preg_idx_from_ballots(PR, r);
       PR.x[r] = x; PR.y[r] = y; PR.wi[r] = (int)CFEAR_SLOT_INTENSITY(s) | (o << 8);
@@ -343,33 +351,72 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
     block_bounds(bounds, red_f);  // (its barriers come after every store of the cloud: the general feature path may read it back)
     return total;
   }
-  // general: any number of slots, a thread takes a contiguous run of them; the cloud goes to memory and comes back
+  // general: any number of slots. Wave w takes the slots [w * RC * 64, (w + 1) * RC * 64) as above, lane <-> slot, but in a
+  // loop of batches of eight rounds (eight independent coalesced loads in flight per lane; a thread walking a run of slots of
+  // its own waits for one load after the other): a counting pass, the scan over the waves, then the points; the cloud goes to
+  // memory and comes back
   build_table();
-  const int ipt = (items + blockDim.x - 1) / blockDim.x;
-  const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
-  int cnt = 0;
-  for (int i = i0; i < i1; i++) {
-    const uint32_t s = g_slots[i];
-    cnt += (CFEAR_SLOT_VALID(s) && CFEAR_SLOT_RANGE(s) > min_range_bin) ? 1 : 0;  // :327
+  const bool small = k > 1 && k < 65536 && items < 65536;  // block-uniform: t / k by multiplication (see above)
+  const unsigned magic = small ? (unsigned)((0x100000000ull + (unsigned)k - 1u) / (unsigned)k) : 0u;
+  const int t_wave = wv * RC * 64;
+  int wtot = 0;
+  for (int r0 = 0; r0 < RC; r0 += 8) {
+    uint32_t sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t_wave + (r0 + u) * 64 + ln;
+      sv[u] = g_slots[((r0 + u < RC) & (t < items)) ? t : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t_wave + (r0 + u) * 64 + ln;
+      const bool on = (r0 + u < RC) & (t < items) & (CFEAR_SLOT_VALID(sv[u]) != 0) & (CFEAR_SLOT_RANGE(sv[u]) > min_range_bin);  // :327
+      wtot += __popcll(__ballot(on));
+    }
   }
-  int o = block_exclusive_scan_1b(cnt, red_i, 0, &total);  // (its barrier also publishes the table)
-  int b = i0 / k, jb = i0 - b * k;  // bearing and slot-in-bearing of item i, advanced without further divisions
-  for (int i = i0; i < i1; i++, jb++) {
-    if (jb == k) { jb = 0; b++; }
-    const uint32_t s = g_slots[i];
-    const int range = CFEAR_SLOT_RANGE(s);
-    if (CFEAR_SLOT_VALID(s) && range > min_range_bin && o < cap) {
-      const double cb = tabbed ? ltab[6 * b + 4] : g_trig[2 * b], sb = tabbed ? ltab[6 * b + 5] : g_trig[2 * b + 1];
-      const double rad = range_res_half + range_res * range;
-      float x = (float)(rad * cb);  // :329
-      float y = (float)(rad * sb);  // :330
-      if (compensate) {  // utils.cpp:96-107 as written (out of line)
-        const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
-        x = p.x; y = p.y;
+  int run;
+  {  // index of the wave's first point (this barrier also publishes the table)
+    auto* sl = CFEAR_LDS_PTR(int, red_i);
+    if (ln == 0) sl[wv] = wtot;
+    __syncthreads();
+    int base = 0; total = 0;
+    for (int i = 0; i < nwv; i++) { const int c = sl[i]; base += i < wv ? c : 0; total += c; }
+    run = base;
+  }
+  for (int r0 = 0; r0 < RC; r0 += 8) {
+    uint32_t sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t_wave + (r0 + u) * 64 + ln;
+      sv[u] = g_slots[((r0 + u < RC) & (t < items)) ? t : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int t = t_wave + (r0 + u) * 64 + ln;
+      const uint32_t s = sv[u];
+      const int range = CFEAR_SLOT_RANGE(s);
+      const bool hit = (r0 + u < RC) & (t < items) & (CFEAR_SLOT_VALID(s) != 0) & (range > min_range_bin);
+      const unsigned long long bal = __ballot(hit);
+      const int o = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+      run += __popcll(bal);
+      if (hit && o < cap) {
+        const int b = min(small ? (int)__umulhi((unsigned)t, magic) : (int)((unsigned)t / (unsigned)k), A - 1);
+        const double cb = tabbed ? ltab[6 * b + 4] : g_trig[2 * b], sb = tabbed ? ltab[6 * b + 5] : g_trig[2 * b + 1];
+        const double rad = range_res_half + range_res * range;
+        float x = (float)(rad * cb);  // :329
+        float y = (float)(rad * sb);  // :330
+        if (compensate) {
+          if (tabbed) compensate_point_tabbed(x, y, ltab + 6 * b, cb, sb, rad, m0, m1, m2, ccw);
+          else {  // utils.cpp:96-107 as written (out of line)
+            const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
+            x = p.x; y = p.y;
+          }
+        }
+        typedef float f32x3 __attribute__((ext_vector_type(3)));
+        typedef f32x3 __attribute__((aligned(4))) f32x3u;
+        *(__attribute__((address_space(1))) f32x3u*)(g_xyi + 3 * o) = f32x3{x, y, (float)CFEAR_SLOT_INTENSITY(s)};
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       }
-      g_xyi[3 * o + 0] = x; g_xyi[3 * o + 1] = y; g_xyi[3 * o + 2] = (float)CFEAR_SLOT_INTENSITY(s);
-      mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
-      o++;
     }
   }
   total = total < cap ? total : cap;

@@ -11,6 +11,8 @@ streams = bench.dense_streams(U, frames) if os.environ.get('ODO_DENSE') else ben
 d_unique = torch.from_numpy(streams).cuda()
 idx = torch.arange(B, device="cuda") % U
 p = bench.params(capi)
+if os.environ.get('ODO_K'):
+    p.k_strongest = int(os.environ['ODO_K'])
 if os.environ.get('ODO_COST'):
     p.cost = int(os.environ['ODO_COST']); p.regularization = 1.0; p.covar_scale = 1.0
 ctx = capi.Context(p, 400, 3360, stream=torch.cuda.current_stream().cuda_stream)
