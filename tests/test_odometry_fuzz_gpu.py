@@ -107,3 +107,33 @@ def test_batched_odometry_at_the_ends_of_the_k_range(oracle, k):
         assert len(fus[0].last_cells()) > 20
     odo.release()
     ctx.close()
+
+
+def test_batched_odometry_with_more_bearings_than_the_cloud_pass_tabulates(oracle):
+    """1000 azimuths: the batched cloud pass keeps per-bearing values (angle, compensation rotation, cos / sin) for up to 810
+    bearings in LDS and evaluates Compensate as written (atan2, sincos per point) beyond that; 12 000 slots per sweep also take
+    its looped branch and the general feature path. Device vs the oracle's fuser, sweep by sweep."""
+    A, R = 1000, 1680
+    rr = np.float32(2 * 0.0595238)
+    imgs, _ = synth.world_sequence(6, A=A, R=R, range_res=rr, seed=3, world_seed=41)
+    kw = dict(range_res=rr, res=3.5)
+    po, pg = mk(oracle, **kw), mk(capi, **kw)
+    ctx = capi.Context(pg, A, R)
+    odo = ctx.odometry(2)
+    fus = [oracle.Fuser(po), oracle.Fuser(po)]
+    streams = [imgs, imgs[::-1].copy()]
+    for t in range(6):
+        odo.step_host(np.stack([s[t] for s in streams]))
+        got = odo.poses()
+        for q in range(2):
+            exp = fus[q].process_polar(streams[q][t])
+            S, nc, nk = odo.summary(q)
+            So = fus[q].last_summary()
+            assert nc == len(fus[q].last_cells()), (t, q, nc, len(fus[q].last_cells()))
+            if t > 0:
+                assert (nk, S.outer_iterations, S.num_residuals) == (fus[q].num_keyframes, So.outer_iterations, So.num_residuals), (t, q)
+                assert list(S.inner_iterations[:8]) == list(So.inner_iterations[:8]), (t, q)
+                assert np.all(np.abs(got[q][:2] - exp[:2]) < 1e-4) and abs(got[q][2] - exp[2]) < 1e-5, (t, q, got[q], exp)
+    assert len(fus[0].last_cells()) > 50
+    odo.release()
+    ctx.close()
