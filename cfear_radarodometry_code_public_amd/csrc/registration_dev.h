@@ -223,12 +223,22 @@ __device__ __forceinline__ double* lds_match_base() {  // one 40 KB block-shared
 // registrations build 623-682 blocks: with eight arrays they went to the copy in memory (an evaluation of 3.5-5 us instead
 // of 1.5). q = the canonical array number of match_ptrs() (tmx tmy a0 a1 a2 sx sy w); -1: not kept in LDS for this cost.
 __device__ __forceinline__ constexpr int match_lds_arrays(int cost) { return cost == CFEAR_COST_P2D ? 8 : (cost == CFEAR_COST_P2L ? 7 : 5); }
-__device__ __forceinline__ constexpr int match_lds_cap(int cost) { return CFEAR_MATCH_LDS_DOUBLES / match_lds_arrays(cost); }
+// (a choice between three constants: written as DOUBLES / arrays(cost) it is an integer division at run time wherever the cost is
+// not a template parameter - the emission paid for one per stored value, a quarter of its instructions)
+__device__ __forceinline__ constexpr int match_lds_cap(int cost) {
+  return cost == CFEAR_COST_P2D ? CFEAR_MATCH_LDS_DOUBLES / 8 : (cost == CFEAR_COST_P2L ? CFEAR_MATCH_LDS_DOUBLES / 7 : CFEAR_MATCH_LDS_DOUBLES / 5);
+}
 __device__ __forceinline__ constexpr int match_lds_idx(int cost, int q) {
   return cost == CFEAR_COST_P2D ? q
        : cost == CFEAR_COST_P2L ? (q < 4 ? q : (q == 4 ? -1 : q - 1))
                                 : (q < 2 ? q : (q < 5 ? -1 : q - 3));
 }
+// (emit_cell spells these positions out)
+static_assert(match_lds_idx(CFEAR_COST_P2L, 2) == 2 && match_lds_idx(CFEAR_COST_P2L, 3) == 3 && match_lds_idx(CFEAR_COST_P2L, 4) == -1 &&
+              match_lds_idx(CFEAR_COST_P2L, 5) == 4 && match_lds_idx(CFEAR_COST_P2L, 6) == 5 && match_lds_idx(CFEAR_COST_P2L, 7) == 6, "P2L layout");
+static_assert(match_lds_idx(CFEAR_COST_P2P, 2) == -1 && match_lds_idx(CFEAR_COST_P2P, 4) == -1 && match_lds_idx(CFEAR_COST_P2P, 5) == 2 &&
+              match_lds_idx(CFEAR_COST_P2P, 6) == 3 && match_lds_idx(CFEAR_COST_P2P, 7) == 4, "P2P layout");
+static_assert(match_lds_idx(CFEAR_COST_P2D, 4) == 4 && match_lds_idx(CFEAR_COST_P2D, 7) == 7, "P2D layout");
 __device__ __forceinline__ MatchPtrs match_ptrs_lds(int cost) {  // null where the cost does not keep the array
   double* base = lds_match_base();
   const size_t cap = (size_t)match_lds_cap(cost);
@@ -733,7 +743,10 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 // flat stores through the address unit). Same arithmetic as write_match.
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
-  const int cost = sh->rp.cost, weight_opt = sh->rp.weight_opt;  // through the LDS-typed pointer
+  // block-uniform values in scalar registers: read from LDS they sit in vector registers, and every branch on them is compiled as
+  // a divergent one (save the exec mask, branch, restore)
+  const int cost = __builtin_amdgcn_readfirstlane(sh->rp.cost), weight_opt = __builtin_amdgcn_readfirstlane(sh->rp.weight_opt);
+  use_lds = __builtin_amdgcn_readfirstlane((int)use_lds) != 0;
   typedef __attribute__((address_space(1))) const double g_cf64;
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) const f64x2 g_cf64x2;
@@ -768,13 +781,6 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
     lds_double* lm = (lds_double*)lds_match_base() + o;
     double* gm = sh->rw.tmx + o;
     const size_t gcap = (size_t)sh->rw.cap;
-    // array q of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
-    auto put = [&](int q, double val) {
-      if (on) {
-        if (use_lds) { const int li = match_lds_idx(cost, q); if (li >= 0) lm[li * match_lds_cap(cost)] = val; }
-        else gm[q * gcap] = val;
-      }
-    };
     const f64x2 r0 = R0[i & 1], r1 = R1[i & 1], r2 = R2[i & 1];
     const auto* T = sh->Trel[ki];
     const auto* Tt = sh->Ttar[ki];
@@ -804,7 +810,17 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
       a1 = Tt[2] * r1.x + Tt[3] * r1.y;
       a2 = 0.0;
     }
-    put(0, tmx); put(1, tmy); put(2, a0); put(3, a1); put(4, a2); put(5, cs.mx); put(6, cs.my); put(7, wgt);
+    if (on) {  // one predicated region for the stores of a match; arrays in the order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
+      if (use_lds) {  // the LDS array keeps what the cost reads (match_lds_idx)
+        const int lc = match_lds_cap(cost);
+        lm[0] = tmx; lm[lc] = tmy;
+        if (cost == CFEAR_COST_P2D) { lm[2 * lc] = a0; lm[3 * lc] = a1; lm[4 * lc] = a2; lm[5 * lc] = cs.mx; lm[6 * lc] = cs.my; lm[7 * lc] = wgt; }
+        else if (cost == CFEAR_COST_P2L) { lm[2 * lc] = a0; lm[3 * lc] = a1; lm[4 * lc] = cs.mx; lm[5 * lc] = cs.my; lm[6 * lc] = wgt; }
+        else { lm[2 * lc] = cs.mx; lm[3 * lc] = cs.my; lm[4 * lc] = wgt; }
+      } else {
+        gm[0] = tmx; gm[gcap] = tmy; gm[2 * gcap] = a0; gm[3 * gcap] = a1; gm[4 * gcap] = a2; gm[5 * gcap] = cs.mx; gm[6 * gcap] = cs.my; gm[7 * gcap] = wgt;
+      }
+    }
   }
 }
 
