@@ -85,10 +85,11 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 }
 // bounding box in one go: v = {min x, max x, min y, max y} per thread -> block-wide values in every thread.
 // scratch: >= 4 * 32 floats... uses 4 floats per wave (<= 16 waves -> 64 floats).
+template <int NT = 0>
 __device__ __forceinline__ void block_bounds(float v[4], float* scratch) {
   auto* sl = CFEAR_LDS_PTR(float, scratch);
   v[0] = wave_min(v[0]); v[1] = wave_max(v[1]); v[2] = wave_min(v[2]); v[3] = wave_max(v[3]);
-  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int w = threadIdx.x >> 6, nw = NT ? (NT + 63) >> 6 : (blockDim.x + 63) >> 6;
   __syncthreads();
   if (lane_id() == 0) { sl[4 * w] = v[0]; sl[4 * w + 1] = v[1]; sl[4 * w + 2] = v[2]; sl[4 * w + 3] = v[3]; }
   __syncthreads();
@@ -134,9 +135,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
 // i.e. between this scan and the previous one that used the same slot there must be a barrier (any barrier) - back-to-back
 // scans alternate slots. (The two-barrier version protects its scratch with a barrier of its own; at 8 waves that is ~0.5 us
 // per scan, and the feature kernel has seven of them per scan of the radar.)
+template <int NT = 0>
 __device__ __forceinline__ int block_exclusive_scan_1b(int v, int* scratch, int slot, int* total) {
   auto* sl = CFEAR_LDS_PTR(int, scratch) + 16 * slot;
-  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = NT ? (NT + 63) >> 6 : (blockDim.x + 63) >> 6;
   const int inc = wave_inclusive_scan(v);
   if (lane == 63) sl[w] = inc;
   __syncthreads();
@@ -152,9 +154,10 @@ __device__ __forceinline__ int block_exclusive_scan_1b(int v, int* scratch, int 
 
 // The one-barrier scan over unsigned values with a block-wide OR of a per-thread flag riding along (entries 8..15 of the slot:
 // at most 8 waves): *any = some thread of the block raised its flag.
+template <int NT = 0>
 __device__ __forceinline__ unsigned block_exclusive_scan_1b_flag(unsigned v, bool flag, int* scratch, int slot, unsigned* total, bool* any) {
   auto* sl = CFEAR_LDS_PTR(int, scratch) + 16 * slot;
-  const int lane = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = lane_id(), w = threadIdx.x >> 6, nw = NT ? (NT + 63) >> 6 : (blockDim.x + 63) >> 6;
   const unsigned inc = wave_inclusive_scan_u(v);
   const bool wf = __ballot(flag) != 0ull;
   if (lane == 63) { sl[w] = (int)inc; sl[8 + w] = wf ? 1 : 0; }

@@ -60,7 +60,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(1))) u32x4 g_u32x4;
   g_u32x4* const g_rng = (g_u32x4*)W.rng;  // candidate ranges of a sample's window rows (16 bytes per sample)
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = CFEAR_FEAT_BLOCK;
   const int ccap = min(CFEAR_CPT_CAP, W.cap);  // points / chunk records the arrays (LDS and the global partial sums) hold
   if (n <= 0 || n > ccap || PR.rounds <= 0) return false;  // block-uniform
   // ---- PCL VoxelGrid (pointnormal.cpp:277-280), leaf = radius_/downsample_factor ----
@@ -76,7 +76,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       if (preg_on(PR, r)) { mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y); }
     }
     float bb[4] = {mnx, mxx, mny, mxy};
-    block_bounds(bb, W.red_f);
+    block_bounds<CFEAR_FEAT_BLOCK>(bb, W.red_f);
     mnx = bb[0]; mxx = bb[1]; mny = bb[2]; mxy = bb[3];
   }
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
@@ -125,7 +125,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     const int w0 = tid * wpt, w1 = min(NW, w0 + wpt);
     int cnt = 0;
     for (int w = w0; w < w1; w++) cnt += __popc(bm[w]);
-    int ex = block_exclusive_scan_1b(cnt, W.red_i, 0, &nv);  // (one-barrier scans: a barrier separates each from the one before)
+    int ex = block_exclusive_scan_1b<CFEAR_FEAT_BLOCK>(cnt, W.red_i, 0, &nv);  // (one-barrier scans: a barrier separates each from the one before)
     for (int w = w0; w < w1; w++) { bmp[w] = (unsigned short)ex; ex += __popc(bm[w]); }
     VS = (nv + 2) & ~1;  // counters per set (even: a set starts on a word)
     NS = (nwv == 8 && 8 * VS <= (int)(CFEAR_CPT_CAP * 8 / 2)) ? 8 : 1;
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         for (int q = 0; q < NSC; q++) { const unsigned c = cw[q * VW + w]; cnt += (int)(c & 0xFFFFu) + (int)(c >> 16); }
       }
       int tot;
-      int o = block_exclusive_scan_1b(cnt, W.red_i, 0, &tot);
+      int o = block_exclusive_scan_1b<CFEAR_FEAT_BLOCK>(cnt, W.red_i, 0, &tot);
       for (int w = w0; w < w1; w++) {
         unsigned c[NSC];
         int sum_lo = 0;
@@ -292,7 +292,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   // partial moments, (4) the epilogue adds a sample's partials in chunk order (deterministic).
   // (chunks of 16: with 512 lanes and some 300-1500 samples of 6..300 candidates each, shorter chunks spread the work more
   // evenly over the lanes than chunks of 32 - fewer lanes wait for the longest chunk of their wave)
-  int C = 16, NC, NA;  // chunk size, chunks, samples that have chunks ("active": only they can become cells)
+  int C = 16, CS = 4, NC, NA;  // chunk size (a power of two: 1 << CS, so that counting chunks is a shift, not an integer division), chunks, samples that have chunks ("active": only they can become cells)
   bool listed = true;  // the active samples are listed behind the chunks (when both lists fit): the epilogue then runs over them only
   {
     const int ipt = (nv + nt - 1) / nt;
@@ -321,7 +321,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
     for (int it = 0;; it++) {  // block-uniform: the chunk list and the active-sample list side by side; if they do not fit, the chunk
                                // list alone (the epilogue then visits every sample), with the chunk size doubled until it fits
       int cnt = 0, act = 0;
-      for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) / C; act += t > 0 ? 1 : 0; }
+      for (int i = i0; i < i1; i++) { const int t = (int)ord[i]; cnt += (t + C - 1) >> CS; act += t > 0 ? 1 : 0; }
       // one scan for the two counts: chunks in bits 0..18, active samples (<= nv <= 4864) in bits 19..31. A dense cloud with a
       // large downsample_factor has far more than 2^19 chunks of 16 (hundreds of voxels that each see thousands of candidates):
       // a thread's count is clamped to 1023 (512 x 1023 < 2^19, the fields cannot run into each other) and a clamped thread
@@ -330,16 +330,16 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
       cnt = big ? 1023 : cnt;
       unsigned tot2;
       bool any_big;
-      const unsigned ex = block_exclusive_scan_1b_flag((unsigned)cnt | ((unsigned)act << 19), big, W.red_i, it & 1, &tot2, &any_big);
+      const unsigned ex = block_exclusive_scan_1b_flag<CFEAR_FEAT_BLOCK>((unsigned)cnt | ((unsigned)act << 19), big, W.red_i, it & 1, &tot2, &any_big);
       o = (int)(ex & 0x7FFFFu); oa = (int)(ex >> 19); NC = (int)(tot2 & 0x7FFFFu); NA = (int)(tot2 >> 19);
       if (!any_big && NC + NA <= ccap) break;
       listed = false;
       if (!any_big && NC <= ccap) break;  // (an active sample has a chunk, so NC >= NA; NC -> NA <= nv <= ccap as the chunks grow)
-      C <<= 1;
+      C <<= 1; CS++;
     }
     for (int i = i0; i < i1; i++) {  // chunk start per sample (over its candidate total), sample per chunk, active samples in order
       const int t = (int)ord[i];
-      const int c = (t + C - 1) / C;
+      const int c = (t + C - 1) >> CS;
       ord[i] = (unsigned short)o;
       for (int j = 0; j < c; j++) chk[o + j] = (unsigned short)i;
       o += c;
@@ -504,7 +504,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         }
       }
       int round_total;
-      const int o = base + block_exclusive_scan_1b(valid, W.red_i, round & 1, &round_total);
+      const int o = base + block_exclusive_scan_1b<CFEAR_FEAT_BLOCK>(valid, W.red_i, round & 1, &round_total);
       if (valid && o < cap_cells) {
         typedef __attribute__((address_space(1))) cfear_cell g_cell;
         typedef double f64x2 __attribute__((ext_vector_type(2)));

@@ -88,6 +88,10 @@ struct FeatureScratch {
 };
 
 #define CFEAR_TWO_PI 6.283185307179586476925286766559
+// threads of every workgroup that runs the code of this header and of features_compact_dev.h (pipeline.hip / replay.hip BLOCK_F): a
+// compile-time constant - blockDim.x is a load from the dispatch packet, a division by it an integer division at run time, and a
+// block-wide scan over "blockDim.x / 64" partial sums a loop instead of eight reads side by side
+#define CFEAR_FEAT_BLOCK 512
 #define CFEAR_INV_TWO_PI 0.15915494309189533576888376337251
 
 // getPeaksFilteredPointCloud (radar_filters.cpp:309-337): row-major over (bearing, slot).
@@ -99,7 +103,7 @@ __device__ inline int cloud_build_block(const uint32_t* __restrict__ slots, int 
   const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // :315
   const double range_res_half = range_res / 2.0;
   const int items = A * k;
-  const int ipt = (items + blockDim.x - 1) / blockDim.x;
+  const int ipt = (items + CFEAR_FEAT_BLOCK - 1) / CFEAR_FEAT_BLOCK;
   const int i0 = threadIdx.x * ipt, i1 = min(items, i0 + ipt);
   int cnt = 0;
   for (int i = i0; i < i1; i++) {
@@ -108,7 +112,7 @@ __device__ inline int cloud_build_block(const uint32_t* __restrict__ slots, int 
     cnt += ok ? 1 : 0;
   }
   int total;
-  int o = block_exclusive_scan(cnt, red_i, &total);
+  int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, red_i, &total);
   for (int i = i0; i < i1; i++) {
     const uint32_t s = slots[i];
     const int range = CFEAR_SLOT_RANGE(s);
@@ -129,7 +133,7 @@ __device__ inline int cloud_build_block(const uint32_t* __restrict__ slots, int 
 
 // Compensate (utils.cpp:96-107) with GetRelTimeStamp (utils.h:28-32)
 __device__ inline void compensate_block(float* __restrict__ xyi, int n, double m0, double m1, double m2, int ccw) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n; i += CFEAR_FEAT_BLOCK) {
     const double px = (double)xyi[3 * i], py = (double)xyi[3 * i + 1];
     const double a = atan2(py, px);
     const double dd = ((a > 0.00001 ? a : (CFEAR_TWO_PI + a)) / CFEAR_TWO_PI);
@@ -206,7 +210,7 @@ __device__ __forceinline__ int preg_idx_from_ballots(const PointRegs& R, int r) 
 // a cloud in memory -> registers (per-call feature builds; the general cloud pass)
 __device__ __forceinline__ void point_regs_from_global(const float* __restrict__ xyi, int n, PointRegs& R) {
   const __attribute__((address_space(1))) float* const g = (const __attribute__((address_space(1))) float*)xyi;
-  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = blockDim.x >> 6;
+  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = CFEAR_FEAT_BLOCK >> 6;
   const int rounds = (n + 64 * nwv - 1) / (64 * nwv);
   R.rounds = rounds <= CFEAR_PT ? rounds : 0;
   R.wbase = wv * rounds * 64; R.onm = 0u;
@@ -253,14 +257,14 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   const int min_range_bin = (int)ceil((double)min_distance_f / range_res);  // radar_filters.cpp:315
   const double range_res_half = range_res / 2.0;
   const int items = A * k;
-  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = blockDim.x >> 6;
+  const int wv = threadIdx.x >> 6, ln = lane_id(), nwv = CFEAR_FEAT_BLOCK >> 6;
   // per-bearing table in LDS, six doubles each: principal angle, sin / cos of the compensation rotation at the bearing's
   // angle, its sweep fraction, cos / sin of the bearing (so that the per-point loop has no global load to wait for)
   auto* ltab = CFEAR_LDS_PTR(double, tab);
   const bool tabbed = A <= tab_bearings;       // block-uniform; more bearings than the table holds: plain formulas
   auto build_table = [&]() {
    if (tabbed) {
-    for (int b = threadIdx.x; b < A; b += blockDim.x) {
+    for (int b = threadIdx.x; b < A; b += CFEAR_FEAT_BLOCK) {
       ltab[6 * b + 4] = g_trig[2 * b]; ltab[6 * b + 5] = g_trig[2 * b + 1];
       if (compensate) {
         const double theta = ((double)(b + 1) / A) * CFEAR_TWO_PI;                   // radar_filters.cpp:317
@@ -348,7 +352,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
     }
     total = total < cap ? total : cap;
     bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
-    block_bounds(bounds, red_f);  // (its barriers come after every store of the cloud: the general feature path may read it back)
+    block_bounds<CFEAR_FEAT_BLOCK>(bounds, red_f);  // (its barriers come after every store of the cloud: the general feature path may read it back)
     return total;
   }
   // general: any number of slots. Wave w takes the slots [w * RC * 64, (w + 1) * RC * 64) as above, lane <-> slot, but in a
@@ -421,7 +425,7 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
   }
   total = total < cap ? total : cap;
   bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
-  block_bounds(bounds, red_f);
+  block_bounds<CFEAR_FEAT_BLOCK>(bounds, red_f);
   __syncthreads();
   point_regs_from_global(xyi, total, PR);
   return total;
@@ -485,7 +489,7 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
                                                 bool lm_ok, PhaseTimer* pt) {
   typedef __attribute__((address_space(1))) float g_f32;
   typedef __attribute__((address_space(1))) int g_i32;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = CFEAR_FEAT_BLOCK;
   // ---- uniform grid over the float cell means (replaces KdTreeFLANN<PointXY>, :151-162) ----
   // the cell means come from the LDS copy the epilogue left in the voxel-list array when they fit (no read-back from memory)
   const auto* lmr = CFEAR_LDS_PTR(float, reinterpret_cast<float*>(W.vlist));
@@ -499,7 +503,7 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
     const float x = lm_ok ? lmr[2 * i] : g_mean[2 * i], y = lm_ok ? lmr[2 * i + 1] : g_mean[2 * i + 1];
     gx0 = fminf(gx0, x); gx1 = fmaxf(gx1, x); gy0 = fminf(gy0, y); gy1 = fmaxf(gy1, y);
   }
-  { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
+  { float bb[4] = {gx0, gx1, gy0, gy1}; block_bounds<CFEAR_FEAT_BLOCK>(bb, W.red_f); gx0 = bb[0]; gx1 = bb[1]; gy0 = bb[2]; gy1 = bb[3]; }
   if (nc == 0) {
     if (tid == 0) { S->gw = 0; S->gh = 0; S->gcell = 1.f; S->gminx = 0.f; S->gminy = 0.f; }
     __syncthreads();
@@ -539,7 +543,7 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
       int cnt = 0;
       for (int g = i0; g < i1; g++) cnt += gc[g + 1];
       int tot;
-      int o = block_exclusive_scan(cnt, W.red_i, &tot);
+      int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &tot);
       for (int g = i0; g < i1; g++) {  // cursor in LDS; the offset of the next bucket goes out as 16 bits
         const int c = gc[g + 1]; gc[g + 1] = o; o += c; g_off16[g + 1] = (unsigned short)o;
       }
@@ -569,7 +573,7 @@ __device__ __forceinline__ void cell_grid_block(ScanDev* __restrict__ S, int nc,
     int cnt = 0;
     for (int g = i0; g < i1; g++) cnt += g_gstart[g + 1];
     int tot;
-    int o = block_exclusive_scan(cnt, W.red_i, &tot);
+    int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &tot);
     for (int g = i0; g < i1; g++) { const int c = g_gstart[g + 1]; W.vcur[g] = o; g_gstart[g + 1] = o + c; o += c; }
     __syncthreads();
   }
@@ -604,7 +608,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   g_f64* const g_part = (g_f64*)W.part;
   g_f32* const g_samples = (g_f32*)W.samples;
   g_i32* const g_rng = (g_i32*)W.rng;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = CFEAR_FEAT_BLOCK;
   const g_f32* const xyi = (const g_f32*)S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
     if (tid == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = 0; S->status = CFEAR_ERR_EMPTY; S->gw = 0; S->gh = 0; }
@@ -623,7 +627,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
     }
     float bb[4] = {mnx, mxx, mny, mxy};
-    block_bounds(bb, W.red_f);
+    block_bounds<CFEAR_FEAT_BLOCK>(bb, W.red_f);
     mnx = bb[0]; mxx = bb[1]; mny = bb[2]; mxy = bb[3];
   }
   const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv);
@@ -651,7 +655,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     int cnt = 0;
     for (int i = i0; i < i1; i++) cnt += (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) ? 1 : 0;
     int nv;
-    int o = block_exclusive_scan(cnt, W.red_i, &nv);
+    int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &nv);
     for (int i = i0; i < i1; i++) {
       const uint64_t k = W.keys[i];
       W.order[i] = (int)(uint32_t)k;
@@ -734,20 +738,20 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   __syncthreads();
   if (pt) pt->mark();
-  int C = 32, NC;
+  int C = 32, CS = 5, NC;  // (C = 1 << CS)
   {
     const int ipt = (nv + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(nv, i0 + ipt);
     int o;
     for (;;) {  // block-uniform: double the chunk size until the chunk list fits
       int cnt = 0;
-      for (int i = i0; i < i1; i++) cnt += (T[i] + C - 1) / C;
-      o = block_exclusive_scan(cnt, W.red_i, &NC);
+      for (int i = i0; i < i1; i++) cnt += (T[i] + C - 1) >> CS;
+      o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &NC);
       if (NC <= W.cap) break;
-      C <<= 1;
+      C <<= 1; CS++;
     }
     for (int i = i0; i < i1; i++) {  // vstart/vlist are free now: chunk start per sample, sample per chunk
-      const int c = (T[i] + C - 1) / C;
+      const int c = (T[i] + C - 1) >> CS;
       W.vstart[i] = o;
       for (int j = 0; j < c; j++) W.vlist[o + j] = i;
       o += c;
@@ -857,7 +861,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         }
       }
       int round_total;
-      const int o = base + block_exclusive_scan(valid, W.red_i, &round_total);
+      const int o = base + block_exclusive_scan<CFEAR_FEAT_BLOCK>(valid, W.red_i, &round_total);
       if (valid && o < cap_cells) {
         typedef __attribute__((address_space(1))) cfear_cell g_cell;
         typedef double f64x2 __attribute__((ext_vector_type(2)));

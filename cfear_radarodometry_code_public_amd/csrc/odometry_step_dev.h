@@ -10,7 +10,7 @@ using namespace cfear_dev;
 
 namespace {
 
-constexpr int BLOCK_F = 512;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
+constexpr int BLOCK_F = CFEAR_FEAT_BLOCK;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
 constexpr int BLOCK_R = CFEAR_REG_BLOCK;   // registration kernels: 256 threads (4 waves = one per SIMD) in pipeline.hip
 static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
 constexpr int MAX_SCANS = 64;  // keyframes + current

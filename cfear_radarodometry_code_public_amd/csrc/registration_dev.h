@@ -863,7 +863,7 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
 
 __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, LRegShared* sh, int itr) {
   const ScanDev* src = scans[n - 1];
-  const int nsrc = src->n_cells;
+  const int nsrc = sh->kf[n - 1].n_cells;  // (the view in LDS: src->n_cells is a round trip to memory in front of every association)
   const int pairs = (n - 1) * nsrc;
   const int nt = CFEAR_REG_BLOCK, tid = threadIdx.x;
   int M;
