@@ -655,8 +655,10 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
       lo[v][0] = l0; lo[v][1] = l1 - c0; lo[v][2] = l2 - (c0 + c1);
       kmax = max(kmax, tot[v]);
     }
-    int best[2] = {-1, -1};
-    float bd[2] = {3.4e38f, 3.4e38f};
+    // nearest candidate, exact-distance ties to the lowest cell index: the minimum of the 64-bit keys (distance bits << 32 | cell
+    // index) - a squared distance is never negative, so its bit pattern orders like its value - one 64-bit compare and two
+    // selects per candidate where the two-level comparison took nine instructions
+    unsigned long long bk[2] = {~0ull, ~0ull};
     for (int k = 0; k < kmax; k += NC) {
       f32x4 c[2][NC];
 #pragma unroll
@@ -675,17 +677,17 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
         for (int w = 0; w < NC; w++) {
           const float dx = qx[u0 + v] - c[v][w].x, dy = qy[u0 + v] - c[v][w].y;
           float d2 = dx * dx; d2 += dy * dy;
-          const int ci = __float_as_int(c[v][w].z);
-          const bool take = (k + w < tot[v]) & ((d2 < bd[v]) | ((d2 == bd[v]) & (ci < best[v])));
-          bd[v] = take ? d2 : bd[v];
-          best[v] = take ? ci : best[v];
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)__float_as_uint(c[v][w].z);
+          const bool take = (k + w < tot[v]) & (key < bk[v]);
+          bk[v] = take ? key : bk[v];
         }
       }
     }
 #pragma unroll
     for (int v = 0; v < 2; v++) {
       const int u = u0 + v;
-      ti[u] = (best[v] >= 0 && (double)bd[v] < curr_radius * curr_radius) ? best[v] : -1;
+      const float bd = __uint_as_float((unsigned)(bk[v] >> 32));
+      ti[u] = (bk[v] != ~0ull && (double)bd < curr_radius * curr_radius) ? (int)(unsigned)bk[v] : -1;
       if (u >= nk) ti[u] = -1;
     }
   };
