@@ -136,7 +136,7 @@ __device__ __forceinline__ void features_step_body(unsigned char* lds /* FeatLds
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 
-template <bool TIMED>
+template <bool TIMED, int KCOST = -1>
 __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds::total bytes */, int q, const OdoParams& OP, SeqState* states,
                                                    const BlockScratch* scratch, double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                    double* poses_out /*[B][3]*/) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
   if (tid >= 64 && tid < 100) cov_work[(size_t)q * 36 + (tid - 64)] = ((tid - 64) % 7 == 0) ? 1.0 : 0.0;
   __syncthreads();
   const RegScratch RW = make_rscratch(B, lds);
-  register_block(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),
+  register_block<KCOST>(sp, ns, poses, cov_work + (size_t)q * 36, OP.rp, RW, reinterpret_cast<double*>(lds + RegLds::par),
                  reinterpret_cast<RegShared*>(lds + RegLds::regsh), sum, TIMED ? &pt : nullptr);  // :186 (result ignored, :184-186)
   __syncthreads();
   if (TIMED) pt.mark();

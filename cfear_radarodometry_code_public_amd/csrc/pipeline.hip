@@ -131,13 +131,14 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
 #ifndef CFEAR_REG_MIN_WG
 #define CFEAR_REG_MIN_WG 3  // workgroups per compute unit the registration step kernel is compiled for (tools: A/B builds)
 #endif
-template <bool TIMED>
+// KCOST: the cost metric the kernel is compiled for (registration_dev.h evaluate_partial), -1: any (the timed instantiation)
+template <bool TIMED, int KCOST>
 __global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  register_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
+  register_step_body<TIMED, KCOST>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
 }
 
 // ---- host-side helpers ---------------------------------------------------------------------------
@@ -346,6 +347,16 @@ static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
   return OP;
 }
 // features -> registration of one sweep of every sequence on `st`, from the filter's slots
+// the registration step kernel of a sweep: the instantiation for the context's cost metric (the per-phase timers: one for all)
+static void launch_register_step(const OdoParams& P, int count, hipStream_t st, cfear_odometry* o) {
+#define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs, \
+                                                  o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out)
+  if (P.phase_times) CFEAR_LAUNCH_REG(true, -1);
+  else if (P.rp.cost == CFEAR_COST_P2L) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2L);
+  else if (P.rp.cost == CFEAR_COST_P2D) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2D);
+  else CFEAR_LAUNCH_REG(false, CFEAR_COST_P2P);
+#undef CFEAR_LAUNCH_REG
+}
 static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoParams& P, const uint32_t* d_slots, int seq_count, hipStream_t st) {
   if (P.phase_times)
     hipLaunchKernelGGL(features_step_kernel<true>, dim3(seq_count), dim3(BLOCK_F), 0, st, d_slots, ctx->d_trig, P, o->d_states,
@@ -353,12 +364,7 @@ static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoP
   else
     hipLaunchKernelGGL(features_step_kernel<false>, dim3(seq_count), dim3(BLOCK_F), 0, st, d_slots, ctx->d_trig, P, o->d_states,
                        o->d_scan_ptrs, o->d_scratch_hdr);
-  if (P.phase_times)
-    hipLaunchKernelGGL(register_step_kernel<true>, dim3(seq_count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-  else
-    hipLaunchKernelGGL(register_step_kernel<false>, dim3(seq_count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs,
-                       o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+  launch_register_step(P, seq_count, st, o);
 }
 
 // per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
@@ -1036,12 +1042,7 @@ int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
                          o->d_scan_ptrs, o->d_scratch_hdr);
     if (o->overlap) CFEAR_HIP_CHECK(ctx, hipEventRecord(o->ev_free[buf][i], so));
     if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
-    if (P.phase_times)
-      hipLaunchKernelGGL(register_step_kernel<true>, dim3(count), dim3(BLOCK_R), 0, so, P, o->d_states, o->d_scan_ptrs,
-                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
-    else
-      hipLaunchKernelGGL(register_step_kernel<false>, dim3(count), dim3(BLOCK_R), 0, so, P, o->d_states, o->d_scan_ptrs,
-                         o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    launch_register_step(P, count, so, o);
     if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, so)) != CFEAR_OK) return rc;
   }
   if (o->overlap) o->filt_pending[buf] = true;

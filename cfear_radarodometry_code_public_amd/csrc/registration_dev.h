@@ -400,8 +400,22 @@ __device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int
   if (lds_match) evaluate_partial_t<true, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
   else evaluate_partial_t<false, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
 }
+// KCOST: the cost metric when the kernel is compiled for one (CFEAR_COST_*; the batched registration kernel exists once per cost:
+// no dispatch, and Huber with the matches in LDS - every preset of the reference - evaluates inline whatever the cost), -1: read
+// from the parameters at run time (per-call API, the replay kernel)
+template <int KCOST = -1>
 __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                  double* res_out = nullptr, int res_cap = 0) {
+  if (KCOST >= 0) {
+    constexpr int KC = KCOST >= 0 ? KCOST : CFEAR_COST_P2L;
+    if (ls->rp.loss == CFEAR_LOSS_HUBER) {
+      if (lds_match && !res_out) evaluate_partial_t<true, KC, true>(ls, M, x0, x1, c, s, nullptr, 0);
+      else evaluate_partial_c<KC, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    } else {
+      evaluate_partial_c<KC, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    }
+    return;
+  }
   const int cost = ls->rp.cost;
   // the default configuration (P2L, Huber, matches in LDS) inline in the kernel: out of line, its two interleaved chains reach
   // the callee-saved registers, whose save / restore through scratch is a round trip to memory per evaluation
@@ -743,11 +757,12 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 // residual blocks of one source cell (up to four keyframes); pos = four 16-bit positions in the match arrays.
 // The source cell is read once; matches that fit the LDS array are stored through an LDS-typed pointer (ds_write, not
 // flat stores through the address unit). Same arithmetic as write_match.
+template <int KCOST = -1>
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
                                           int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
   // block-uniform values in scalar registers: read from LDS they sit in vector registers, and every branch on them is compiled as
   // a divergent one (save the exec mask, branch, restore)
-  const int cost = __builtin_amdgcn_readfirstlane(sh->rp.cost), weight_opt = __builtin_amdgcn_readfirstlane(sh->rp.weight_opt);
+  const int cost = KCOST >= 0 ? KCOST : __builtin_amdgcn_readfirstlane(sh->rp.cost), weight_opt = __builtin_amdgcn_readfirstlane(sh->rp.weight_opt);
   use_lds = __builtin_amdgcn_readfirstlane((int)use_lds) != 0;
   typedef __attribute__((address_space(1))) const double g_cf64;
   typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -850,6 +865,7 @@ __device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LReg
 }
 // residual blocks of block b of the source cells; before = matches in front of this block, per keyframe. Returns the
 // matches of the block per keyframe (0 when the block is the only one: nothing follows it).
+template <int KCOST = -1>
 __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int b,
                                                       Assoc4 a, unsigned long long e, unsigned long long before, bool use_lds) {
   const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
@@ -859,10 +875,11 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
     if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
     e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
   }
-  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell(scans, src, sh, nsrc, nk, j, a, before + e, use_lds);
+  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell<KCOST>(scans, src, sh, nsrc, nk, j, a, before + e, use_lds);
   return tb;
 }
 
+template <int KCOST = -1>
 __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, LRegShared* sh, int itr) {
   const ScanDev* src = scans[n - 1];
   const int nsrc = sh->kf[n - 1].n_cells;  // (the view in LDS: src->n_cells is a round trip to memory in front of every association)
@@ -879,16 +896,16 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= match_lds_cap(sh->rp.cost);
-      (void)emit_block(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), use_lds);
+      use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+      (void)emit_block<KCOST>(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), use_lds);
     } else {
       unsigned long long T = 0;
       for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, nk, nsrc, itr, b).tb;  // every field <= nsrc <= 4 * blockDim
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= match_lds_cap(sh->rp.cost);
+      use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
       unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
-      for (int b = 0; b * nt < nsrc; b++) before += emit_block(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
+      for (int b = 0; b * nt < nsrc; b++) before += emit_block<KCOST>(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
     }
   } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
@@ -901,7 +918,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       cnt += (ti >= 0) ? 1 : 0;
     }
     int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
-    use_lds = M <= match_lds_cap(sh->rp.cost);
+    use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];
       if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, use_lds);
@@ -1262,6 +1279,7 @@ __device__ __forceinline__ void ctl_step(LRegShared* sh, long long* acc = nullpt
 // n_scan_normal_reg::Register. poses: n x 3 in global memory (in/out); cov6: 36 doubles or null;
 // out: summary in global memory. par_lds: >= 3*n doubles of LDS; sh: RegShared in LDS.
 // Wave 0 is the controller; every wave executes the published commands (two barriers per command).
+template <int KCOST = -1>
 __device__ inline int register_block(ScanDev* const* scans, int n, double* poses, double* cov6, const RegParams& P_in,
                                      const RegScratch& W_in, double* par_lds, RegShared* sh, cfear_reg_summary* out,
                                      PhaseTimer* pt = nullptr, const double* prior_cov6 = nullptr) {
@@ -1336,15 +1354,15 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     if (acc2) tb = (long long)wall_clock64();
     if (cmd == REG_CMD_BUILD) {
       if (pt) pt->mark();
-      const int M = build_problem_block(scans, n, ls, ls->itr);
+      const int M = build_problem_block<KCOST>(scans, n, ls, ls->itr);
       if (tid == 0) ls->M = M;
       // the first evaluation of the solve that follows, at the pose the problem was built for: straight away instead of as a
       // command of its own (a barrier pair and a turn of the controller less per outer iteration); block-uniform condition,
       // the same as ctl_after_build's
-      if (M * ((ls->rp.cost == CFEAR_COST_P2L) ? 1 : 2) > 1) evaluate_partial(ls, M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
+      if (M * (((KCOST >= 0 ? KCOST : ls->rp.cost) == CFEAR_COST_P2L) ? 1 : 2) > 1) evaluate_partial<KCOST>(ls, M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
       if (pt) pt->mark();
     } else {
-      evaluate_partial(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
+      evaluate_partial<KCOST>(ls, ls->M, ls->lds_match, ls->x[0], ls->x[1], ls->c, ls->s);
     }
     long long t1 = 0;
     if (pt && (pt->acc || acc2) && tid == 0) t1 = (long long)wall_clock64();
