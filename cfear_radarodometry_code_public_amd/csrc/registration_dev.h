@@ -151,7 +151,7 @@ struct RegIo {  // where the controller reads/writes the caller-visible data
 struct RegShared {
   // command published by the controller (wave 0) to all waves
   int cmd, itr, M, state;
-  int lds_match, pad_a;  // compacted matches live in the LDS match array (M <= match_lds_cap(cost))
+  int lds_match, pad_a;  // where the compacted matches live: 1 the LDS match array (M <= match_lds_cap(cost)), 2 its capacity there and the rest in memory, 0 memory
   double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
   double c, s;  // cos/sin of x[2], computed once by the controller
   double cur_c, cur_s, prev_c, prev_s;  // cos/sin of xcur[2] and prev_par[2]: the values published with the evaluation that produced
@@ -252,7 +252,9 @@ __device__ __forceinline__ MatchPtrs match_ptrs_lds(int cost) {  // null where t
 // with (c, s) = (cos, sin)(theta). Residuals: n_scan_normal.h:190-201 (P2L), :224-243 (P2D), :336-350 (P2P);
 // corrector = sqrt(rho'). Only the first CFEAR_EVAL_WAVES waves work; lane 0 of each leaves its partial
 // sums in W.red[i * 32 + wave].
-template <bool LDS, int COST, bool HUBER>
+// SRC: where the matches are - 0: the arrays in memory, 1: the LDS array, 2: the first match_lds_cap(COST) of them in the LDS array
+// and the rest in memory (a problem with more residual blocks than the LDS array holds: dense scenes)
+template <int SRC, int COST, bool HUBER>
 __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, double x0, double x1, double c, double s,
                                                    double* res_out, int res_cap) {
   const int wave = threadIdx.x >> 6;
@@ -261,7 +263,11 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
   typedef __attribute__((address_space(3))) const double lds_cdouble;
   struct Rd {
     lds_cdouble* l; const double* g; size_t cap;
-    __device__ __forceinline__ double operator()(int arr, int i) const { return LDS ? l[match_lds_idx(COST, arr) * match_lds_cap(COST) + i] : g[arr * cap + i]; }
+    __device__ __forceinline__ double operator()(int arr, int i) const {
+      if (SRC == 1) return l[match_lds_idx(COST, arr) * match_lds_cap(COST) + i];
+      if (SRC == 0) return g[arr * cap + i];
+      return i < match_lds_cap(COST) ? l[match_lds_idx(COST, arr) * match_lds_cap(COST) + i] : g[arr * cap + i];
+    }
   } rd;
   rd.l = (lds_cdouble*)lds_match_base(); rd.g = ls->rw.tmx; rd.cap = (size_t)ls->rw.cap;
   const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
@@ -276,8 +282,31 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     // by sqrt(rho' w) first, which is how GetCost's residuals below are still formed.)
     constexpr int nr = (COST == CFEAR_COST_P2L) ? 1 : 2;
     struct Head { double r[2], J[2][3], w2, cost; };  // what a match contributes, before it is multiplied out (few live registers)
-    auto head = [&](int i, bool on) -> Head {
+    // the values of match i the cost reads (array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w), from LDS or from memory: one
+    // branch per match, global_load (not flat) for the copy in memory
+    struct Raw { double v[8]; };
+    typedef __attribute__((address_space(1))) const double g_cdouble;
+    auto load = [&](int i) -> Raw {
+      Raw r;
+      constexpr int lc = match_lds_cap(COST);
+      auto from_lds = [&]() {
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.v[q] = match_lds_idx(COST, q) >= 0 ? rd.l[(match_lds_idx(COST, q) >= 0 ? match_lds_idx(COST, q) : 0) * lc + i] : 0.0;
+      };
+      auto from_mem = [&]() {
+        g_cdouble* g = (g_cdouble*)rd.g;
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.v[q] = match_lds_idx(COST, q) >= 0 ? g[q * rd.cap + i] : 0.0;
+      };
+      if (SRC == 1) from_lds();
+      else if (SRC == 0) from_mem();
+      else { if (i < lc) from_lds(); else from_mem(); }
+      return r;
+    };
+    auto head = [&](const Raw& raw, bool on) -> Head {
       Head h;
+      auto rd = [&](int q, int) -> double { return raw.v[q]; };
+      const int i = 0;
       const double sx = rd(5, i), sy = rd(6, i), tmx = rd(0, i), tmy = rd(1, i), wgt = on ? rd(7, i) : 0.0;
       const double px = (c * sx - s * sy) + x0;
       const double py = (s * sx + c * sy) + x1;
@@ -326,11 +355,28 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
         a.h11 += j1 * h.J[k][1]; a.h12 += j1 * h.J[k][2]; a.h22 += j2 * h.J[k][2];
       }
     };
+    if (SRC == 1) {
 #pragma unroll 1
-    for (int i = threadIdx.x; i < M; i += 2 * nthr) {  // array order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
-      const bool onb = i + nthr < M;
-      const Head A = head(i, true), B = head(onb ? i + nthr : i, onb);
-      add(A); add(B);
+      for (int i = threadIdx.x; i < M; i += 2 * nthr) {
+        const bool onb = i + nthr < M;
+        const Head A = head(load(i), true), B = head(load(onb ? i + nthr : i), onb);
+        add(A); add(B);
+      }
+    } else if (threadIdx.x < M) {
+      // matches in memory: the loads of the next pair are issued before this pair is worked on (trip after trip, each waited
+      // for its own round trip: 3.6-5.5 us per evaluation of a dense scene's 1100 blocks against 1.5 us out of LDS)
+      int i = threadIdx.x;
+      Raw ra = load(i), rb = load(i + nthr < M ? i + nthr : i);
+#pragma unroll 1
+      for (; i < M; i += 2 * nthr) {
+        const int in = i + 2 * nthr;
+        const int ia = in < M ? in : i, ib = in + nthr < M ? in + nthr : ia;
+        const Raw na = load(ia), nb = load(ib);
+        const bool onb = i + nthr < M;
+        const Head A = head(ra, true), B = head(rb, onb);
+        add(A); add(B);
+        ra = na; rb = nb;
+      }
     }
   } else
   for (int i = threadIdx.x; i < M; i += nthr) {  // GetCost: also the robustified residuals, in residual-block order
@@ -397,8 +443,9 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
 template <int COST, bool HUBER>
 __device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                 double* res_out, int res_cap) {
-  if (lds_match) evaluate_partial_t<true, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
-  else evaluate_partial_t<false, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
+  if (lds_match == 1) evaluate_partial_t<1, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
+  else if (lds_match == 2) evaluate_partial_t<2, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_t<0, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
 }
 // KCOST: the cost metric when the kernel is compiled for one (CFEAR_COST_*; the batched registration kernel exists once per cost:
 // no dispatch, and Huber with the matches in LDS - every preset of the reference - evaluates inline whatever the cost), -1: read
@@ -409,7 +456,7 @@ __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, in
   if (KCOST >= 0) {
     constexpr int KC = KCOST >= 0 ? KCOST : CFEAR_COST_P2L;
     if (ls->rp.loss == CFEAR_LOSS_HUBER) {
-      if (lds_match && !res_out) evaluate_partial_t<true, KC, true>(ls, M, x0, x1, c, s, nullptr, 0);
+      if (lds_match == 1 && !res_out) evaluate_partial_t<1, KC, true>(ls, M, x0, x1, c, s, nullptr, 0);
       else evaluate_partial_c<KC, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
     } else {
       evaluate_partial_c<KC, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
@@ -419,8 +466,8 @@ __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, in
   const int cost = ls->rp.cost;
   // the default configuration (P2L, Huber, matches in LDS) inline in the kernel: out of line, its two interleaved chains reach
   // the callee-saved registers, whose save / restore through scratch is a round trip to memory per evaluation
-  if (ls->rp.loss == CFEAR_LOSS_HUBER && cost == CFEAR_COST_P2L && lds_match && !res_out) {
-    evaluate_partial_t<true, CFEAR_COST_P2L, true>(ls, M, x0, x1, c, s, nullptr, 0);
+  if (ls->rp.loss == CFEAR_LOSS_HUBER && cost == CFEAR_COST_P2L && lds_match == 1 && !res_out) {
+    evaluate_partial_t<1, CFEAR_COST_P2L, true>(ls, M, x0, x1, c, s, nullptr, 0);
     return;
   }
   if (ls->rp.loss == CFEAR_LOSS_HUBER) {
@@ -759,11 +806,11 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 // flat stores through the address unit). Same arithmetic as write_match.
 template <int KCOST = -1>
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
-                                          int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, bool use_lds) {
+                                          int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, int mode /* RegShared::lds_match */) {
   // block-uniform values in scalar registers: read from LDS they sit in vector registers, and every branch on them is compiled as
   // a divergent one (save the exec mask, branch, restore)
   const int cost = KCOST >= 0 ? KCOST : __builtin_amdgcn_readfirstlane(sh->rp.cost), weight_opt = __builtin_amdgcn_readfirstlane(sh->rp.weight_opt);
-  use_lds = __builtin_amdgcn_readfirstlane((int)use_lds) != 0;
+  mode = __builtin_amdgcn_readfirstlane(mode);
   typedef __attribute__((address_space(1))) const double g_cf64;
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) const f64x2 g_cf64x2;
@@ -828,8 +875,8 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
       a2 = 0.0;
     }
     if (on) {  // one predicated region for the stores of a match; arrays in the order of match_ptrs(): tmx tmy a0 a1 a2 sx sy w
-      if (use_lds) {  // the LDS array keeps what the cost reads (match_lds_idx)
-        const int lc = match_lds_cap(cost);
+      const int lc = match_lds_cap(cost);
+      if (mode == 1 || (mode == 2 && o < lc)) {  // the LDS array keeps what the cost reads (match_lds_idx)
         lm[0] = tmx; lm[lc] = tmy;
         if (cost == CFEAR_COST_P2D) { lm[2 * lc] = a0; lm[3 * lc] = a1; lm[4 * lc] = a2; lm[5 * lc] = cs.mx; lm[6 * lc] = cs.my; lm[7 * lc] = wgt; }
         else if (cost == CFEAR_COST_P2L) { lm[2 * lc] = a0; lm[3 * lc] = a1; lm[4 * lc] = cs.mx; lm[5 * lc] = cs.my; lm[6 * lc] = wgt; }
@@ -867,7 +914,7 @@ __device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LReg
 // matches of the block per keyframe (0 when the block is the only one: nothing follows it).
 template <int KCOST = -1>
 __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int b,
-                                                      Assoc4 a, unsigned long long e, unsigned long long before, bool use_lds) {
+                                                      Assoc4 a, unsigned long long e, unsigned long long before, int mode) {
   const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
   unsigned long long tb = 0;
   if (nsrc > CFEAR_REG_BLOCK) {  // positions inside the block: the same scan again (cheaper than keeping them)
@@ -875,7 +922,7 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
     if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
     e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
   }
-  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell<KCOST>(scans, src, sh, nsrc, nk, j, a, before + e, use_lds);
+  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell<KCOST>(scans, src, sh, nsrc, nk, j, a, before + e, mode);
   return tb;
 }
 
@@ -886,7 +933,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   const int pairs = (n - 1) * nsrc;
   const int nt = CFEAR_REG_BLOCK, tid = threadIdx.x;
   int M;
-  bool use_lds;
+  int mode;  // RegShared::lds_match
   const int nk = n - 1;
   const bool can_park = 4 * (long long)nsrc <= (long long)sh->rw.cap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
   if (nk <= 4 && (nsrc <= nt || (nsrc <= 4 * nt && can_park))) {
@@ -896,16 +943,16 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
-      (void)emit_block<KCOST>(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), use_lds);
+      mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 2;
+      (void)emit_block<KCOST>(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
     } else {
       unsigned long long T = 0;
       for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, nk, nsrc, itr, b).tb;  // every field <= nsrc <= 4 * blockDim
       const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
       M = (int)(t0 + t1 + t2 + t3);
-      use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+      mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 2;
       unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
-      for (int b = 0; b * nt < nsrc; b++) before += emit_block<KCOST>(scans, src, sh, nk, nsrc, b, none, 0, before, use_lds);
+      for (int b = 0; b * nt < nsrc; b++) before += emit_block<KCOST>(scans, src, sh, nk, nsrc, b, none, 0, before, mode);
     }
   } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
@@ -918,13 +965,13 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       cnt += (ti >= 0) ? 1 : 0;
     }
     int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
-    use_lds = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+    mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 0;
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];
-      if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, use_lds);
+      if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, mode == 1);
     }
   }
-  if (tid == 0) sh->lds_match = use_lds ? 1 : 0;
+  if (tid == 0) sh->lds_match = mode;
   __syncthreads();
   return M;
 }
