@@ -72,3 +72,7 @@ extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_staging(cfear_
 extern "C" __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);
 // kstrongest.hip
 __attribute__((visibility("hidden"))) int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);
+
+// scans (keyframes + current) the batched registration kernels of register_step.hip are compiled for: pipeline.hip launches them
+// when submap_scan_size + 1 fits, its own 64-scan instantiation otherwise
+#define CFEAR_STEP_SMALL_SCANS 8

@@ -13,14 +13,15 @@ namespace {
 constexpr int BLOCK_F = CFEAR_FEAT_BLOCK;   // features / cloud kernels: two workgroups per compute unit (features_compact_dev.h)
 constexpr int BLOCK_R = CFEAR_REG_BLOCK;   // registration kernels: 256 threads (4 waves = one per SIMD) in pipeline.hip
 static_assert(BLOCK_R >= 64 * CFEAR_EVAL_WAVES, "the controller sums the partial results of CFEAR_EVAL_WAVES waves unconditionally");
-constexpr int MAX_SCANS = 64;  // keyframes + current
+constexpr int MAX_SCANS = 64;  // keyframes + current: the layout of SeqState in memory (the same in every translation unit, whatever CFEAR_REG_MAX_SCANS)
+static_assert(CFEAR_REG_MAX_SCANS <= MAX_SCANS, "a registration cannot have more scans than a sequence keeps");
 static_assert(FeatLdsC::total <= 80384, "two feature workgroups per compute unit");
 struct RegLds {  // registration kernels
   static constexpr size_t red_d = 0;                                  // 10 sums x CFEAR_RED_STRIDE waves
-  static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*MAX_SCANS doubles
-  static constexpr size_t red_i = par + 3 * MAX_SCANS * sizeof(double);  // 64 ints
-  static constexpr size_t scanptr = red_i + 64 * sizeof(int);        // MAX_SCANS pointers
-  static constexpr size_t regsh = scanptr + MAX_SCANS * sizeof(void*);  // RegShared
+  static constexpr size_t par = red_d + 10 * CFEAR_RED_STRIDE * sizeof(double);        // 3*CFEAR_REG_MAX_SCANS doubles
+  static constexpr size_t red_i = par + 3 * CFEAR_REG_MAX_SCANS * sizeof(double);  // 64 ints
+  static constexpr size_t scanptr = red_i + 64 * sizeof(int);        // CFEAR_REG_MAX_SCANS pointers
+  static constexpr size_t regsh = scanptr + CFEAR_REG_MAX_SCANS * sizeof(void*);  // RegShared
   static constexpr size_t total = (regsh + sizeof(RegShared) + 15) / 16 * 16;
 };
 
@@ -245,6 +246,21 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
     }
     if (!TIMED && OP.wg_times) OP.wg_times[(size_t)q * 32 + 15] = (long long)wall_clock64();
   }
+}
+
+
+
+#ifndef CFEAR_REG_MIN_WG
+#define CFEAR_REG_MIN_WG 3  // workgroups per compute unit the registration step kernel is compiled for (tools: A/B builds)
+#endif
+// KCOST: the cost metric the kernel is compiled for (registration_dev.h evaluate_partial), -1: any (the timed instantiation)
+template <bool TIMED, int KCOST>
+__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+                                                                const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
+                                                                double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
+                                                                double* poses_out /*[B][3]*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
+  register_step_body<TIMED, KCOST>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
 }
 
 

@@ -128,19 +128,6 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
-#ifndef CFEAR_REG_MIN_WG
-#define CFEAR_REG_MIN_WG 3  // workgroups per compute unit the registration step kernel is compiled for (tools: A/B builds)
-#endif
-// KCOST: the cost metric the kernel is compiled for (registration_dev.h evaluate_partial), -1: any (the timed instantiation)
-template <bool TIMED, int KCOST>
-__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
-                                                                const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
-                                                                double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
-                                                                double* poses_out /*[B][3]*/) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  register_step_body<TIMED, KCOST>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
-}
-
 // ---- host-side helpers ---------------------------------------------------------------------------
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -328,6 +315,10 @@ static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
 
 // replay.hip: features -> registration of `cnt` consecutive sweeps of every sequence in one launch (a persistent workgroup per
 // sequence); odo_params points at an OdoParams (the struct is local to each translation unit, same definition)
+// register_step.hip: the batched registration step kernel for registrations of up to CFEAR_STEP_SMALL_SCANS scans
+__attribute__((visibility("hidden"))) void cfear_launch_register_step_small(const void* odo_params, int count, hipStream_t st, void* states, void* const* scan_slots,
+                                                                           const void* scratch, double* poses_work, double* cov_work,
+                                                                           cfear_reg_summary* summaries, double* poses_out);
 __attribute__((visibility("hidden"))) void cfear_launch_replay_chunk(const uint32_t* d_slots, int cnt, int B, const double* d_trig, const void* odo_params,
                                                                     void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
                                                                     double* poses_out, cfear_sweep_record* records, hipStream_t stream);
@@ -347,14 +338,16 @@ static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
   return OP;
 }
 // features -> registration of one sweep of every sequence on `st`, from the filter's slots
-// the registration step kernel of a sweep: the instantiation for the context's cost metric (the per-phase timers: one for all)
+// the registration step kernel of a sweep. register_step.hip holds the production instantiations (one per cost metric, registrations of
+// up to CFEAR_STEP_SMALL_SCANS scans: a bigger LDS match array); a larger submap runs the instantiation of this file (any cost, 64 scans)
 static void launch_register_step(const OdoParams& P, int count, hipStream_t st, cfear_odometry* o) {
+  if (P.submap + 1 <= CFEAR_STEP_SMALL_SCANS) {
+    cfear_launch_register_step_small(&P, count, st, o->d_states, reinterpret_cast<void* const*>(o->d_scan_ptrs), o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    return;
+  }
 #define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs, \
                                                   o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out)
-  if (P.phase_times) CFEAR_LAUNCH_REG(true, -1);
-  else if (P.rp.cost == CFEAR_COST_P2L) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2L);
-  else if (P.rp.cost == CFEAR_COST_P2D) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2D);
-  else CFEAR_LAUNCH_REG(false, CFEAR_COST_P2P);
+  if (P.phase_times) CFEAR_LAUNCH_REG(true, -1); else CFEAR_LAUNCH_REG(false, -1);
 #undef CFEAR_LAUNCH_REG
 }
 static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoParams& P, const uint32_t* d_slots, int seq_count, hipStream_t st) {

@@ -131,7 +131,11 @@ struct NormalEq { double cost, g0, g1, g2, h00, h01, h02, h11, h12, h22; };
 
 struct SolveSummary { int num_iterations; int termination; double final_cost; double last_relative_decrease; };
 
-#define CFEAR_REG_MAX_SCANS 64
+#ifndef CFEAR_REG_MAX_SCANS
+#define CFEAR_REG_MAX_SCANS 64  // scans (keyframes + current) a registration of this translation unit can have: sizes the per-scan arrays
+                                // of RegShared. register_step.hip compiles the batched step kernel for 8 (submap_scan_size <= 7: every
+                                // preset of the reference) and spends the 10 KB of LDS that frees on the match array
+#endif
 #define CFEAR_RED_STRIDE 8  // partial sums of up to 8 waves per quantity (W.red)
 #define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
 #ifndef CFEAR_REG_BLOCK
