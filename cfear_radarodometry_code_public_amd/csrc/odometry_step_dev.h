@@ -25,7 +25,10 @@ struct RegLds {  // registration kernels
   static constexpr size_t total = (regsh + sizeof(RegShared) + 15) / 16 * 16;
 };
 
-static_assert(RegLds::total + sizeof(double) * CFEAR_MATCH_LDS_DOUBLES <= 53760,
+#ifndef CFEAR_REG_LDS_BUDGET
+#define CFEAR_REG_LDS_BUDGET 53760  // three registration workgroups per compute unit (replay.hip: one, with the whole unit's LDS)
+#endif
+static_assert(RegLds::total + sizeof(double) * CFEAR_MATCH_LDS_DOUBLES <= CFEAR_REG_LDS_BUDGET,
               "registration kernels: more than 53,760 B of LDS costs the third workgroup per compute unit");
 
 // Global per-sequence working memory (also one per context for the per-call API).

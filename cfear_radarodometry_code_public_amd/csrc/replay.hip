@@ -9,6 +9,10 @@
 // (CFEAR_REG_BLOCK = 512: the association takes 512 source cells per pass, waves 4..7 sit out the evaluations), the LDS
 // segment is the larger of the two stages' (one workgroup per compute unit is plenty for a replay: there are few sequences).
 #define CFEAR_REG_BLOCK 512
+// one workgroup per compute unit: the LDS the feature stage does not need while the registration runs is not the limit, the unit's
+// 160 KB are - 1200 residual blocks with all eight arrays (P2L 1371, P2P 1920) stay in LDS, a dense street canyon's 1100-1200 included
+#define CFEAR_MATCH_LDS_CAP 1200
+#define CFEAR_REG_LDS_BUDGET (160 * 1024)
 #include "common.h"
 #include "odometry_step_dev.h"
 
