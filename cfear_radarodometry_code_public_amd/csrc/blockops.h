@@ -273,7 +273,8 @@ __device__ __forceinline__ void wave_sum10_transposed(const double (&v)[10], dou
 }
 
 // In-place ascending bitonic sort of keys[0..p2) (p2 = power of two, padded by the caller).
-__device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int p2) {
+template <typename KeyPtr>
+__device__ __forceinline__ void block_bitonic_sort(KeyPtr keys, int p2) {
   for (int k = 2; k <= p2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();

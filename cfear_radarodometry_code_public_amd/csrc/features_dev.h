@@ -6,6 +6,7 @@
 // pointnormal.cpp:7-63, 151-162, 265-297 (features). Third-party behaviour restated from
 // SURVEY.md section 9 (PCL VoxelGrid, FLANN radius search).
 #pragma once
+#include <type_traits>
 #include "blockops.h"
 #include "../../include/cfear_hip.h"
 
@@ -387,42 +388,51 @@ __device__ inline int cloud_step_block(const uint32_t* __restrict__ slots, int A
     for (int i = 0; i < nwv; i++) { const int c = sl[i]; base += i < wv ? c : 0; total += c; }
     run = base;
   }
-  for (int r0 = 0; r0 < RC; r0 += 8) {
-    uint32_t sv[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t_wave + (r0 + u) * 64 + ln;
-      sv[u] = g_slots[((r0 + u < RC) & (t < items)) ? t : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int t = t_wave + (r0 + u) * 64 + ln;
-      const uint32_t s = sv[u];
-      const int range = CFEAR_SLOT_RANGE(s);
-      const bool hit = (r0 + u < RC) & (t < items) & (CFEAR_SLOT_VALID(s) != 0) & (range > min_range_bin);
-      const unsigned long long bal = __ballot(hit);
-      const int o = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-      run += __popcll(bal);
-      if (hit && o < cap) {
-        const int b = min(small ? (int)__umulhi((unsigned)t, magic) : (int)((unsigned)t / (unsigned)k), A - 1);
-        const double cb = tabbed ? ltab[6 * b + 4] : g_trig[2 * b], sb = tabbed ? ltab[6 * b + 5] : g_trig[2 * b + 1];
-        const double rad = range_res_half + range_res * range;
-        float x = (float)(rad * cb);  // :329
-        float y = (float)(rad * sb);  // :330
-        if (compensate) {
-          if (tabbed) compensate_point_tabbed(x, y, ltab + 6 * b, cb, sb, rad, m0, m1, m2, ccw);
-          else {  // utils.cpp:96-107 as written (out of line)
-            const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
-            x = p.x; y = p.y;
+  // (the block-uniform choices - bearing table, slot -> bearing by multiplication - as compile-time constants of the loop body: tested
+  // inside it they doubled its instruction count; the usual case is both)
+  auto points_pass = [&](auto tab_c, auto small_c) {
+    constexpr bool TAB = decltype(tab_c)::value, SMALL = decltype(small_c)::value;
+    for (int r0 = 0; r0 < RC; r0 += 8) {
+      uint32_t sv[8];
+  #pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t_wave + (r0 + u) * 64 + ln;
+        sv[u] = g_slots[((r0 + u < RC) & (t < items)) ? t : 0];
+      }
+  #pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int t = t_wave + (r0 + u) * 64 + ln;
+        const uint32_t s = sv[u];
+        const int range = CFEAR_SLOT_RANGE(s);
+        const bool hit = (r0 + u < RC) & (t < items) & (CFEAR_SLOT_VALID(s) != 0) & (range > min_range_bin);
+        const unsigned long long bal = __ballot(hit);
+        const int o = run + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        run += __popcll(bal);
+        if (hit && o < cap) {
+          const int b = min(SMALL ? (int)__umulhi((unsigned)t, magic) : (int)((unsigned)t / (unsigned)k), A - 1);
+          const double cb = TAB ? ltab[6 * b + 4] : g_trig[2 * b], sb = TAB ? ltab[6 * b + 5] : g_trig[2 * b + 1];
+          const double rad = range_res_half + range_res * range;
+          float x = (float)(rad * cb);  // :329
+          float y = (float)(rad * sb);  // :330
+          if (compensate) {
+            if (TAB) compensate_point_tabbed(x, y, ltab + 6 * b, cb, sb, rad, m0, m1, m2, ccw);
+            else {  // utils.cpp:96-107 as written (out of line)
+              const float2 p = compensate_point_plain(x, y, m0, m1, m2, ccw);
+              x = p.x; y = p.y;
+            }
           }
+          typedef float f32x3 __attribute__((ext_vector_type(3)));
+          typedef f32x3 __attribute__((aligned(4))) f32x3u;
+          *(__attribute__((address_space(1))) f32x3u*)(g_xyi + 3 * o) = f32x3{x, y, (float)CFEAR_SLOT_INTENSITY(s)};
+          mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
         }
-        typedef float f32x3 __attribute__((ext_vector_type(3)));
-        typedef f32x3 __attribute__((aligned(4))) f32x3u;
-        *(__attribute__((address_space(1))) f32x3u*)(g_xyi + 3 * o) = f32x3{x, y, (float)CFEAR_SLOT_INTENSITY(s)};
-        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
       }
     }
-  }
+  };
+  if (tabbed && small) points_pass(std::true_type{}, std::true_type{});
+  else if (tabbed) points_pass(std::true_type{}, std::false_type{});
+  else if (small) points_pass(std::false_type{}, std::true_type{});
+  else points_pass(std::false_type{}, std::false_type{});
   total = total < cap ? total : cap;
   bounds[0] = mnx; bounds[1] = mxx; bounds[2] = mny; bounds[3] = mxy;
   block_bounds<CFEAR_FEAT_BLOCK>(bounds, red_f);
@@ -449,7 +459,8 @@ __device__ inline void eig2(double a, double b, double c, double* lmin, double* 
   vmin[0] = -vmax[1]; vmin[1] = vmax[0];
 }
 
-__device__ inline int lower_bound_int(const int* a, int n, long long v) {
+template <typename IntPtr>
+__device__ inline int lower_bound_int(IntPtr a, int n, long long v) {
   int lo = 0, hi = n;
   while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)a[mid] < v) lo = mid + 1; else hi = mid; }
   return lo;
@@ -458,7 +469,8 @@ __device__ inline int lower_bound_int(const int* a, int n, long long v) {
 // shifted weighted moments of the points q in [a, b) of the sorted array that lie within r2 of (cx, cy)
 struct CellAcc { int m; double s0, s1x, s1y, sxx, sxy, syy; };
 // lane `sub` of a group of GS lanes takes the batches a + 4*sub, a + 4*(sub + GS), ... (the chunked caller uses sub = 0, GS = 1)
-__device__ __forceinline__ void accumulate_range(const float* __restrict__ sp, int a, int b, float cx, float cy, float r2,
+template <typename FloatPtr>
+__device__ __forceinline__ void accumulate_range(FloatPtr sp, int a, int b, float cx, float cy, float r2,
                                         int weight_intensity, CellAcc& A, int sub, int GS) {
   const double cxd = (double)cx, cyd = (double)cy;
   for (int q = a + 4 * sub; q < b; q += 4 * GS) {
@@ -608,6 +620,13 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   g_f64* const g_part = (g_f64*)W.part;
   g_f32* const g_samples = (g_f32*)W.samples;
   g_i32* const g_rng = (g_i32*)W.rng;
+  typedef __attribute__((address_space(1))) uint64_t g_u64;
+  g_u64* const g_keys = (g_u64*)W.keys;      // (every caller hands this path arrays in memory: make_fscratch)
+  g_i32* const g_order = (g_i32*)W.order;
+  g_i32* const g_vstart = (g_i32*)W.vstart;
+  g_i32* const g_vlist = (g_i32*)W.vlist;
+  g_i32* const g_tmpi = (g_i32*)W.tmpi;
+  g_f32* const g_spts = (g_f32*)W.spts;
   const int tid = threadIdx.x, nt = CFEAR_FEAT_BLOCK;
   const g_f32* const xyi = (const g_f32*)S->xyi;
   if (n <= 0) {  // reference: exit(0) (pointnormal.cpp:72-75)
@@ -643,38 +662,38 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       const uint64_t idx = (uint64_t)((long long)ijk0 + (long long)ijk1 * (long long)div0);
       key = (idx << 32) | (uint64_t)(uint32_t)i;
     }
-    W.keys[i] = key;
+    g_keys[i] = key;
   }
   if (pt) pt->mark();
-  block_bitonic_sort(W.keys, p2);  // [3P] std::sort on the voxel index, pinned as stable by the point index
+  block_bitonic_sort(g_keys, p2);  // [3P] std::sort on the voxel index, pinned as stable by the point index
   if (pt) pt->mark();
   // ---- voxel segments, sorted order ----
   {
     const int ipt = (n + nt - 1) / nt;
     const int i0 = tid * ipt, i1 = min(n, i0 + ipt);
     int cnt = 0;
-    for (int i = i0; i < i1; i++) cnt += (i == 0 || (W.keys[i] >> 32) != (W.keys[i - 1] >> 32)) ? 1 : 0;
+    for (int i = i0; i < i1; i++) cnt += (i == 0 || (g_keys[i] >> 32) != (g_keys[i - 1] >> 32)) ? 1 : 0;
     int nv;
     int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &nv);
     for (int i = i0; i < i1; i++) {
-      const uint64_t k = W.keys[i];
-      W.order[i] = (int)(uint32_t)k;
-      if (i == 0 || (k >> 32) != (W.keys[i - 1] >> 32)) { W.vstart[o] = i; W.vlist[o] = (int)(k >> 32); o++; }
+      const uint64_t k = g_keys[i];
+      g_order[i] = (int)(uint32_t)k;
+      if (i == 0 || (k >> 32) != (g_keys[i - 1] >> 32)) { g_vstart[o] = i; g_vlist[o] = (int)(k >> 32); o++; }
     }
     nv_out = nv;
-    if (tid == 0) { W.vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
+    if (tid == 0) { g_vstart[nv] = n; S->n_samples = nv; S->n_points = n; S->status = 0; }
     __syncthreads();
   }
   }
   const int nv = nv_out;  // known to every thread: no read-back of S->n_samples through memory
   // stage the points in sorted order (over the key region when it is in LDS: every key has been consumed)
   for (int q = tid; q < n; q += nt) {
-    const int pi = W.order[q];
-    W.spts[3 * q] = xyi[3 * pi]; W.spts[3 * q + 1] = xyi[3 * pi + 1]; W.spts[3 * q + 2] = xyi[3 * pi + 2];
+    const int pi = g_order[q];
+    g_spts[3 * q] = xyi[3 * pi]; g_spts[3 * q + 1] = xyi[3 * pi + 1]; g_spts[3 * q + 2] = xyi[3 * pi + 2];
   }
   __syncthreads();
   if (pt) pt->mark();
-  const float* __restrict__ sp = W.spts;
+  const g_f32* const sp = g_spts;
   // ---- centroids: float sums in ascending (voxel, point) order, divided by float(count) ([3P] PCL CentroidPoint) ----
   // (the same loop goes on to the sample's candidate ranges below: the centroid stays in registers instead of being read
   // back from memory behind a barrier)
@@ -688,11 +707,11 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   // candidates: (1) per sample the candidate row ranges and their total, (2) a scan turns them into a chunk
   // list, (3) one lane per chunk accumulates partial moments, (4) the epilogue adds a sample's partials in
   // chunk order (deterministic).
-  int* __restrict__ T = W.order;  // the sorted order has been consumed by the staging above
+  g_i32* const T = g_order;  // the sorted order has been consumed by the staging above
   for (int v = tid; v < nv; v += nt) {
     float cx, cy;
     {
-      const int a = W.vstart[v], b = W.vstart[v + 1];
+      const int a = g_vstart[v], b = g_vstart[v + 1];
       float sx = 0.f, sy = 0.f, si = 0.f;
       for (int q = a; q < b; q++) { sx += sp[3 * q]; sy += sp[3 * q + 1]; si += sp[3 * q + 2]; }
       const float cnt = (float)(b - a);
@@ -704,7 +723,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
     int tot = 0, nr = 0;
     int R[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long vid = W.vlist[v];
+    const long long vid = g_vlist[v];
     for (int gy = gy0; gy <= gy1 && gx0 <= gx1; gy++) {
       // voxels gx0..gx1 of this row are contiguous in the sorted order: search the voxel list
       const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
@@ -713,10 +732,10 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       int lo, hi;
       if (k0 <= vid) { lo = v - (int)min((long long)v, vid - k0); hi = v; }
       else { lo = v; hi = (int)min((long long)nv, (long long)v + (k0 - vid)); }
-      const int p0 = lo + lower_bound_int(W.vlist + lo, hi - lo, k0);
+      const int p0 = lo + lower_bound_int(g_vlist + lo, hi - lo, k0);
       int p1 = p0;
-      while (p1 < nv && (long long)W.vlist[p1] <= k1) p1++;
-      const int a = W.vstart[p0], b = W.vstart[p1];
+      while (p1 < nv && (long long)g_vlist[p1] <= k1) p1++;
+      const int a = g_vstart[p0], b = g_vstart[p1];
       if (b > a) {
 #pragma unroll
         for (int u = 0; u < 4; u++)  // static indices: a run-time index would move R[] to per-thread scratch
@@ -733,8 +752,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   }
   const bool wide = (int)(2.0f * rq * inv) + 2 > 4;  // block-uniform
   if (wide) {
-    for (int i = tid; i < nv; i += nt) { W.tmpi[i] = W.vlist[i]; W.tmpi[W.cap + 8 + i] = W.vstart[i]; }
-    if (tid == 0) W.tmpi[W.cap + 8 + nv] = W.vstart[nv];
+    for (int i = tid; i < nv; i += nt) { g_tmpi[i] = g_vlist[i]; g_tmpi[W.cap + 8 + i] = g_vstart[i]; }
+    if (tid == 0) g_tmpi[W.cap + 8 + nv] = g_vstart[nv];
   }
   __syncthreads();
   if (pt) pt->mark();
@@ -752,17 +771,17 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     }
     for (int i = i0; i < i1; i++) {  // vstart/vlist are free now: chunk start per sample, sample per chunk
       const int c = (T[i] + C - 1) >> CS;
-      W.vstart[i] = o;
-      for (int j = 0; j < c; j++) W.vlist[o + j] = i;
+      g_vstart[i] = o;
+      for (int j = 0; j < c; j++) g_vlist[o + j] = i;
       o += c;
     }
-    if (tid == 0) W.vstart[nv] = NC;
+    if (tid == 0) g_vstart[nv] = NC;
     __syncthreads();
   }
   if (pt) pt->mark();
   for (int w = tid; w < NC; w += nt) {
-    const int v = W.vlist[w];
-    const int j = w - W.vstart[v];
+    const int v = g_vlist[w];
+    const int j = w - g_vstart[v];
     float cx, cy;
     i32x4 r0, r1;
     {
@@ -791,8 +810,8 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       int gx0 = (int)(floorf((cx - rq) * inv) - (float)min_b0), gx1 = (int)(floorf((cx + rq) * inv) - (float)min_b0);
       int gy0 = (int)(floorf((cy - rq) * inv) - (float)min_b1), gy1 = (int)(floorf((cy + rq) * inv) - (float)min_b1);
       gx0 = max(gx0, 0); gy0 = max(gy0, 0); gx1 = min(gx1, div0 - 1); gy1 = min(gy1, div1 - 1);
-      const int* vl = W.tmpi;  // copies of vlist/vstart made before they were reused
-      const int* vs = W.tmpi + W.cap + 8;
+      const g_i32* vl = g_tmpi;  // copies of vlist/vstart made before they were reused
+      const g_i32* vs = g_tmpi + W.cap + 8;
       for (int gy = gy0; gy <= gy1 && left > 0; gy++) {
         const long long k0 = (long long)gx0 + (long long)gy * div0, k1 = (long long)gx1 + (long long)gy * div0;
         const int p0 = lower_bound_int(vl, nv, k0);
@@ -824,7 +843,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       if (v < nv) {
         double md = 0, s0 = 0, s1x = 0, s1y = 0, sxx = 0, sxy = 0, syy = 0;
         const size_t cs = (size_t)W.cap;
-        const int w0 = W.vstart[v], w1 = W.vstart[v + 1];
+        const int w0 = g_vstart[v], w1 = g_vstart[v + 1];
         // two chunks per trip: all fourteen loads in flight together, added in chunk order (a sample has one to three chunks
         // as a rule: one round trip to memory instead of one per chunk)
         for (int w = w0; w < w1; w += 2) {
