@@ -174,7 +174,7 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS = 1, 2, 3, 4, 5
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT = 1, 2, 3, 4, 5, 6
 
 
 class Context:
@@ -354,8 +354,9 @@ class Context:
         return bool(ok.value), cov.reshape(6, 6), costs
 
     def pinned(self, shape, dtype=np.uint8):
-        """Page-locked host array (cfear_host_alloc): copies from it overlap with kernels. Freed by pinned_free(arr) or when
-        the context closes."""
+        """Page-locked host array (cfear_host_alloc): copies from it overlap with kernels. Freed by pinned_free(arr) - arr or any
+        view / slice of it - or when the context closes: the array and its views must not be touched after either (the memory is
+        gone; NumPy cannot know)."""
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
         self._check(self._L.cfear_host_alloc(self._h, nbytes, C.byref(ptr)), "cfear_host_alloc")
@@ -366,8 +367,13 @@ class Context:
         return arr
 
     def pinned_free(self, arr):
-        ptr = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
-        if ptr is not None and self._h:
+        root = arr
+        while isinstance(getattr(root, "base", None), np.ndarray):  # a view / slice: the allocation is its root array's
+            root = root.base
+        ptr = getattr(self, "_pinned", {}).pop(root.ctypes.data, None)
+        if ptr is None:
+            raise ValueError("pinned_free: not an array of Context.pinned() of this context (or already freed)")
+        if self._h:
             self._L.cfear_host_free(self._h, ptr)
 
     def odometry(self, n_sequences, overlap=None, filter_cus=None):

@@ -512,7 +512,7 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   // rows over the resident slots.
   const long long slots_total = 1024LL * occ_eff;
   int rows_per_wave = (int)((n_rows + slots_total - 1) / slots_total);
-  const int rows_cap = ctx->tune_k1_rows > 0 ? ctx->tune_k1_rows : (n_rows >= 1536LL * 400 ? 6 : 4);
+  const int rows_cap = ctx->tune_k1_rows > 0 ? ctx->tune_k1_rows : (n_scans >= 1536 ? 6 : 4);
   if (rows_per_wave > rows_cap) rows_per_wave = rows_cap;
   if (rows_per_wave < 1) rows_per_wave = 1;
   const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;

@@ -143,6 +143,7 @@ FeatureParams feature_params(const cfear_ctx* ctx) {
 RegParams reg_params(const cfear_ctx* ctx) {
   RegParams P;
   P.cost = ctx->par.cost; P.loss = ctx->par.loss; P.weight_opt = ctx->par.weight_opt;
+  P.recompute_repeats = ctx->tune_repeat_shortcut ? 0 : 1;
   P.loss_limit = ctx->par.loss_limit; P.covar_scale = ctx->par.covar_scale; P.regularization = ctx->par.regularization;
   P.assoc_radius = ctx->par.assoc_radius;
   P.max_outer = ctx->par.max_itr_association; P.min_itr = ctx->par.min_itr; P.max_inner = ctx->par.max_solver_iterations;
@@ -255,7 +256,9 @@ struct cfear_odometry {
   hipEvent_t rp_filt[2] = {nullptr, nullptr}, rp_used[2] = {nullptr, nullptr};  // chunk filtered / chunk consumed by the odometry kernels
   hipEvent_t rp_in = nullptr;  // device-resident frames ready on the context stream
   bool rp_used_pending[2] = {false, false};
-  int rp_chunk = 0;            // sweeps per chunk the buffers are sized for
+  bool rp_ready = false;       // stream + events exist
+  int rp_chunk = 0;            // sweeps per chunk the slot buffers are sized for
+  int rp_polar_chunk = 0;      // ... and the staging buffers (allocated on the first replay from host memory only)
   cfear_sweep_record* d_records = nullptr;
   size_t records_cap = 0;      // records
   long long* d_phase_times = nullptr;  // optional [B][32] (cfear_odometry_phase_times)
@@ -709,7 +712,8 @@ namespace {
 // Minimum-norm least squares of A c = b (A: m x 10), what Eigen's bdcSvd().solve() returns (odometrykeyframefuser.cpp:337), by a
 // one-sided Jacobi (Hestenes) singular value decomposition: plane rotations from the right make the columns of W = A V
 // mutually orthogonal; then the singular values are the column norms, U = W / sigma, and c = V diag(1 / sigma) U^T b over the
-// singular values above the rank threshold (Eigen's default: max(m, n) * epsilon * sigma_max). Works on A itself - no normal
+// singular values above the rank threshold (Eigen's SVDBase::threshold(): diagSize = min(m, n) times epsilon, times sigma_max; numpy's lstsq
+// default is max(m, n) - with 27-125 samples 3-12 x higher, which would cut a weakly observed yaw direction Eigen keeps). Works on A itself - no normal
 // equations - so nothing is lost to squaring the condition number (the yaw column is ~1e-5 of the others).
 static void lstsq10_svd(int m, const double* A, const double* b, double c[10]) {
   const int n = 10;
@@ -746,7 +750,7 @@ static void lstsq10_svd(int m, const double* A, const double* b, double c[10]) {
     sig[j] = sqrt(q);
     if (sig[j] > smax) smax = sig[j];
   }
-  const double thr = (double)(m > n ? m : n) * 2.220446049250313e-16 * smax;
+  const double thr = (double)(m < n ? m : n) * 2.220446049250313e-16 * smax;
   for (int k = 0; k < n; k++) c[k] = 0.0;
   for (int j = 0; j < n; j++) {
     if (!(sig[j] > thr)) continue;
@@ -1154,29 +1158,44 @@ void cfear_host_free(cfear_ctx* ctx, void* p) {
   (void)hipHostFree(p);
 }
 
-static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, size_t n_records) {
-  if (!o->rp_stream) {
-    CFEAR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->rp_stream, hipStreamNonBlocking));
-    ctx->aux_streams.push_back(o->rp_stream);
+// chunk: sweeps per chunk the slot buffers must hold; staging: the host route also needs the two polar staging buffers of that many
+// sweeps (the device route filters the frames where they lie and never touches them: for thousands of sequences they would be
+// gigabytes allocated for nothing)
+static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, bool staging, size_t n_records) {
+  if (!o->rp_ready) {  // events first, the stream last, the flag only when everything exists: a failure leaves nothing half-made behind
     for (hipEvent_t* e : {&o->rp_filt[0], &o->rp_filt[1], &o->rp_used[0], &o->rp_used[1], &o->rp_in})
-      CFEAR_HIP_CHECK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+      if (!*e) CFEAR_HIP_CHECK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!o->rp_stream) {
+      CFEAR_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->rp_stream, hipStreamNonBlocking));
+      ctx->aux_streams.push_back(o->rp_stream);
+    }
+    o->rp_ready = true;
   }
+  const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
   if (chunk > o->rp_chunk) {
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(o->rp_stream));
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 2; i++) {
-      if (o->rp_polar[i]) (void)hipFree(o->rp_polar[i]);
       if (o->rp_slots[i]) (void)hipFree(o->rp_slots[i]);
-      o->rp_polar[i] = nullptr; o->rp_slots[i] = nullptr;
+      o->rp_slots[i] = nullptr;
       o->rp_used_pending[i] = false;
     }
     o->rp_chunk = 0;
-    const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
-    for (int i = 0; i < 2; i++) {
-      if (hipMalloc(&o->rp_polar[i], sweep * chunk + 64) != hipSuccess || hipMalloc(&o->rp_slots[i], sizeof(uint32_t) * slots * chunk) != hipSuccess)
-        return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay staging");
-    }
+    for (int i = 0; i < 2; i++)
+      if (hipMalloc(&o->rp_slots[i], sizeof(uint32_t) * slots * chunk) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay slot buffers");
     o->rp_chunk = chunk;
+  }
+  if (staging && chunk > o->rp_polar_chunk) {
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(o->rp_stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2; i++) {
+      if (o->rp_polar[i]) (void)hipFree(o->rp_polar[i]);
+      o->rp_polar[i] = nullptr;
+    }
+    o->rp_polar_chunk = 0;
+    for (int i = 0; i < 2; i++)
+      if (hipMalloc(&o->rp_polar[i], sweep * chunk + 64) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay staging");
+    o->rp_polar_chunk = chunk;
   }
   if (n_records > o->records_cap) {
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1190,16 +1209,20 @@ static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, size_t n_
 
 // frames: n_sweeps x B x A x R bytes on the host (copied chunk by chunk into the staging buffers) or on the device (filtered where
 // they lie); d_records: where the per-sweep records go on the device (null: none)
-static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, bool on_device, int n_sweeps, cfear_sweep_record* d_records) {
+static int replay_impl_queue(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, bool on_device, int n_sweeps, cfear_sweep_record* d_records) {
   const size_t sweep = (size_t)o->B * ctx->A * ctx->R, slots = (size_t)o->B * o->cap_points;
   // chunk: enough sweeps for the filter to run at its streaming rate (>= ~16 k azimuth rows per launch) and for the copy of the
-  // next chunk to hide behind the odometry kernels of this one, at most 256 MB of staging per buffer
-  int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)64, ((size_t)256 << 20) / sweep));
+  // next chunk to hide behind the odometry kernels of this one, at most 256 MB per buffer (host route: of staged sweeps; device
+  // route: of filter slots - there is no staging)
+  const size_t per_sweep = on_device ? sizeof(uint32_t) * slots : sweep;
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)64, ((size_t)256 << 20) / per_sweep));
   chunk = std::min(chunk, n_sweeps);
-  chunk = std::max(chunk, o->rp_chunk > n_sweeps ? 1 : std::min(o->rp_chunk, n_sweeps));  // (buffers of an earlier call are at least as good)
-  int rc = replay_ensure(ctx, o, chunk, 0);
+  {  // buffers of an earlier call may hold more sweeps per chunk: at least as good
+    const int have = on_device ? o->rp_chunk : std::min(o->rp_chunk, o->rp_polar_chunk);
+    chunk = std::max(chunk, std::min(have, n_sweeps));
+  }
+  int rc = replay_ensure(ctx, o, chunk, !on_device, 0);
   if (rc != CFEAR_OK) return rc;
-  chunk = std::min(o->rp_chunk, n_sweeps);
   const int nchunks = (n_sweeps + chunk - 1) / chunk;
   OdoParams OP = odo_params(ctx, o);
   const bool persistent = o->B <= ctx->tune_replay_persistent_max && !OP.phase_times && !OP.wg_times;
@@ -1245,6 +1268,18 @@ static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames,
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
+static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, bool on_device, int n_sweeps, cfear_sweep_record* d_records) {
+  const int rc = replay_impl_queue(ctx, o, frames, on_device, n_sweeps, d_records);
+  if (rc != CFEAR_OK && o->rp_stream) {
+    // an error after work was queued: copies out of the caller's frames and kernels that read them may be in flight - nothing of
+    // this call is left running when it returns (the error text is kept)
+    const std::string keep = ctx->err;
+    (void)hipStreamSynchronize(o->rp_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->err = keep;
+  }
+  return rc;
+}
 
 static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, int n_sweeps) {
   if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
@@ -1257,7 +1292,7 @@ static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames
 int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* h_frames, int n_sweeps, cfear_sweep_record* records) {
   int rc = replay_check(ctx, o, h_frames, n_sweeps);
   if (rc != CFEAR_OK) return rc;
-  if (records && (rc = replay_ensure(ctx, o, 0, (size_t)n_sweeps * o->B)) != CFEAR_OK) return rc;
+  if (records && (rc = replay_ensure(ctx, o, 0, false, (size_t)n_sweeps * o->B)) != CFEAR_OK) return rc;
   rc = replay_impl(ctx, o, h_frames, false, n_sweeps, records ? o->d_records : nullptr);
   if (rc != CFEAR_OK) return rc;
   if (records) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(records, o->d_records, sizeof(cfear_sweep_record) * (size_t)n_sweeps * o->B, hipMemcpyDeviceToHost, ctx->stream));

@@ -17,6 +17,7 @@ namespace cfear_dev {
 
 struct RegParams {
   int cost, loss, weight_opt;
+  int recompute_repeats;  // 1: an outer iteration that would repeat the previous one exactly is run again anyway (ctl_lm_done; cfear_tune REPEAT_SHORTCUT = 0)
   double loss_limit, covar_scale, regularization, assoc_radius;
   int max_outer, min_itr, max_inner;
 };
@@ -1133,7 +1134,7 @@ __device__ __noinline__ int ctl_lm_done(LRegShared* sh) {
       sh->prev_par[0] = sh->xcur[0]; sh->prev_par[1] = sh->xcur[1]; sh->prev_par[2] = sh->xcur[2]; sh->prev_c = sh->cur_c; sh->prev_s = sh->cur_s;
       sh->itr = itr + 1;  // for-loop increment (:102)
       if (sh->itr <= P.max_outer && sh->success) {
-        if (!sh->moved && itr >= 2) continue;  // the next outer iteration is an exact repeat of this one (see above)
+        if (!sh->moved && itr >= 2 && !P.recompute_repeats) continue;  // the next outer iteration is an exact repeat of this one (see above)
         return CTL_BUILD;
       }
     }
@@ -1387,6 +1388,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
     sh->tsrc_last[0] = last_in0; sh->tsrc_last[1] = last_in1; sh->tsrc_last[2] = last_in2;
     sh->prev_score = 1.7976931348623157e308;
     sh->success = 1; sh->nres = 0; sh->M = 0; sh->ret = 0; sh->itr = 1; sh->nrec = 0;
+    sh->moved = 1;  // (set by every solve's first evaluation, ctl_after_it0_body; a conservative value until then)
     sh->ss.num_iterations = 0; sh->ss.termination = 0; sh->ss.final_cost = 0; sh->ss.last_relative_decrease = 0;
     ctl_publish_build(ls, true);
   }

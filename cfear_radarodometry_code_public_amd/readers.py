@@ -133,9 +133,11 @@ def oxford_png_rows(polar, timestamps=None, encoder=None, valid=None):
 _LZ4_MAGIC = 0x184D2204
 
 
-def lz4_block_decompress(src, max_out=None):
-    """one LZ4 block (sequences of literals + matches) -> bytes"""
-    out = bytearray()
+def lz4_block_decompress(src, max_out=None, history=b""):
+    """one LZ4 block (sequences of literals + matches) -> bytes. history: the (up to 64 KB of) output in front of this block that
+    its matches may reach into (frames with linked blocks)"""
+    out = bytearray(history)
+    base = len(out)
     i, n = 0, len(src)
     while i < n:
         tok = src[i]; i += 1
@@ -167,9 +169,9 @@ def lz4_block_decompress(src, max_out=None):
         else:  # overlapping match: the pattern of `off` bytes repeats
             pat = bytes(out[start:])
             out += (pat * (ml // off + 1))[:ml]
-        if max_out is not None and len(out) > max_out:
+        if max_out is not None and len(out) - base > max_out:
             raise ValueError("lz4: block larger than announced")
-    return bytes(out)
+    return bytes(out[base:])
 
 
 def lz4_frame_decompress(data):
@@ -190,8 +192,8 @@ def lz4_frame_decompress(data):
         if block_max is None:
             raise ValueError("lz4 frame: bad block size code")
         i += 8 * content_size + 4 * dict_id + 1  # + header checksum byte
-        if not (flg >> 5) & 1:
-            raise NotImplementedError("lz4 frame with linked blocks")  # roslz4 writes independent blocks
+        linked = not (flg >> 5) & 1  # (roslz4 writes independent blocks; the lz4 command line tool links them by default)
+        hist = b""
         while True:
             sz, = struct.unpack_from("<I", data, i); i += 4
             if sz == 0:
@@ -199,7 +201,9 @@ def lz4_frame_decompress(data):
             raw = sz >> 31
             sz &= 0x7FFFFFFF
             blk = data[i:i + sz]; i += sz + 4 * block_checksum
-            out.append(bytes(blk) if raw else lz4_block_decompress(blk, block_max))
+            out.append(bytes(blk) if raw else lz4_block_decompress(blk, block_max, hist))
+            if linked:
+                hist = (hist + out[-1])[-65536:]
         i += 4 * content_checksum
     return b"".join(out)
 

@@ -85,9 +85,12 @@ int cfear_synchronize(cfear_ctx* ctx);
  * workgroups that walk a whole chunk of sweeps in one launch; more sequences (or 0) take the two launches per sweep of the
  * batched step. FILTER_CUS = F (with ODOMETRY_OVERLAP >= 1): the filter stream is created with a compute-unit mask of F units spread
  * evenly over the chip and the odometry streams with the complement (hipExtStreamCreateWithCUMask), so that the HBM-bound filter
- * of sweep t + 1 and the latency-bound odometry kernels of sweep t run side by side without sharing a unit's registers and LDS. */
+ * of sweep t + 1 and the latency-bound odometry kernels of sweep t run side by side without sharing a unit's registers and LDS.
+ * REPEAT_SHORTCUT (default 1): an outer registration iteration (n_scan_normal.cpp:102-151) that starts from the pose, radius and
+ * keyframes of the previous one - a solve that accepted no step - repeats it bit for bit, so its summary is taken from the
+ * previous one instead of associating and solving again; 0 runs it again (the tests compare the two). */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
-       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5 };
+       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

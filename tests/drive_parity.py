@@ -30,7 +30,7 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
         ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
     odo = ctx.odometry(1)
     buf = ctx.pinned((piece, 1, A, R))
-    mism, dev_poses, cpu_poses, cells = [], [], [], []
+    mism, dev_poses, cpu_poses, cells, nkfs = [], [], [], [], []
     t_dev = t_cpu = 0.0
     fill, base = 0, 0
     t_start = time.time()
@@ -58,7 +58,7 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
             g = r["pose"]
             if not (np.all(np.abs(g[:2] - e[:2]) < 1e-4) and abs(g[2] - e[2]) < 1e-5):
                 mism.append((t, "pose", [float(v) for v in g], [float(v) for v in e]))
-            dev_poses.append(np.array(g)); cpu_poses.append(np.array(e)); cells.append(exp[4])
+            dev_poses.append(np.array(g)); cpu_poses.append(np.array(e)); cells.append(exp[4]); nkfs.append(exp[3])
         t_cpu += time.time() - t0
         base += fill
         fill = 0
@@ -78,6 +78,6 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
     dev_poses, cpu_poses = np.array(dev_poses), np.array(cpu_poses)
     gtk = kitti.poses_from_xyt(gt)
     out = dict(mismatches=mism, poses_dev=dev_poses, poses_cpu=cpu_poses, gt=gt, cells=np.array(cells), motions=motions,
-               seconds_device=t_dev, seconds_oracle=t_cpu,
+               seconds_device=t_dev, seconds_oracle=t_cpu, keyframes_max=int(max(nkfs)) if nkfs else 0,
                drift_dev=kitti.drift(gtk, kitti.poses_from_xyt(dev_poses)), drift_cpu=kitti.drift(gtk, kitti.poses_from_xyt(cpu_poses)))
     return out

@@ -37,13 +37,16 @@ def test_drive_replay_matches_oracle_at_every_sweep(oracle, kind, sweeps, min_ce
 
 
 @pytest.mark.parametrize("name,kind,sweeps,params", [
-    ("config2_p2d", "blocks", 1500, dict(cost=2, regularization=1.0, covar_scale=1.0)),                       # BASELINE configs[2]
+    # BASELINE configs[2] = SURVEY 8(d) Config 3: the P2D cost with the values of params/baseline_p2d/oxford_cfear-2:22-23
+    ("config2_p2d", "blocks", 1500, dict(cost=2, regularization=0.1, covar_scale=1.0)),
+    # the same cost with the struct default regularization = 1 (odometrykeyframefuser.h:102; params/submap_keyframes uses it too)
+    ("p2d_reg1", "blocks", 600, dict(cost=2, regularization=1.0, covar_scale=1.0)),
     ("cfear3_k40_p2p", "blocks", 1000, dict(k_strongest=40, cost=0, submap_scan_size=4, res=3.0)),            # oxford_cfear-3:13-25 (general cloud / feature paths)
     ("cfear2_p2l", "canyon", 800, dict(cost=1, submap_scan_size=3, res=3.5, weight_intensity=0)),             # oxford_cfear-2
     ("cauchy_ccw", "field", 800, dict(loss=2, loss_limit=0.2, radar_ccw=1)),
     # the dense canyon with the two-residual costs: more residual blocks than the LDS match array holds (622 for P2D), so the
     # array's capacity stays in LDS and the rest is evaluated from memory
-    ("p2d_canyon", "canyon", 400, dict(cost=2, regularization=1.0, covar_scale=1.0)),
+    ("p2d_canyon", "canyon", 400, dict(cost=2, regularization=0.1, covar_scale=1.0)),
     ("p2p_canyon", "canyon", 400, dict(cost=0)),
 ])
 def test_drive_replay_of_the_other_presets(oracle, name, kind, sweeps, params):

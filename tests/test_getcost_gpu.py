@@ -71,7 +71,7 @@ def test_cov_by_sampling_matches_oracle(oracle, steps, xy, yaw, cost):
     # squares is a one-sided Jacobi SVD, the oracle's an eigen-decomposition of the normal matrix: neither is numpy's)
     xs, ths = np.linspace(-xy / 2, xy / 2, steps), np.linspace(-yaw / 2, yaw / 2, steps)
     rows = [[x * x, y * y, z * z, x * y, y * z, z * x, x, y, z, 1.0] for z in ths for x in xs for y in xs]
-    c = np.linalg.lstsq(np.array(rows), costs_g, rcond=None)[0]
+    c = np.linalg.lstsq(np.array(rows), costs_g, rcond=10 * np.finfo(float).eps)[0]  # Eigen's rank threshold: min(rows, cols) * eps (SVDBase::threshold)
     H = np.array([[2 * c[0], c[3], c[5]], [c[3], 2 * c[1], c[4]], [c[5], c[4], 2 * c[2]]])
     convex = bool(np.all(np.linalg.eigvalsh(H) > 0))
     assert ok_g == (convex and S.num_residuals - 3 != 0)
@@ -80,6 +80,43 @@ def test_cov_by_sampling_matches_oracle(oracle, steps, xy, yaw, cost):
         exp = np.eye(6)
         exp[:2, :2] = C3[:2, :2]; exp[5, 5] = C3[2, 2]; exp[0, 5] = C3[0, 2]; exp[1, 5] = C3[1, 2]; exp[5, 0] = C3[2, 0]; exp[5, 1] = C3[2, 1]
         assert np.allclose(cov_g, exp, rtol=1e-6, atol=1e-14)
+    ctx.close()
+
+
+def test_cov_by_sampling_keeps_a_weak_yaw_direction_like_eigen(oracle):
+    """Nearly rank-deficient sample design: the yaw range is so small that the yaw^2 column's singular value sits between Eigen's
+    rank threshold (min(rows, cols) * eps * sigma_max = 10 eps, SVDBase::threshold(), what bdcSvd().solve() at
+    odometrykeyframefuser.cpp:337 uses) and numpy's default (max(rows, cols) * eps = 125 eps with 5 samples per axis). Eigen keeps
+    the direction - the fitted Hessian then has the cost's real curvature in yaw and is convex -, the higher threshold would cut it
+    (H[2][2] = 0: 'not convex', no covariance)."""
+    po, ctx, so, sg, gt = build(oracle, 4, cost=1, loss=1, weight_opt=4, loss_limit=0.1)
+    ret, P, cov_reg, S = oracle.register(so, gt[:4].copy(), po)
+    steps, xy, eps = 5, 0.4, np.finfo(float).eps
+    xs = np.linspace(-xy / 2, xy / 2, steps)
+
+    def design(yaw):
+        ths = np.linspace(-yaw / 2, yaw / 2, steps)
+        return np.array([[x * x, y * y, z * z, x * y, y * z, z * x, x, y, z, 1.0] for z in ths for x in xs for y in xs])
+    yaw = 1e-6
+    for _ in range(60):  # geometric bisection on the range: smallest singular value at ~35 eps of the largest
+        sv = np.linalg.svd(design(yaw), compute_uv=False)
+        ratio = sv[-1] / sv[0]
+        if 30 * eps < ratio < 42 * eps:
+            break
+        yaw *= np.sqrt(35 * eps / ratio)  # sigma_min ~ yaw^2
+    assert 10 * eps * 2 < ratio < 125 * eps / 2
+    ok_g, cov_g, costs_g = ctx.cov_by_sampling(sg, P, S.final_cost, S.num_residuals, itr=S.outer_iterations, xy_range=xy, yaw_range=yaw, steps=steps)
+    Am = design(yaw)
+
+    def fit(rcond):
+        c = np.linalg.lstsq(Am, costs_g, rcond=rcond)[0]
+        return np.array([[2 * c[0], c[3], c[5]], [c[3], 2 * c[1], c[4]], [c[5], c[4], 2 * c[2]]])
+    H_eigen, H_numpy_default = fit(10 * eps), fit(None)
+    assert H_numpy_default[2, 2] < 1e-3 * abs(H_eigen[2, 2])  # the direction is gone under the higher threshold
+    convex = bool(np.all(np.linalg.eigvalsh(H_eigen) > 0))
+    assert convex and ok_g  # the registration cost is convex in yaw around its minimum
+    C3 = 2.0 * np.linalg.inv(H_eigen) * (S.final_cost / (S.num_residuals - 3)) * 4.0
+    assert np.allclose(cov_g[:2, :2], C3[:2, :2], rtol=1e-3) and np.isclose(cov_g[5, 5], C3[2, 2], rtol=0.3)  # (a singular value at 35 eps is known to ~10 %)
     ctx.close()
 
 

@@ -1,0 +1,147 @@
+"""The reference's large-submap presets through the device fuser (odometrykeyframefuser.cpp:470-494: a ring of up to
+submap_scan_size keyframes; n_scan_normal.cpp:359-367: one scan pair per keyframe), against the oracle's fuser at EVERY sweep -
+keyframe / outer / inner iteration / residual / cell counts and the pose (1e-4 m, 1e-5 rad):
+
+  * params/baseline_p2d/oxford_cfear-3-s10 and -p2d-s10: 10 keyframes, k = 40, Cauchy(0.1), P2P resp. P2D (regularization 0.1);
+  * params/submap_keyframes/submap_keyframe_cfear-3:15 sweeps submap_scan_size over 1..10 (k = 12, Huber, unweighted): 8 is the
+    first value past the batched registration kernels compiled for <= 8 scans (CFEAR_STEP_SMALL_SCANS), 5 the first past the
+    four-keyframes-at-once association;
+  * launch/oxford_demo:62-71, CFEAR-3-s50: 50 keyframes, Cauchy, k = 40, P2P - the reference's most accurate published setting.
+
+With submap_scan_size > 7 the batched step launches register_step_kernel<false, -1> of pipeline.hip (64-scan shared state, cost
+read at run time); the replay route runs replay_chunk_kernel. Both routes are driven here, on the street canyon (several echoes
+per azimuth, >= 500 oriented surface points per sweep at k = 12) long enough for the 50-slot ring to fill and turn over."""
+import os
+
+import numpy as np
+import pytest
+
+import drive_parity
+from cfear_radarodometry_code_public_amd import capi, kitti, synth
+
+pytestmark = pytest.mark.gpu
+
+S10_P2P = dict(k_strongest=40, cost=0, loss=2, loss_limit=0.1, submap_scan_size=10, res=3.0, weight_intensity=1, weight_opt=4, regularization=0.1, covar_scale=1.0)
+S10_P2D = dict(S10_P2P, cost=2)
+S50 = dict(k_strongest=40, cost=0, loss=2, loss_limit=0.1, submap_scan_size=50, res=3.0, weight_intensity=1, weight_opt=4)
+SWEEP = dict(k_strongest=12, loss=1, loss_limit=0.1, res=3.0, weight_intensity=0, weight_opt=0, regularization=1.0, covar_scale=1.0)
+
+
+@pytest.mark.parametrize("name,kind,sweeps,params", [
+    ("s10_p2p", "canyon", 300, S10_P2P),
+    ("s10_p2d", "canyon", 300, S10_P2D),
+    ("s8_p2l", "blocks", 400, dict(SWEEP, cost=1, submap_scan_size=8)),
+    ("s5_p2d", "blocks", 300, dict(SWEEP, cost=2, submap_scan_size=5)),
+    ("s50_cfear3", "canyon", 600, S50),
+])
+def test_large_submap_replay_matches_oracle_at_every_sweep(oracle, name, kind, sweeps, params):
+    """replay route (cfear_odometry_replay_host, one persistent workgroup per sequence)"""
+    T = int(os.environ.get("CFEAR_LARGE_SUBMAP_SWEEPS", str(sweeps)))
+    out = drive_parity.run(oracle, T, kind, world_seed=4, seed=7, params=params)
+    m = out["mismatches"]
+    assert not m, "%s: %d sweeps disagree; first (sweep, what, device, oracle): %r" % (name, len(m), m[:3])
+    d, c = out["drift_dev"], out["drift_cpu"]
+    assert d["segments"] == c["segments"]
+    if d["segments"]:
+        assert abs(d["translation_percent"] - c["translation_percent"]) < 1e-6
+    s = params["submap_scan_size"]
+    if T >= 4 * s:  # the ring filled (and turned over)
+        assert out["keyframes_max"] == s
+
+
+def _batched_parity(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.0595238), persistent_max=0, route="step"):
+    """B sequences (different drives) through the batched route - cfear_odometry_step_host, or cfear_odometry_replay_host with the
+    persistent workgroups switched off (two launches per sweep) - against B oracle fusers, every sweep"""
+    kw = dict(drive_parity.BASE, range_res=rr)
+    kw.update(params)
+    fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
+    ctx = capi.Context(capi.default_params(**kw), A, R)
+    ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
+    odo = ctx.odometry(B)
+    gens = [synth.drive_chunks(T, kind, 10 + q, 20 + q, A, R, rr, ccw=False) for q in range(B)]
+    frames = np.empty((T, B, A, R), dtype=np.uint8)
+    for q, g in enumerate(gens):
+        for t0, chunk in g:
+            frames[t0:t0 + len(chunk), q] = chunk
+    recs = None
+    if route == "replay":
+        recs = odo.replay_host(frames)
+    kmax = 0
+    for t in range(T):
+        if route == "step":
+            odo.step_host(frames[t])
+            got = odo.poses()
+        for q in range(B):
+            exp = fus[q].process_polar(frames[t, q])
+            So = fus[q].last_summary()
+            no = max(int(So.outer_iterations), 0)
+            e = (int(So.outer_iterations), [int(v) for v in So.inner_iterations[:min(no, 8)]], int(So.num_residuals), int(fus[q].num_keyframes), len(fus[q].last_cells()))
+            if route == "step":
+                S, nc, nk = odo.summary(q)
+                g = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(max(int(S.outer_iterations), 0), 8)]], int(S.num_residuals), nk, nc)
+                pose = got[q]
+            else:
+                r = recs[t, q]
+                g = (int(r["outer_iterations"]), [int(v) for v in r["inner_iterations"][:min(max(int(r["outer_iterations"]), 0), 8)]], int(r["num_residuals"]),
+                     int(r["n_keyframes"]), int(r["n_cells"]))
+                pose = r["pose"]
+            if t > 0:
+                assert g == e, (t, q, g, e)
+            assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
+            kmax = max(kmax, e[3])
+    odo.release()
+    ctx.close()
+    return kmax
+
+
+@pytest.mark.parametrize("name,kind,sweeps,params,route", [
+    ("s10_p2p", "canyon", 60, S10_P2P, "step"),
+    ("s10_p2d", "canyon", 60, S10_P2D, "replay"),
+    ("s8_p2l", "blocks", 80, dict(SWEEP, cost=1, submap_scan_size=8), "step"),
+    ("s8_p2p", "blocks", 60, dict(SWEEP, cost=0, submap_scan_size=8), "replay"),
+    ("s7_p2l", "blocks", 60, dict(SWEEP, cost=1, submap_scan_size=7), "step"),   # the last size of the production instantiations
+    ("s50_cfear3", "canyon", 140, S50, "step"),
+])
+def test_large_submap_batched_route_matches_oracle(oracle, name, kind, sweeps, params, route):
+    """batched route: features_step_kernel + register_step_kernel per sweep, three sequences side by side"""
+    kmax = _batched_parity(oracle, params, kind, sweeps, route=route)
+    assert kmax == min(params["submap_scan_size"], kmax)  # (the ring never exceeds submap_scan_size)
+    if sweeps >= 3 * params["submap_scan_size"]:
+        assert kmax == params["submap_scan_size"]
+
+
+def test_repeat_shortcut_off_gives_identical_results():
+    """An outer iteration that would repeat the previous one bit for bit is not recomputed (ctl_lm_done); with the shortcut
+    switched off (cfear_tune REPEAT_SHORTCUT = 0) the iteration runs again - and every summary field, pose and covariance of a
+    drive must be identical: the shortcut is an optimisation, not a change of the algorithm."""
+    A, R, rr = 400, 3360, np.float32(0.0595238)
+    T, B = 60, 2
+    frames = np.empty((T, B, A, R), dtype=np.uint8)
+    for q in range(B):
+        for t0, chunk in synth.drive_chunks(T, "blocks", 31 + q, 41 + q, A, R, rr, ccw=False):
+            frames[t0:t0 + len(chunk), q] = chunk
+    results = {}
+    for cost in (1, 2):
+        for shortcut in (1, 0):
+            kw = dict(drive_parity.BASE, range_res=rr, cost=cost)
+            ctx = capi.Context(capi.default_params(**kw), A, R)
+            ctx.tune(capi.TUNE_REPEAT_SHORTCUT, shortcut)
+            odo = ctx.odometry(B)
+            poses, summ = [], []
+            for t in range(T):
+                odo.step_host(frames[t])
+                poses.append(odo.poses())
+                for q in range(B):
+                    S = odo.summary(q)[0]
+                    summ.append((S.success, S.usable, S.outer_iterations, S.num_residuals, S.num_residual_blocks, S.final_cost, S.score,
+                                 list(S.inner_iterations[:8]), list(S.termination[:8]), list(S.outer_cost[:8]), [list(p) for p in S.outer_pose[:8]]))
+            cov = odo.covariances()
+            results[(cost, shortcut)] = (np.array(poses), summ, cov)
+            odo.release()
+            ctx.close()
+        a, b = results[(cost, 1)], results[(cost, 0)]
+        assert np.array_equal(a[0], b[0])
+        assert a[1] == b[1]
+        assert np.array_equal(a[2], b[2])
+        # the shortcut was really taken somewhere: registrations that end with repeated single-evaluation solves
+        assert any(s[7][:s[2] - 1][-2:] == [1, 1] for s in a[1] if s[2] >= 5)

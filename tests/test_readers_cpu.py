@@ -124,3 +124,84 @@ def test_lz4_frame_known_answers_and_roundtrip():
                  synth.world_scan(synth.World(3), 2, 40, 512).tobytes()):
         assert readers.lz4_frame_decompress(readers.lz4_frame_compress(data, block_size=1 << 16)) == data
     assert len(readers.lz4_frame_compress(b"ab" * 40000)) < 2000
+
+
+@pytest.mark.parametrize("compress_level,optimize", [(0, False), (1, False), (6, False), (9, True)])
+def test_png_written_by_pillow_oxford_layout(tmp_path, compress_level, optimize):
+    """An encoder that is not ours: Pillow (libpng-style adaptive per-row filters - all five types occur -, several IDAT chunks,
+    different zlib levels incl. stored blocks) writes the 400 x 3779 Oxford radar layout (README:133; 11 metadata columns in front
+    of the 3768 range bins); read_png_gray8 / read_oxford_png must give back exactly what PIL.Image.open decodes."""
+    PIL = pytest.importorskip("PIL.Image")
+    polar = synth.world_scan(synth.World(5), 1, 400, 3768, np.float32(0.0438), seed=2)
+    ts = 1547131046353776 + np.arange(400) * 625
+    rows = readers.oxford_png_rows(polar, ts, (np.arange(400) * 14) % 5600)
+    f = tmp_path / "pil.png"
+    PIL.fromarray(rows, mode="L").save(f, format="PNG", compress_level=compress_level, optimize=optimize)
+    ref = np.array(PIL.open(f))
+    assert ref.shape == (400, 3779) and np.array_equal(ref, rows)
+    got = readers.read_png_gray8(f)
+    assert np.array_equal(got, ref)
+    ox = readers.read_oxford_png(f)
+    assert np.array_equal(ox["polar"], polar) and np.array_equal(ox["timestamps"], ts)
+    # which row filters and how many IDAT chunks the file really has (the test means something only if they vary)
+    data = f.read_bytes()
+    idat = [body for t, body in readers._png_chunks(data) if t == b"IDAT"]
+    raw = zlib.decompress(b"".join(idat))
+    filters = {raw[y * 3780] for y in range(400)}
+    assert filters <= {0, 1, 2, 3, 4}
+    if compress_level in (6, 9):
+        assert len(filters) >= 2  # adaptive filtering chose more than one type on a radar image
+
+
+def test_png_smooth_image_by_pillow_uses_every_filter_type(tmp_path):
+    """a smooth gradient + noise image makes libpng-style heuristics pick Sub / Up / Average / Paeth rows; ours decodes them all"""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    y, x = np.mgrid[0:300, 0:500]
+    img = ((np.sin(x / 17.0) * 60 + np.cos(y / 9.0) * 50 + 128) + rng.normal(0, 1.5, (300, 500))).clip(0, 255).astype(np.uint8)
+    img[::7] = rng.integers(0, 256, (len(img[::7]), 500), dtype=np.uint8)  # noisy rows: filter None
+    f = tmp_path / "g.png"
+    PIL.fromarray(img, mode="L").save(f, format="PNG", compress_level=6)
+    raw = zlib.decompress(b"".join(body for t, body in readers._png_chunks(f.read_bytes()) if t == b"IDAT"))
+    assert len({raw[r * 501] for r in range(300)}) >= 4
+    assert np.array_equal(readers.read_png_gray8(f), np.array(PIL.open(f)))
+
+
+def test_png_rejects_what_the_oxford_sdk_never_writes(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    f = tmp_path / "rgb.png"
+    PIL.fromarray(np.zeros((4, 4, 3), dtype=np.uint8), mode="RGB").save(f)
+    with pytest.raises(ValueError):
+        readers.read_png_gray8(f)
+    f16 = tmp_path / "g16.png"
+    PIL.fromarray(np.zeros((4, 4), dtype=np.uint16)).save(f16)
+    with pytest.raises(ValueError):
+        readers.read_png_gray8(f16)
+
+
+def test_lz4_frame_published_format_vectors():
+    """Frames reconstructed by hand from the LZ4 frame format description (v1.6.x): an empty frame (header + end mark only), with
+    and without a content checksum (xxh32 of nothing = 0x02CC5D05), an uncompressed-block frame, a frame with block-independence
+    off and 64 KB maximum block size; `xxhash` (in the image) checks the header checksum byte our decoder skips over."""
+    xxhash = pytest.importorskip("xxhash")
+
+    def header(flg, bd, extra=b""):
+        desc = bytes([flg, bd]) + extra
+        return struct.pack("<I", 0x184D2204) + desc + bytes([(xxhash.xxh32(desc, seed=0).intdigest() >> 8) & 0xFF])
+    end = struct.pack("<I", 0)
+    assert readers.lz4_frame_decompress(header(0x60, 0x40) + end) == b""                                        # version 01, independent blocks
+    assert readers.lz4_frame_decompress(header(0x64, 0x40) + end + struct.pack("<I", 0x02CC5D05)) == b""        # + content checksum
+    assert header(0x64, 0x40)[-1] == 0xA7  # the byte the specification's own example of this descriptor carries
+    payload = bytes(range(200)) * 3
+    f = header(0x40, 0x40) + struct.pack("<I", len(payload) | 0x80000000) + payload + end                        # linked blocks flag, stored block
+    assert readers.lz4_frame_decompress(f) == payload
+    f = header(0x68, 0x40, struct.pack("<Q", len(payload))) + struct.pack("<I", len(payload) | 0x80000000) + payload + end  # content size field
+    assert readers.lz4_frame_decompress(f) == payload
+    assert readers.lz4_frame_decompress(b"") == b""
+    # linked blocks: the second block's only match reaches 8 bytes back into the first block's output
+    b1 = bytes([0x80]) + b"ABCDEFGH"                               # 8 literals, end of block
+    b2 = bytes([0x04, 0x08, 0x00, 0x50]) + b"vwxyz"                # no literals, match offset 8 length 8, then 5 literals
+    f = header(0x40, 0x40) + struct.pack("<I", len(b1)) + b1 + struct.pack("<I", len(b2)) + b2 + end
+    assert readers.lz4_frame_decompress(f) == b"ABCDEFGH" + b"ABCDEFGH" + b"vwxyz"
+    with pytest.raises(ValueError):  # the same blocks declared independent: the match has nothing to refer to
+        readers.lz4_frame_decompress(header(0x60, 0x40) + struct.pack("<I", len(b1)) + b1 + struct.pack("<I", len(b2)) + b2 + end)

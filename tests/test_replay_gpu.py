@@ -72,6 +72,32 @@ def test_bench_two_ranks_through_the_launcher_on_one_gpu():
     assert r["state"]["replicas_bit_identical"] is True
 
 
+def test_bench_eight_ranks_through_the_launcher_on_one_gpu():
+    """BASELINE configs[3]'s shape - eight ranks, one sequence shard each - with real device work: `python bench.py --gpus 8` starts
+    the eight ranks itself; --share-gpu puts them all on cuda:0 and the reduction on gloo. The day an 8-GPU node runs it the only
+    new variables are the device index and the RCCL backend. The line must carry the per-rank rates and roofline fractions."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "4", "--warmup", "2", "--sequences", "256",
+                          "--unique", "8", "--repeats", "2", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["sequences_per_gpu"] == 256 and r["config"]["sweeps_per_step"] == 8 * 256 and "INVALID" in r
+    assert r["scaling"] == "weak" and r["steps"] == 4
+    assert len(r["per_rank_scans_per_s"]) == 8 and all(v > 0 for v in r["per_rank_scans_per_s"])
+    assert len(r["per_rank_filter_frac_of_hbm_peak"]) == 8 and all(0 < v < 1 for v in r["per_rank_filter_frac_of_hbm_peak"])
+    # value = the units all ranks processed / the slowest rank's time
+    assert abs(r["value"] - 8 * 256 * 4 / (r["ms_per_step"] * 4 / 1e3)) < 1e-6 * r["value"]
+    assert r["value"] <= sum(r["per_rank_scans_per_s"]) * (1 + 1e-9)
+    assert r["state"]["replicas_bit_identical"] is True and r["config"]["keyframes_at_first_timed_step_min"] == 4
+
+
 @pytest.mark.parametrize("B,persistent_max", [(1, 256), (1, 0), (3, 256), (3, 0)])
 def test_replay_host_equals_step_host(B, persistent_max):
     """cfear_odometry_replay_host (chunks copied and filtered ahead on a second stream; a persistent workgroup per sequence or the
