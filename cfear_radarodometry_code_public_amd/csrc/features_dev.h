@@ -904,7 +904,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       base += round_total;
     }
     n_cells_out = base < cap_cells ? base : cap_cells;
-    if (tid == 0) S->n_cells = n_cells_out;
+    if (tid == 0) { S->n_cells = n_cells_out; if (base > cap_cells) S->status = CFEAR_ERR_CAPACITY; }  // more cells than the scan block holds (cfear_tune MAX_CELLS): the first cap_cells are kept
     __syncthreads();
   }
   if (pt) pt->mark();

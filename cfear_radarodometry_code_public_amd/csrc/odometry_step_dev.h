@@ -66,6 +66,7 @@ struct OdoParams {
   // computed, not fetched from the pointer table (a memory round trip at the start of both kernels)
   unsigned char* scans_base; size_t scan_stride;
   cfear_sweep_record* records;  // optional [B]: this sweep's record of every sequence (cfear_odometry_replay_host)
+  int* flags;  // one word per odometry object: bit 0 = some scan had more cells than its block holds (CFEAR_ERR_CAPACITY); null: cannot happen
 };
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -137,6 +138,7 @@ __device__ __forceinline__ void features_step_body(unsigned char* lds /* FeatLds
   if (TIMED) { pt.mark(); pt.mark(); }
   CFEAR_STOP_AT(1, );
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR, true);  // :161
+  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) atomicOr(OP.flags, 1);  // (thread 0 wrote the status itself)
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 

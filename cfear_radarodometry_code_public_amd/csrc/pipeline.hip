@@ -153,26 +153,28 @@ RegParams reg_params(const cfear_ctx* ctx) {
 constexpr int GRID_CAP = CFEAR_GRID_CAP;
 
 struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, total; };
-ScanLayout scan_layout(int cap_points) {
+// cap_cells <= cap_points: cells a scan can hold (every cell is the centroid neighbourhood of an occupied voxel, so never more than
+// points; the batched odometry may be sized for fewer: cfear_tune MAX_CELLS)
+ScanLayout scan_layout(int cap_points, int cap_cells) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
-  L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_points, 256);
-  L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_points, 256);
+  L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_cells, 256);
+  L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_cells, 256);
   L.gstart = o; o = align_up(o + (sizeof(int) + sizeof(uint2)) * (GRID_CAP + 4), 256);  // 32-bit offsets + the region of the 16-bit ones (grid_off16)
-  L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_points, 256);
-  L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_points, 256);
-  L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_points, 256);
+  L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_cells, 256);
+  L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_cells, 256);
+  L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_cells, 256);
   L.total = o;
   return L;
 }
 // writes a ScanDev header for a flat device block at d_base
-ScanDev scan_header(unsigned char* d_base, int cap_points) {
-  const ScanLayout L = scan_layout(cap_points);
+ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells) {
+  const ScanLayout L = scan_layout(cap_points, cap_cells);
   ScanDev h;
   memset(&h, 0, sizeof(h));
   h.status = CFEAR_ERR_EMPTY;
-  h.cap_points = cap_points; h.cap_cells = cap_points; h.cap_grid = GRID_CAP;
+  h.cap_points = cap_points; h.cap_cells = cap_cells; h.cap_grid = GRID_CAP;
   h.xyi = reinterpret_cast<float*>(d_base + L.xyi);
   h.cells = reinterpret_cast<cfear_cell*>(d_base + L.cells);
   h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
@@ -235,7 +237,8 @@ struct cfear_scan {
   int cap_points = 0;
 };
 struct cfear_odometry {
-  int B = 0, nslots = 0, cap_points = 0, pair_cap = 0;
+  int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
+  int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells (only allocated when cap_cells < cap_points)
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
   ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
   size_t scan_stride = 0;              // bytes between consecutive scan slots of d_scans
@@ -305,6 +308,7 @@ static int odo_timed_event(cfear_ctx* ctx, cfear_odometry* o, std::vector<hipEve
   CFEAR_HIP_CHECK(ctx, hipEventRecord(e, st));
   return CFEAR_OK;
 }
+static int odo_capacity_check(cfear_ctx* ctx, cfear_odometry* o, const char* what);
 // make everything the internal streams have been given so far visible to the context stream
 static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
   if (o->overlap && o->step_no > 0) {
@@ -338,6 +342,7 @@ static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
   OP.seq0 = 0;
   OP.scans_base = o->d_scans; OP.scan_stride = o->scan_stride;
   OP.records = nullptr;
+  OP.flags = o->d_flags;
   return OP;
 }
 // features -> registration of one sweep of every sequence on `st`, from the filter's slots
@@ -494,9 +499,9 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = cap;
-  const ScanLayout L = scan_layout(cap);
+  const ScanLayout L = scan_layout(cap, cap);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
-  const ScanDev h = scan_header(s->d_block, cap);
+  const ScanDev h = scan_header(s->d_block, cap, cap);
   ScanDev back;
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);  // h lives until the synchronize below
   if (e == hipSuccess) {
@@ -536,9 +541,9 @@ int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = n;
-  const ScanLayout L = scan_layout(n);
+  const ScanLayout L = scan_layout(n, n);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
-  const ScanDev h = scan_header(s->d_block, n);
+  const ScanDev h = scan_header(s->d_block, n, n);
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(s->d_block + L.cells, cells, sizeof(cfear_cell) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
@@ -875,7 +880,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times,
-                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records};
+                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records, o->d_flags};
   for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1], o->rp_in}) if (e) (void)hipEventDestroy(e);
   if (o->rp_stream) (void)hipStreamDestroy(o->rp_stream);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -900,6 +905,7 @@ int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_summaries, 0, sizeof(cfear_reg_summary) * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_poses_out, 0, sizeof(double) * 3 * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_cov_work, 0, sizeof(double) * 36 * (size_t)o->B, ctx->stream));
+  if (o->d_flags) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int), ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }
@@ -913,9 +919,26 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   cfear_odometry* o = new (std::nothrow) cfear_odometry();
   if (!o) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "odometry alloc");
   const int B = n_sequences, s = ctx->par.submap_scan_size;
-  o->B = B; o->nslots = s + 1; o->cap_points = ctx->A * ctx->par.k_strongest; o->pair_cap = s * o->cap_points;
-  const ScanLayout SL = scan_layout(o->cap_points);
+  o->B = B; o->nslots = s + 1; o->cap_points = ctx->A * ctx->par.k_strongest;
+  o->cap_cells = ctx->tune_max_cells > 0 ? std::min(ctx->tune_max_cells, o->cap_points) : o->cap_points;
+  // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,
+  // n_scan_normal.cpp:242,258); the association parks four results per source cell in the same scratch
+  o->pair_cap = std::max(s, 4) * o->cap_cells;
+  const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells);
   const ScratchLayout WL = scratch_layout(o->cap_points, o->pair_cap);
+  {  // refuse what cannot fit with a message that names the numbers (a bare NOMEM after gigabytes of partial allocations helps nobody)
+    size_t free_b = 0, total_b = 0;
+    const size_t per_seq = SL.total * (size_t)o->nslots + WL.total + sizeof(uint32_t) * 2 * (size_t)o->cap_points + sizeof(SeqState) + 4096;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_seq * (size_t)B > free_b) {
+      char msg[512];
+      snprintf(msg, sizeof(msg), "odometry_create: %d sequences x %.1f MB (%d scan slots of %.2f MB for %d points / %d cells each + %.1f MB of scratch for %d residual "
+               "blocks) = %.1f GB, %.1f GB free: at most %zu sequences fit - or size the scans for fewer cells (cfear_tune CFEAR_TUNE_MAX_CELLS, now %d)",
+               B, per_seq / 1048576.0, o->nslots, SL.total / 1048576.0, o->cap_points, o->cap_cells, WL.total / 1048576.0, o->pair_cap,
+               per_seq * (double)B / 1073741824.0, free_b / 1073741824.0, free_b / per_seq, o->cap_cells);
+      delete o;
+      return cfear_fail(ctx, CFEAR_ERR_NOMEM, msg);
+    }
+  }
   bool ok = true;
   ok = ok && hipMalloc(&o->d_scans, SL.total * (size_t)B * o->nslots) == hipSuccess;
   ok = ok && hipMalloc(&o->d_scan_ptrs, sizeof(ScanDev*) * (size_t)B * o->nslots) == hipSuccess;
@@ -929,6 +952,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_poses_out, sizeof(double) * 3 * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+  if (ok && o->cap_cells < o->cap_points) ok = hipMalloc(&o->d_flags, sizeof(int)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int)) == hipSuccess;
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc odometry state"); }
   o->scan_stride = SL.total;
   std::vector<ScanDev*> ptrs((size_t)B * o->nslots);
@@ -937,7 +961,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   for (int q = 0; q < B; q++) {
     for (int j = 0; j < o->nslots; j++) {
       unsigned char* blk = o->d_scans + SL.total * ((size_t)q * o->nslots + j);
-      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points);
+      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points, o->cap_cells);
       ptrs[(size_t)q * o->nslots + j] = reinterpret_cast<ScanDev*>(blk);
     }
     hdrs[q] = scratch_header(o->d_scratch + WL.total * (size_t)q, o->cap_points, o->pair_cap);
@@ -1297,7 +1321,7 @@ int cfear_odometry_replay_host(cfear_ctx* ctx, cfear_odometry* o, const uint8_t*
   if (rc != CFEAR_OK) return rc;
   if (records) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(records, o->d_records, sizeof(cfear_sweep_record) * (size_t)n_sweeps * o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return CFEAR_OK;
+  return odo_capacity_check(ctx, o, "odometry_replay_host");
 }
 
 int cfear_odometry_replay_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_frames, int n_sweeps, cfear_sweep_record* d_records) {
@@ -1306,13 +1330,27 @@ int cfear_odometry_replay_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_
   return replay_impl(ctx, o, d_frames, true, n_sweeps, d_records);  // asynchronous: nothing is waited for
 }
 
+// after a synchronisation of the context stream: has any scan of this object overflowed its cell capacity (CFEAR_TUNE_MAX_CELLS)?
+static int odo_capacity_check(cfear_ctx* ctx, cfear_odometry* o, const char* what) {
+  if (!o->d_flags) return CFEAR_OK;  // sized for every filtered point: cannot happen
+  int f = 0;
+  CFEAR_HIP_CHECK(ctx, hipMemcpy(&f, o->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (f & 1) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "%s: a scan produced more than %d oriented surface points (cfear_tune CFEAR_TUNE_MAX_CELLS): its first %d were kept, "
+             "the results of that sequence are those of a truncated scan", what, o->cap_cells, o->cap_cells);
+    return cfear_fail(ctx, CFEAR_ERR_CAPACITY, msg);
+  }
+  return CFEAR_OK;
+}
+
 int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* o, double* poses_xyt) {
   if (!ctx || !o || !poses_xyt) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_poses: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, o->d_poses_out, sizeof(double) * 3 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return CFEAR_OK;
+  return odo_capacity_check(ctx, o, "odometry_poses");
 }
 
 int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* o, double* cov6) {
@@ -1321,7 +1359,7 @@ int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* o, double* cov6) 
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6, o->d_cov_work, sizeof(double) * 36 * (size_t)o->B, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return CFEAR_OK;
+  return odo_capacity_check(ctx, o, "odometry_covariances");
 }
 
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfear_reg_summary* summary, int* n_cells,
@@ -1336,13 +1374,13 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfea
     CFEAR_HIP_CHECK(ctx, hipMemcpy(&st, o->d_states + sequence, sizeof(st), hipMemcpyDeviceToHost));
     if (n_keyframes) *n_keyframes = st.nkf;
     if (n_cells) {  // cells of the scan built by the last step
-      const ScanLayout SL = scan_layout(o->cap_points);
+      const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells);
       ScanDev h;
       CFEAR_HIP_CHECK(ctx, hipMemcpy(&h, o->d_scans + SL.total * ((size_t)sequence * o->nslots + st.last_slot), sizeof(h), hipMemcpyDeviceToHost));
       *n_cells = h.n_cells;
     }
   }
-  return CFEAR_OK;
+  return odo_capacity_check(ctx, o, "odometry_summary");
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@ extern "C" {
 #define CFEAR_ERR_UNSUPPORTED (-3) /* size outside the compiled kernel range */
 #define CFEAR_ERR_EMPTY (-4)       /* empty cloud (reference: exit(0)) */
 #define CFEAR_ERR_NOMEM (-5)
+#define CFEAR_ERR_CAPACITY (-6)    /* a scan produced more oriented surface points than CFEAR_TUNE_MAX_CELLS allows */
 
 /* registration.h:48-60 */
 enum { CFEAR_COST_P2P = 0, CFEAR_COST_P2L = 1, CFEAR_COST_P2D = 2 };
@@ -88,9 +89,15 @@ int cfear_synchronize(cfear_ctx* ctx);
  * of sweep t + 1 and the latency-bound odometry kernels of sweep t run side by side without sharing a unit's registers and LDS.
  * REPEAT_SHORTCUT (default 1): an outer registration iteration (n_scan_normal.cpp:102-151) that starts from the pose, radius and
  * keyframes of the previous one - a solve that accepted no step - repeats it bit for bit, so its summary is taken from the
- * previous one instead of associating and solving again; 0 runs it again (the tests compare the two). */
+ * previous one instead of associating and solving again; 0 runs it again (the tests compare the two).
+ * MAX_CELLS = n (default 0 = A * k_strongest, the number of filtered points: cannot overflow): oriented surface points per scan
+ * the batched odometry objects created afterwards are sized for. A sequence's memory is (submap_scan_size + 1) scan blocks of
+ * ~12 B per point + 256 B per cell, plus submap_scan_size * cells * 68 B of residual-block scratch: with the default that is
+ * 9 MB at submap_scan_size 4, k 12, but 280 MB at submap_scan_size 50, k 40 (launch/oxford_demo:62-71) - where real scans have a
+ * few hundred to ~1500 cells. A scan that produces more cells than n keeps the first n (ascending voxel index) and the reading
+ * calls (poses / covariances / summary / replay_host) return CFEAR_ERR_CAPACITY from then on: never silently. */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
-       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6 };
+       CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6, CFEAR_TUNE_MAX_CELLS = 7 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

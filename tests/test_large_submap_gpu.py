@@ -144,4 +144,43 @@ def test_repeat_shortcut_off_gives_identical_results():
         assert a[1] == b[1]
         assert np.array_equal(a[2], b[2])
         # the shortcut was really taken somewhere: registrations that end with repeated single-evaluation solves
-        assert any(s[7][:s[2] - 1][-2:] == [1, 1] for s in a[1] if s[2] >= 5)
+        assert any(s[7][:s[2]][-2:] == [1, 1] for s in a[1] if 4 <= s[2] <= 8)
+
+
+def test_max_cells_capacity_is_loud_and_otherwise_invisible():
+    """cfear_tune MAX_CELLS sizes the scan blocks / residual-block scratch of a batched odometry object for fewer oriented surface
+    points than filtered points (280 MB per sequence at s = 50, k = 40 otherwise). Enough capacity: bit-identical results. Too
+    little: the reading calls fail with CFEAR_ERR_CAPACITY (-6) and a message naming the limit - never a silently truncated scan.
+    An object that cannot fit the GPU is refused with the numbers in the message."""
+    A, R, rr = 400, 3360, np.float32(0.0595238)
+    T, B = 24, 2
+    frames = np.empty((T, B, A, R), dtype=np.uint8)
+    for q in range(B):
+        for t0, chunk in synth.drive_chunks(T, "canyon", 51 + q, 61 + q, A, R, rr, ccw=False):
+            frames[t0:t0 + len(chunk), q] = chunk
+    kw = dict(drive_parity.BASE, range_res=rr, submap_scan_size=10, cost=0, loss=2)
+    out = {}
+    for mc in (0, 1024):
+        ctx = capi.Context(capi.default_params(**kw), A, R)
+        odo = ctx.odometry(B, max_cells=mc)
+        rec = odo.replay_host(frames)
+        out[mc] = (rec.copy(), odo.poses(), odo.covariances())
+        assert rec["n_cells"].max() <= 1024 and rec["n_cells"][1:].min() > 300
+        odo.release()
+        ctx.close()
+    for a, b in zip(out[0], out[1024]):
+        assert np.array_equal(a, b)
+    ctx = capi.Context(capi.default_params(**kw), A, R)
+    odo = ctx.odometry(B, max_cells=200)
+    for t in range(3):
+        odo.step_host(frames[t])
+    with pytest.raises(capi.CfearError, match=r"rc=-6.*more than 200 oriented surface points"):
+        odo.poses()
+    with pytest.raises(capi.CfearError, match="rc=-6"):
+        odo.summary(0)
+    odo.reset()  # a reset clears the condition
+    odo.release()
+    with pytest.raises(capi.CfearError, match=r"rc=-5.*sequences fit.*CFEAR_TUNE_MAX_CELLS"):
+        ctx.tune(capi.TUNE_MAX_CELLS, 0)
+        ctx.odometry(200000)
+    ctx.close()
