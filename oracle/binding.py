@@ -67,6 +67,29 @@ def build(force=False):
     return so
 
 
+PERT = {"voxel_reverse": 1, "voxel_random": 2, "voxel_stdsort": 4, "sum_reverse": 8, "sum_pairwise": 16, "wsum_eigen_redux": 32,
+        "eig_jacobi": 64, "nn_tie_high": 128}
+_STDSORT = None
+
+
+def set_perturbation(mask=0, seed=1):
+    """[3P] sensitivity modes of the oracle (cfear_oracle.h; process-wide; 0 = the oracle as specified). mask: an int or a list of
+    PERT names. 'voxel_stdsort' loads oracle/libcfear_stdsort.so (libstdc++'s std::sort called as PCL <= 1.9 calls it)."""
+    global _STDSORT
+    L = lib()
+    if not isinstance(mask, int):
+        mask = sum(PERT[m] for m in mask)
+    if (mask & PERT["voxel_stdsort"]) and _STDSORT is None:
+        so = os.path.join(_HERE, "libcfear_stdsort.so")
+        src = os.path.join(_HERE, "stdsort_perm.cpp")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libcfear_stdsort.so"], stdout=subprocess.DEVNULL)
+        _STDSORT = C.CDLL(so)
+        L.cfo_set_voxel_sorter(C.cast(_STDSORT.cfo_stdsort_perm, C.c_void_p))
+    L.cfo_set_perturbation(C.c_uint(mask), C.c_uint64(seed))
+    return mask
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -75,6 +98,9 @@ def lib():
     u8p, u32p, f32p, f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
                              C.POINTER(C.c_double))
     L.cfo_default_params.argtypes = [C.POINTER(Params)]
+    L.cfo_set_perturbation.argtypes = [C.c_uint, C.c_uint64]
+    L.cfo_set_voxel_sorter.argtypes = [C.c_void_p]
+    L.cfo_get_perturbation.restype = C.c_uint
     L.cfo_filter.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
     L.cfo_filter_bruteforce.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
     L.cfo_cloud.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p]

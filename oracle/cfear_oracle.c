@@ -22,6 +22,47 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* ---- [3P] sensitivity modes (cfear_oracle.h): deliberate variations of third-party behaviour that the reference's sources do not
+ * pin, switched on by tests/run_3p_sensitivity.py only to BOUND their effect on poses and iteration counts. 0 = the oracle. ---- */
+static unsigned g_pert = 0;
+static uint64_t g_pert_seed = 1;
+static cfo_voxel_sorter g_voxel_sorter = NULL;
+void cfo_set_perturbation(unsigned mask, uint64_t seed) { g_pert = mask; g_pert_seed = seed ? seed : 1; }
+void cfo_set_voxel_sorter(cfo_voxel_sorter fn) { g_voxel_sorter = fn; }
+unsigned cfo_get_perturbation(void) { return g_pert; }
+static uint64_t pert_rand(uint64_t* st) { /* xorshift64* */
+  uint64_t x = *st; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; *st = x;
+  return x * 0x2545F4914F6CDD1DULL;
+}
+/* sum of v[0..n) in the order of the active mode: as written (sequential), reversed, pairwise (a balanced tree), or Eigen 3.3's
+ * vectorised redux for an aligned VectorXd with 2-double packets (what `w.sum()` at pointnormal.cpp:19 compiles to on x86-64 /
+ * SSE2: two packet accumulators over quads, then the odd packet, the horizontal add, the scalar tail) */
+static double pert_sum_tree(const double* v, int n) {
+  if (n <= 0) return 0.0;
+  if (n == 1) return v[0];
+  if (n == 2) return v[0] + v[1];
+  const int h = n / 2;
+  return pert_sum_tree(v, h) + pert_sum_tree(v + h, n - h);
+}
+static double pert_sum(const double* v, int n, int is_wsum) {
+  if (g_pert & CFO_PERT_SUM_REVERSE) { double s = 0; for (int i = n - 1; i >= 0; i--) s += v[i]; return s; }
+  if (g_pert & CFO_PERT_SUM_PAIRWISE) return pert_sum_tree(v, n);
+  if ((g_pert & CFO_PERT_WSUM_EIGEN_REDUX) && is_wsum && n >= 2) {
+    const int a2 = (n / 2) * 2, a4 = (n / 4) * 4;
+    double p0[2] = {v[0], v[1]};
+    if (a2 > 2) {
+      double p1[2] = {v[2], v[3]};
+      for (int i = 4; i < a4; i += 4) { p0[0] += v[i]; p0[1] += v[i + 1]; p1[0] += v[i + 2]; p1[1] += v[i + 3]; }
+      p0[0] += p1[0]; p0[1] += p1[1];
+      if (a2 > a4) { p0[0] += v[a4]; p0[1] += v[a4 + 1]; }
+    }
+    double s = p0[0] + p0[1];
+    for (int i = a2; i < n; i++) s += v[i];
+    return s;
+  }
+  double s = 0; for (int i = 0; i < n; i++) s += v[i]; return s;
+}
+
 static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -304,7 +345,22 @@ static int nb_cmp(const void* a, const void* b) {
 /* Symmetric 2x2 eigen-decomposition, closed form. [3P] Eigen::SelfAdjointEigenSolver<Matrix2d>
  * (pointnormal.cpp:39-45) is iterative; equal up to rounding, eigenvalues ascending, unit vectors,
  * identity eigenvectors for an isotropic matrix. Reads the lower triangle like Eigen. */
+/* the same decomposition by one Jacobi rotation (Rutishauser's stable tangent): a different sequence of roundings for the same
+ * mathematical result - stands in for Eigen's iterative tridiagonal QR, whose last ulps differ from the closed form too */
+static void eig2_jacobi(double a, double b, double c, double* lmin, double* lmax, double vmin[2], double vmax[2]) {
+  double l0 = a, l1 = c, cs = 1.0, sn = 0.0;
+  if (b != 0.0) {
+    const double theta = (c - a) / (2.0 * b);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    cs = 1.0 / sqrt(t * t + 1.0); sn = t * cs;
+    l0 = a - t * b; l1 = c + t * b;
+  }
+  /* eigenvectors: (cs, -sn) for l0, (sn, cs) for l1 */
+  if (l0 <= l1) { *lmin = l0; *lmax = l1; vmin[0] = cs; vmin[1] = -sn; vmax[0] = sn; vmax[1] = cs; }
+  else { *lmin = l1; *lmax = l0; vmin[0] = sn; vmin[1] = cs; vmax[0] = cs; vmax[1] = -sn; }
+}
 static void eig2(double a, double b, double c, double* lmin, double* lmax, double vmin[2], double vmax[2]) {
+  if (g_pert & CFO_PERT_EIG_JACOBI) { eig2_jacobi(a, b, c, lmin, lmax, vmin, vmax); return; }
   const double t1 = 0.5 * (a + c);
   const double d = 0.5 * (a - c);
   const double t0 = sqrt(d * d + b * b);
@@ -325,20 +381,31 @@ static void eig2(double a, double b, double c, double* lmin, double* lmax, doubl
 static void make_cell(const float* pts, const int* idx, int N, int weight_intensity, cfo_cell* c) {
   memset(c, 0, sizeof(*c));
   c->nsamples = N;
-  double sum = 0;
+  double sum = 0, ux = 0, uy = 0, cxx = 0, cyx = 0, cyy = 0;
+  if (g_pert & (CFO_PERT_SUM_REVERSE | CFO_PERT_SUM_PAIRWISE | CFO_PERT_WSUM_EIGEN_REDUX)) {
+    /* [3P] sensitivity modes: the same terms, added up in another order (pert_sum) */
+    double* t = (double*)malloc(sizeof(double) * 3 * (size_t)N);
+    for (int i = 0; i < N; i++) t[i] = weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0;
+    sum = pert_sum(t, N, 1);
+    for (int i = 0; i < N; i++) { const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum; t[i] = w * (double)pts[3 * idx[i]]; t[N + i] = w * (double)pts[3 * idx[i] + 1]; }
+    ux = pert_sum(t, N, 0); uy = pert_sum(t + N, N, 0);
+    for (int i = 0; i < N; i++) {
+      const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum;
+      const double dx = (double)pts[3 * idx[i]] - ux, dy = (double)pts[3 * idx[i] + 1] - uy;
+      t[i] = dx * (w * dx); t[N + i] = dy * (w * dx); t[2 * N + i] = dy * (w * dy);
+    }
+    cxx = pert_sum(t, N, 0); cyx = pert_sum(t + N, N, 0); cyy = pert_sum(t + 2 * N, N, 0);
+    free(t);
+  } else {
   for (int i = 0; i < N; i++) { /* :13-18 */
     const double w = weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0;
     sum += w;
   }
-  c->sum_intensity = sum;
-  c->avg_intensity = sum / N;
-  double ux = 0, uy = 0;
   for (int i = 0; i < N; i++) { /* :21-24 */
     const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum;
     ux += w * (double)pts[3 * idx[i]];
     uy += w * (double)pts[3 * idx[i] + 1];
   }
-  double cxx = 0, cyx = 0, cyy = 0;
   for (int i = 0; i < N; i++) { /* :26-33: cov = x^T * (w .* x) */
     const double w = (weight_intensity ? fmax((double)pts[3 * idx[i] + 2] - 60.0, 0.0) : 1.0) / sum;
     const double dx = (double)pts[3 * idx[i]] - ux, dy = (double)pts[3 * idx[i] + 1] - uy;
@@ -346,6 +413,9 @@ static void make_cell(const float* pts, const int* idx, int N, int weight_intens
     cyx += dy * (w * dx); /* lower triangle entry (1,0), the one the eigensolver reads */
     cyy += dy * (w * dy);
   }
+  }
+  c->sum_intensity = sum;
+  c->avg_intensity = sum / N;
   c->mean[0] = ux; c->mean[1] = uy;
   c->cov[0] = cxx; c->cov[1] = cyx; c->cov[2] = cyy;
   double lmin, lmax, vmin[2], vmax[2];
@@ -423,6 +493,35 @@ cfo_scan* cfo_scan_create(const float* xyi, int n, const cfo_params* p, int brut
     keys[i] = (idx << 24) | (uint64_t)i; /* [3P] std::sort on idx only is unstable; pinned here as stable */
   }
   qsort(keys, (size_t)n, sizeof(uint64_t), u64_cmp);
+  if (g_pert & (CFO_PERT_VOXEL_REVERSE | CFO_PERT_VOXEL_RANDOM | CFO_PERT_VOXEL_STDSORT)) {
+    /* [3P] sensitivity modes: another order of the points INSIDE a voxel (PCL sorts on the voxel index only, with an unstable
+     * sort: std::sort up to 1.9, boost's integer_sort from 1.10) - the float centroid sums below then round differently */
+    if ((g_pert & CFO_PERT_VOXEL_STDSORT) && g_voxel_sorter) {
+      /* exactly PCL <= 1.9: index_vector in point order, std::sort with operator< on idx (oracle/stdsort_perm.cpp, libstdc++) */
+      uint32_t* vi = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (size_t)n);
+      uint32_t* pi = vi + n;
+      for (int i = 0; i < n; i++) {
+        const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
+        const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
+        vi[i] = (uint32_t)(ijk0 + ijk1 * div0); pi[i] = (uint32_t)i;
+      }
+      g_voxel_sorter(vi, pi, n);
+      for (int i = 0; i < n; i++) keys[i] = ((uint64_t)vi[i] << 24) | (uint64_t)pi[i];
+      free(vi);
+    } else {
+      uint64_t st = g_pert_seed * 0x9E3779B97F4A7C15ULL + (uint64_t)n;
+      for (int i = 0; i < n;) {
+        int j = i;
+        while (j < n && (keys[j] >> 24) == (keys[i] >> 24)) j++;
+        if (g_pert & CFO_PERT_VOXEL_REVERSE) {
+          for (int a = i, b = j - 1; a < b; a++, b--) { const uint64_t t = keys[a]; keys[a] = keys[b]; keys[b] = t; }
+        } else {
+          for (int a = j - 1; a > i; a--) { const int b = i + (int)(pert_rand(&st) % (uint64_t)(a - i + 1)); const uint64_t t = keys[a]; keys[a] = keys[b]; keys[b] = t; }
+        }
+        i = j;
+      }
+    }
+  }
   /* centroids: [3P] pcl::CentroidPoint<PointXYZI>: float sums divided by float(count), ascending idx */
   s->samples = (float*)malloc(sizeof(float) * 3 * (size_t)n);
   int* vstart = (int*)malloc(sizeof(int) * ((size_t)n + 1));
@@ -516,7 +615,7 @@ int cfo_scan_closest(const cfo_scan* s, double px, double py, double d, int brut
     for (int i = 0; i < s->ncells; i++) {
       const float dx = qx - s->mean_f[2 * i], dy = qy - s->mean_f[2 * i + 1];
       float d2 = dx * dx; d2 += dy * dy;
-      if (d2 < bd) { bd = d2; best = i; }
+      if (d2 < bd || ((g_pert & CFO_PERT_NN_TIE_HIGH) && d2 == bd)) { bd = d2; best = i; }
     }
   } else {
     const double m = d * (1.0 + 1e-6) + 1e-6;
@@ -531,7 +630,7 @@ int cfo_scan_closest(const cfo_scan* s, double px, double py, double d, int brut
         const int i = s->gorder[q];
         const float dx = qx - s->mean_f[2 * i], dy = qy - s->mean_f[2 * i + 1];
         float d2 = dx * dx; d2 += dy * dy;
-        if (d2 < bd || (d2 == bd && i < best)) { bd = d2; best = i; }
+        if (d2 < bd || (d2 == bd && ((g_pert & CFO_PERT_NN_TIE_HIGH) ? i > best : i < best))) { bd = d2; best = i; }
       }
     }
   }

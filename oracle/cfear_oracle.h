@@ -60,6 +60,23 @@ typedef struct cfo_params {
 
 void cfo_default_params(cfo_params* p);
 
+/* ---- [3P] sensitivity modes (tests/run_3p_sensitivity.py; process-wide, 0 = the oracle as specified). Each bit swaps one piece
+ * of third-party behaviour that the reference's sources do not pin for another admissible one, so that its effect on poses and
+ * iteration counts over long drives can be BOUNDED (profiles/r04_3p_sensitivity.json):
+ *   VOXEL_REVERSE / VOXEL_RANDOM / VOXEL_STDSORT  order of the points inside a voxel when the float centroid is summed
+ *       (PCL VoxelGrid sorts on the voxel index with an unstable sort; STDSORT = libstdc++ std::sort on the index only, i.e.
+ *       exactly PCL <= 1.9 on Ubuntu: needs cfo_set_voxel_sorter with the function of oracle/stdsort_perm.cpp);
+ *   SUM_REVERSE / SUM_PAIRWISE  order in which a cell's weights, mean and covariance terms are added (pointnormal.cpp:13-33);
+ *   WSUM_EIGEN_REDUX            only `w.sum()` (pointnormal.cpp:19) in the order of Eigen's vectorised redux (SSE2 packets);
+ *   EIG_JACOBI                  the 2x2 eigen-decomposition by a Jacobi rotation instead of the closed form (:39-45);
+ *   NN_TIE_HIGH                 exact-distance ties of the 1-NN search go to the highest cell index instead of the lowest. */
+enum { CFO_PERT_VOXEL_REVERSE = 1, CFO_PERT_VOXEL_RANDOM = 2, CFO_PERT_VOXEL_STDSORT = 4, CFO_PERT_SUM_REVERSE = 8,
+       CFO_PERT_SUM_PAIRWISE = 16, CFO_PERT_WSUM_EIGEN_REDUX = 32, CFO_PERT_EIG_JACOBI = 64, CFO_PERT_NN_TIE_HIGH = 128 };
+typedef void (*cfo_voxel_sorter)(uint32_t* voxel_idx, uint32_t* point_idx, int n);
+void cfo_set_perturbation(unsigned mask, uint64_t seed);
+unsigned cfo_get_perturbation(void);
+void cfo_set_voxel_sorter(cfo_voxel_sorter fn);
+
 /* Packed k-strongest slot: bits 0..15 range bin, 16..23 intensity, 24 valid, 25 peak. */
 #define CFO_SLOT_RANGE(s) ((int)((s) & 0xFFFFu))
 #define CFO_SLOT_INTENSITY(s) ((int)(((s) >> 16) & 0xFFu))

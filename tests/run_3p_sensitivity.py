@@ -1,0 +1,131 @@
+"""[3P] sensitivity sweep (checker script; runs the ORACLE only, on the CPU): how much do the third-party behaviours that the
+reference's sources do not pin - the order of the points inside a PCL VoxelGrid voxel (std::sort up to PCL 1.9, boost integer_sort
+from 1.10: unstable either way), the order in which Eigen adds up a cell's weights / moments, the rounding of the 2x2
+eigen-decomposition, which of two exactly equidistant cells FLANN returns - move the poses, the iteration counts and the drift
+of a long drive?  Each mode of oracle/cfear_oracle.h (CFO_PERT_*) replays the same driving-like recordings as
+tests/test_drive_replay_gpu.py (synth.DriveWorld / drive_plan: stops, crawling, ramps to 3.5 m/sweep, corners, reversing; Oxford shape
+400 x 3768) through the oracle's fuser and is compared, sweep by sweep, with the unperturbed oracle.
+
+  python tests/run_3p_sensitivity.py [sweeps=2000] [out=profiles/r04_3p_sensitivity.json] [kinds=blocks,canyon,field]
+
+Per mode and drive: the largest difference of a single sweep's registered motion (T_prev^-1 T_cur: what one Register() call returns,
+comparable with the 1e-4 m / 1e-5 rad parity bar), the largest difference of the accumulated pose, the KITTI drift of both runs, and
+the fraction of sweeps whose cell count / residual count / iteration counts / keyframe decision differ."""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+MODES = [["voxel_reverse"], ["voxel_random"], ["voxel_stdsort"], ["sum_reverse"], ["sum_pairwise"], ["wsum_eigen_redux"], ["eig_jacobi"], ["nn_tie_high"],
+         ["voxel_stdsort", "wsum_eigen_redux", "eig_jacobi", "nn_tie_high"]]  # the last: everything a PCL 1.9 / Eigen 3.3 build would plausibly do, together
+CONFIGS = {  # the headline configuration (BASELINE configs[1]) and the reference's most demanding shipped one
+    "cfear3_p2l_k12_s4": dict(),
+    "cfear3_p2p_k40_s4": dict(k_strongest=40, cost=0),
+}
+
+
+def run_modes(job):
+    kind, T, cfg_name = job
+    import numpy as np
+    import drive_parity
+    from oracle import binding as ob
+    from cfear_radarodometry_code_public_amd import kitti, synth
+    A, R, RR = drive_parity.A, drive_parity.R, drive_parity.RR
+    kw = dict(drive_parity.BASE)
+    kw.update(CONFIGS[cfg_name])
+    world = synth.DriveWorld(kind, 0)
+    _, motions, gt = synth.drive_plan(T, world, 1)
+    imgs = np.empty((T, A, R), dtype=np.uint8)
+    t0 = time.time()
+    for s0, chunk in synth.drive_chunks(T, kind, 0, 1, A, R, RR, ccw=False, procs=int(os.environ.get("CFEAR_3P_RENDER_PROCS", "4"))):
+        imgs[s0:s0 + len(chunk)] = chunk
+    t_render = time.time() - t0
+
+    def replay(mask):
+        ob.set_perturbation(mask, seed=7)
+        fu = ob.Fuser(ob.default_params(**kw))
+        poses, counts = np.zeros((T, 3)), []
+        for t in range(T):
+            poses[t] = fu.process_polar(imgs[t])
+            S = fu.last_summary()
+            no = max(int(S.outer_iterations), 0)
+            counts.append((len(fu.last_cells()), int(S.num_residuals), (no,) + tuple(int(v) for v in S.inner_iterations[:min(no, 8)]), int(fu.num_keyframes)))
+        ob.set_perturbation(0)
+        return poses, counts
+
+    def rel_motion(p):  # T_{t-1}^-1 T_t as (dx, dy, dtheta) in the frame of t-1
+        d = np.zeros((len(p) - 1, 3))
+        c, s = np.cos(p[:-1, 2]), np.sin(p[:-1, 2])
+        dx, dy = p[1:, 0] - p[:-1, 0], p[1:, 1] - p[:-1, 1]
+        d[:, 0] = c * dx + s * dy; d[:, 1] = -s * dx + c * dy
+        d[:, 2] = np.arctan2(np.sin(p[1:, 2] - p[:-1, 2]), np.cos(p[1:, 2] - p[:-1, 2]))
+        return d
+    base_p, base_c = replay(0)
+    gtk = kitti.poses_from_xyt(gt)
+    d0 = kitti.drift(gtk, kitti.poses_from_xyt(base_p))
+    out = {"kind": kind, "config": cfg_name, "sweeps": T, "cells_median": float(np.median([c[0] for c in base_c])), "render_s": t_render,
+           "drift_unperturbed": d0, "modes": {}}
+    m0 = rel_motion(base_p)
+    for mode in MODES:
+        p, c = replay(mode)
+        m = rel_motion(p)
+        dm = np.abs(m - m0)
+        dpos = np.linalg.norm(p[:, :2] - base_p[:, :2], axis=1)
+        drot = np.abs(np.arctan2(np.sin(p[:, 2] - base_p[:, 2]), np.cos(p[:, 2] - base_p[:, 2])))
+        d = kitti.drift(gtk, kitti.poses_from_xyt(p))
+        n = float(T - 1)
+        out["modes"]["+".join(mode)] = {
+            "per_sweep_motion_max_diff_m": float(np.hypot(dm[:, 0], dm[:, 1]).max()), "per_sweep_motion_max_diff_rad": float(dm[:, 2].max()),
+            "per_sweep_motion_p99_diff_m": float(np.percentile(np.hypot(dm[:, 0], dm[:, 1]), 99)),
+            "sweeps_over_1e-4_m_or_1e-5_rad": int(np.sum((np.hypot(dm[:, 0], dm[:, 1]) > 1e-4) | (dm[:, 2] > 1e-5))),
+            "accumulated_pose_max_diff_m": float(dpos.max()), "accumulated_pose_max_diff_rad": float(drot.max()),
+            "accumulated_pose_final_diff_m": float(dpos[-1]),
+            "drift_translation_percent": d["translation_percent"], "drift_translation_percent_delta": d["translation_percent"] - d0["translation_percent"],
+            "drift_rotation_deg_per_100m_delta": d["rotation_deg_per_100m"] - d0["rotation_deg_per_100m"],
+            "frac_sweeps_cell_count_differs": sum(a[0] != b[0] for a, b in zip(c[1:], base_c[1:])) / n,
+            "frac_sweeps_residual_count_differs": sum(a[1] != b[1] for a, b in zip(c[1:], base_c[1:])) / n,
+            "frac_sweeps_iteration_counts_differ": sum(a[2] != b[2] for a, b in zip(c[1:], base_c[1:])) / n,
+            "frac_sweeps_keyframe_count_differs": sum(a[3] != b[3] for a, b in zip(c[1:], base_c[1:])) / n,
+        }
+    return out
+
+
+def main():
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_3p_sensitivity.json")
+    kinds = (sys.argv[3] if len(sys.argv) > 3 else "blocks,canyon,field").split(",")
+    jobs = [(k, T, c) for c in CONFIGS for k in kinds]
+    t0 = time.time()
+    import concurrent.futures as cf
+    with cf.ProcessPoolExecutor(max_workers=int(os.environ.get("CFEAR_3P_PROCS", "2")), mp_context=mp.get_context("spawn")) as pool:  # (its workers may have children: the renderers)
+        res = list(pool.map(run_modes, jobs))
+    rep = {"what": "oracle with one [3P] behaviour swapped (oracle/cfear_oracle.h CFO_PERT_*) against the unperturbed oracle, same recordings, every sweep",
+           "sweeps_per_drive": T, "wall_s": time.time() - t0, "runs": res}
+    worst = {}
+    for r in res:
+        for name, m in r["modes"].items():
+            w = worst.setdefault(name, {"per_sweep_motion_max_diff_m": 0.0, "per_sweep_motion_max_diff_rad": 0.0, "sweeps_over_1e-4_m_or_1e-5_rad": 0,
+                                        "drift_translation_percent_delta_abs_max": 0.0, "frac_sweeps_iteration_counts_differ_max": 0.0,
+                                        "frac_sweeps_cell_count_differs_max": 0.0, "accumulated_pose_max_diff_m": 0.0})
+            w["per_sweep_motion_max_diff_m"] = max(w["per_sweep_motion_max_diff_m"], m["per_sweep_motion_max_diff_m"])
+            w["per_sweep_motion_max_diff_rad"] = max(w["per_sweep_motion_max_diff_rad"], m["per_sweep_motion_max_diff_rad"])
+            w["sweeps_over_1e-4_m_or_1e-5_rad"] += m["sweeps_over_1e-4_m_or_1e-5_rad"]
+            w["drift_translation_percent_delta_abs_max"] = max(w["drift_translation_percent_delta_abs_max"], abs(m["drift_translation_percent_delta"]))
+            w["frac_sweeps_iteration_counts_differ_max"] = max(w["frac_sweeps_iteration_counts_differ_max"], m["frac_sweeps_iteration_counts_differ"])
+            w["frac_sweeps_cell_count_differs_max"] = max(w["frac_sweeps_cell_count_differs_max"], m["frac_sweeps_cell_count_differs"])
+            w["accumulated_pose_max_diff_m"] = max(w["accumulated_pose_max_diff_m"], m["accumulated_pose_max_diff_m"])
+    rep["worst_over_all_drives"] = worst
+    with open(out_path, "w") as fh:
+        json.dump(rep, fh, indent=1)
+    for name, w in worst.items():
+        print("%-60s per-sweep %.2e m %.2e rad (%d sweeps over the bar)  accumulated %.2e m  drift delta %.2e %%  iteration counts differ on %.2f %% of sweeps" % (
+            name, w["per_sweep_motion_max_diff_m"], w["per_sweep_motion_max_diff_rad"], w["sweeps_over_1e-4_m_or_1e-5_rad"], w["accumulated_pose_max_diff_m"],
+            w["drift_translation_percent_delta_abs_max"], 100 * w["frac_sweeps_iteration_counts_differ_max"]))
+
+
+if __name__ == "__main__":
+    main()

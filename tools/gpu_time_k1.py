@@ -11,6 +11,12 @@ data["uniform"] = torch.randint(0, 256, (n, A, R), dtype=torch.uint8, device="cu
 w = synth.World(1234)
 base = torch.from_numpy(np.stack([synth.world_scan(w, t, seed=1) for t in range(8)])).cuda()
 data["world"] = base.repeat(n // 8, 1, 1).contiguous()
+if os.environ.get("K1_TIES"):  # S-ties: five intensity levels, > 64 candidates tie at the threshold (the positional scan decides)
+    tb = torch.from_numpy(np.stack([synth.ties_scan(A, R, seed=7 + u) for u in range(8)])).cuda()
+    data["ties"] = tb.repeat(n // 8, 1, 1).contiguous()
+if os.environ.get("K1_UNIFORM_SEEDED"):  # S-uniform as SURVEY 8(d) seeds it (0xC0FFEE + seq) instead of torch.randint
+    ub = torch.from_numpy(np.stack([synth.uniform_scan(A, R, seed=0xC0FFEE + u) for u in range(min(n, 64))])).cuda()
+    data["uniform"] = ub.repeat((n + ub.shape[0] - 1) // ub.shape[0], 1, 1)[:n].contiguous()
 out = torch.zeros((n, A, k), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 configs = [tuple(int(x) for x in c.split(",")) for c in os.environ.get("K1_CONFIGS", "7,4").split(";")]
