@@ -24,6 +24,20 @@
 
 #include "common.h"
 
+// tools/build_k1_stop_variants.sh: profile builds whose row loop ends after phase n (1 load + LDS staging, 2 threshold search and
+// candidate masks, 3 candidates to lanes, 4 ranking; 0 = the product kernel); PMC counters of successive variants difference into
+// per-phase instruction counts (tools/pmc_k1_phases.sh). What a stopped row stores depends on the phase's results, so nothing of
+// the phase is optimised away.
+#ifndef CFEAR_K1_STOP
+#define CFEAR_K1_STOP 0
+#endif
+#define K1_STOP_AT(n, val)                                                           \
+  if (CFEAR_K1_STOP == (n)) {                                                        \
+    if (lane < k) slots[g * (long long)k + lane] = (uint32_t)(val);                  \
+    wave_lds_fence();                                                                \
+    continue;                                                                        \
+  }
+
 namespace {
 
 constexpr uint32_t HI = 0x80808080u;
@@ -91,21 +105,27 @@ __device__ __forceinline__ uint4 chunk_keep(uint4 v, int lo, int hi) {
   return v;
 }
 
-// per-byte (x >= T) as 0x80 flags; brep = (T & 0x7f) replicated, THIGH = (T >= 128)
+// per-byte (x >= T) in bit 7 of every byte (the other bits are not cleared); brep = (T & 0x7f) replicated, THIGH = (T >= 128)
 template <bool THIGH>
-__device__ __forceinline__ uint32_t ge_flags(uint32_t x, uint32_t brep) {
+__device__ __forceinline__ uint32_t ge_bit7(uint32_t x, uint32_t brep) {
   const uint32_t d = (x | HI) - brep;
-  return (THIGH ? (x & d) : (x | d)) & HI;
+  return THIGH ? (x & d) : (x | d);
 }
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }  // v_bfi_b32
 
-// Chunk candidate mask layout: bit (8*b + d) <-> byte b of dword d (byte index 4*d + b in the chunk).
+// Chunk candidate mask layout: bit (8*b + d) <-> byte b of dword d (byte index 4*d + b in the chunk). The four flag bits of a
+// byte position are gathered with bit-field inserts (bit 7 from dword 3, bit 6 from dword 2 >> 1, ...: one v_bfi_b32 per dword
+// instead of an AND with 0x80808080 and an OR) and moved down once.
 template <int NCH, bool THIGH>
 __device__ __forceinline__ void ge_masks_t(const uint4 (&v)[NCH], uint32_t brep, uint32_t (&m)[NCH]) {
 #pragma unroll
   for (int j = 0; j < NCH; j++) {
-    const uint32_t g0 = ge_flags<THIGH>(v[j].x, brep), g1 = ge_flags<THIGH>(v[j].y, brep);
-    const uint32_t g2 = ge_flags<THIGH>(v[j].z, brep), g3 = ge_flags<THIGH>(v[j].w, brep);
-    m[j] = (g0 >> 7) | (g1 >> 6) | (g2 >> 5) | (g3 >> 4);
+    const uint32_t t0 = ge_bit7<THIGH>(v[j].x, brep), t1 = ge_bit7<THIGH>(v[j].y, brep);
+    const uint32_t t2 = ge_bit7<THIGH>(v[j].z, brep), t3 = ge_bit7<THIGH>(v[j].w, brep);
+    uint32_t u = bfi(0x80808080u, t3, t2 >> 1);
+    u = bfi(0xC0C0C0C0u, u, t1 >> 2);
+    u = bfi(0xE0E0E0E0u, u, t0 >> 3);
+    m[j] = (u >> 4) & 0x0F0F0F0Fu;
   }
 }
 // masks of the bytes >= T (1 <= T <= 255; T == 256 -> none), restricted to the row by the validity
@@ -310,6 +330,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     const uint32_t vtail = (~lds_ge[tb] & 0x0F0F0F0Fu) & (jt == 0 ? vhead : 0x0F0F0F0Fu);
     const uint32_t vtail2 = 0u;  // groups after jt hold no row bytes
     wave_lds_fence();
+    K1_STOP_AT(1, v[0].x ^ v[1].y ^ v[2].z ^ v[3].w ^ vhead ^ vtail);
 
     // ---- threshold search: first probe = previous row's threshold ----
     int lo = Tprev;
@@ -327,6 +348,21 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       }
       if (tl > lo) lo = tl;  // count(bytes >= tl) >= k is guaranteed
       cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+    }
+    if (cnt > 64 && lo < 255) {
+      // far too many (a wave's first row starts from z_min; a cluttered row after a quiet one): jump to the k-th largest per-lane
+      // maximum - at least k lanes hold a byte that large, so count(>= it) >= k - instead of bisecting with a full recount per
+      // step (eight recounts on uniformly distributed bytes, where ~76 % of the bins pass z_min)
+      int lm = lane_max_byte_lds<NCH>(win, lane, head, R);
+      int tl = lo, th = 256;
+      while (th - tl > 1) {
+        const int mid = (tl + th) >> 1;
+        if (__popcll(__ballot(lm >= mid)) >= k) tl = mid; else th = mid;
+      }
+      if (tl > lo) {
+        lo = tl;
+        cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+      }
     }
     if (cnt > 64) {
       int hi = 256;
@@ -355,7 +391,8 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int bp = 16 * (j * 64 + lane) - head;  // range bin of byte 0 of this chunk
-        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);
+        const int nb = pstar - bp;                   // chunk bytes with index >= nb have range >= pstar (m is inside the row already)
+        const uint32_t keep = lds_ge[nb < 0 ? 0 : (nb > 16 ? 16 : nb)];
         m[j] = mg[j] | (m[j] & ~mg[j] & keep);  // (> lo) | (== lo & range >= pstar)
       }
       cnt = k;
@@ -367,12 +404,13 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
         const int bp = 16 * (j * 64 + lane) - head;
-        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);
+        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);  // (zeros are not in m: the row end has to be cut here; rare path)
         m[j] |= (~m[j]) & 0x0F0F0F0Fu & keep;
       }
       cnt += need;
     }
 
+    K1_STOP_AT(2, (uint32_t)cnt + (m[0] ^ m[1] ^ m[NCH - 2] ^ m[NCH - 1]));
     // ---- compaction without a per-candidate loop (strong returns cluster: a lane often holds five or more
     // candidates). Lane l's candidates take the slots ex[l] .. ex[l] + count - 1 (DPP prefix sum). The lane that
     // owns slot s finds its producer l (producers scatter their id to their first slot, a DPP max-scan spreads it),
@@ -425,18 +463,46 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
         key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
       }
     }
-    // rank = number of larger keys: every lane reads the same four keys per LDS instruction (broadcast), a compare and
-    // an add per key; lanes >= C hold key 0, so reading past C is harmless.
-    wave_lds_fence();  // every lane has fetched its slot code
-    keys[lane] = key;
-    wave_lds_fence();
+    K1_STOP_AT(3, key);
+    // ---- ranks. Few candidates (C <= 2k, the usual case behind a threshold that tracks the previous azimuth): every lane counts the
+    // larger keys among all C - four keys per LDS instruction (broadcast reads), a compare and an add per key; lanes >= C hold key 0,
+    // so reading past C is harmless. Many candidates (a cold threshold, uniformly distributed bytes: C up to 64): two vector
+    // instructions per key are the largest item of the row, so first K* = the k-th largest key by bisection on count(key >= mid) - one
+    // vector compare per step, the count and the interval on the scalar unit, ending as soon as a step counts exactly k (keys are
+    // distinct: the range bin is part of the key, so equal intensities are split by range exactly like std::pair<uchar, int>) -
+    // then the k kept keys move to the front of the LDS array (a prefix count of the ballot) and are ranked among themselves.
+    bool kept;
     int rank = 0;
-    for (int j = 0; j < C; j += 4) {
-      const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
-      rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+    wave_lds_fence();  // every lane has fetched its slot code
+    if (C > 2 * k) {  // wave-uniform
+      const uint32_t k24 = key & 0xFFFFFFu;  // intensity << 16 | range (lanes >= C hold 0)
+      uint32_t klo = (uint32_t)lo << 16, khi = 256u << 16;  // count(>= klo) = C > k, count(>= khi) = 0
+      while (khi - klo > 1u) {
+        const uint32_t mid = (klo + khi) >> 1;
+        const int c = __popcll(__ballot(k24 >= mid));
+        if (c >= k) { klo = mid; if (c == k) break; } else khi = mid;
+      }
+      kept = k24 >= klo;  // exactly k lanes (kk = k)
+      const unsigned long long keptb = __ballot(kept);
+      const int kpos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(keptb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)keptb, 0u));
+      if (kept) keys[kpos] = key;
+      if (lane >= kk && lane < kk + 4) keys[lane] = 0u;  // the rest of the last group of four (key 0 is smaller than any kept key)
+      wave_lds_fence();
+      for (int j = 0; j < kk; j += 4) {
+        const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
+        rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+      }
+    } else {
+      keys[lane] = key;
+      wave_lds_fence();
+      for (int j = 0; j < C; j += 4) {
+        const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
+        rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+      }
+      kept = lane < C && rank < kk;
     }
-    const bool kept = lane < C && rank < kk;
     const int mpos = (int)(key & 0xFFFFu);
+    K1_STOP_AT(4, key + (uint32_t)rank);
 
     // ---- axial non-max suppression (radar_filters.cpp:238-298) on the kept points ----
     uint32_t peak = 0;
