@@ -174,7 +174,7 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS = 1, 2, 3, 4, 5, 6, 7
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class Context:
@@ -376,13 +376,15 @@ class Context:
         if self._h:
             self._L.cfear_host_free(self._h, ptr)
 
-    def odometry(self, n_sequences, overlap=None, filter_cus=None, max_cells=None):
+    def odometry(self, n_sequences, overlap=None, filter_cus=None, max_cells=None, reg_order=None):
         """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
         sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams"""
         if overlap is not None:
             self.tune(TUNE_ODOMETRY_OVERLAP, int(overlap))
         if filter_cus is not None:
             self.tune(TUNE_FILTER_CUS, int(filter_cus))
+        if reg_order is not None:  # registration workgroups longest first (keys: the previous sweep's work)
+            self.tune(TUNE_REGISTRATION_ORDER, int(reg_order))
         if max_cells is not None:  # oriented surface points per scan the object is sized for (0: every filtered point)
             self.tune(TUNE_MAX_CELLS, int(max_cells))
         return Odometry(self, n_sequences)

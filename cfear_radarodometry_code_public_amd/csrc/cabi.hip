@@ -119,6 +119,7 @@ int cfear_tune(cfear_ctx* ctx, int key, int value) {
     case CFEAR_TUNE_FILTER_ROWS_PER_WAVE: ctx->tune_k1_rows = value > 0 ? value : 0; return CFEAR_OK;
     case CFEAR_TUNE_ODOMETRY_OVERLAP: ctx->tune_odo_overlap = value < 0 ? 0 : (value > 8 ? 8 : value); return CFEAR_OK;
     case CFEAR_TUNE_FILTER_CUS: ctx->tune_filter_cus = value < 0 ? 0 : value; return CFEAR_OK;
+    case CFEAR_TUNE_REGISTRATION_ORDER: ctx->tune_reg_order = value != 0; return CFEAR_OK;
     case CFEAR_TUNE_MAX_CELLS: ctx->tune_max_cells = value < 0 ? 0 : value; return CFEAR_OK;
     case CFEAR_TUNE_REPEAT_SHORTCUT: ctx->tune_repeat_shortcut = value != 0; return CFEAR_OK;
     case CFEAR_TUNE_REPLAY_PERSISTENT_MAX: ctx->tune_replay_persistent_max = value < 0 ? 0 : value; return CFEAR_OK;

@@ -66,6 +66,10 @@ struct OdoParams {
   // computed, not fetched from the pointer table (a memory round trip at the start of both kernels)
   unsigned char* scans_base; size_t scan_stride;
   cfear_sweep_record* records;  // optional [B]: this sweep's record of every sequence (cfear_odometry_replay_host)
+  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): order[blockIdx.x] = the sequence a workgroup takes (null:
+  // seq0 + blockIdx.x), work[q] = what sequence q's registration of THIS sweep cost (evaluations x residual blocks + associations),
+  // the key the next sweep's order is sorted by (null: not recorded)
+  const int* order; unsigned* work;
   int* flags;  // one word per odometry object: bit 0 = some scan had more cells than its block holds (CFEAR_ERR_CAPACITY); null: cannot happen
 };
 
@@ -171,6 +175,7 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
     if (tid == 0) {
       st->ring[0] = cur_slot; st->kf_pose[0] = aff_identity(); st->nkf = 1; st->free_slot = (cur_slot + 1) % nslots;
       st->frames++; st->last_slot = cur_slot;
+      if (OP.work) OP.work[q] = 0u;
       sum->success = 0; sum->usable = 0; sum->outer_iterations = 0; sum->num_residuals = 0; sum->num_residual_blocks = 0;
       double v[3]; aff_to_xyt(st->Tcurrent, v);
       poses_out[3 * q] = v[0]; poses_out[3 * q + 1] = v[1]; poses_out[3 * q + 2] = v[2];
@@ -249,6 +254,13 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
       r->outer_iterations = sum->outer_iterations; r->num_residuals = sum->num_residuals; r->n_keyframes = st->nkf; r->n_cells = cur->n_cells;
       for (int i = 0; i < 8; i++) r->inner_iterations[i] = sum->inner_iterations[i];
     }
+    if (OP.work) {  // from the solver state in LDS: no read-back of the summary from memory
+      const RegShared* rs = reinterpret_cast<const RegShared*>(lds + RegLds::regsh);
+      int evals = 0;
+      for (int i = 0; i < rs->nrec; i++) evals += rs->orec[i].inner;
+      const int nsrc = rs->kf[ns - 1].n_cells;
+      OP.work[q] = (unsigned)evals * (unsigned)rs->M + 6u * (unsigned)rs->nrec * (unsigned)(nkf * nsrc);
+    }
     if (!TIMED && OP.wg_times) OP.wg_times[(size_t)q * 32 + 15] = (long long)wall_clock64();
   }
 }
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kerne
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
-  register_step_body<TIMED, KCOST>(lds, OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
+  register_step_body<TIMED, KCOST>(lds, OP.order ? OP.order[blockIdx.x] : OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
 }
 
 

@@ -128,6 +128,33 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
+// Registration workgroups longest first: sequences ordered by the work their registration took in the previous sweep (a sequence's
+// scene changes slowly), as a counting sort over 256 buckets of the key - one workgroup, a few microseconds. The order inside a
+// bucket is whatever the atomics give: results do not depend on which workgroup slot a sequence takes.
+__global__ __launch_bounds__(1024) void order_kernel(const unsigned* work, int B, int* order) {
+  __shared__ unsigned hist[256], red[16];
+  const int tid = threadIdx.x;
+  unsigned mx = 1u;
+  for (int i = tid; i < B; i += 1024) mx = max(mx, work[i]);
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  if (tid < 256) hist[tid] = 0u;
+  __syncthreads();
+  mx = 1u;
+  for (int i = 0; i < 16; i++) mx = max(mx, red[i]);
+  const float scale = 255.0f / (float)mx;
+  for (int i = tid; i < B; i += 1024) atomicAdd(&hist[255 - min(255, (int)((float)work[i] * scale))], 1u);  // bucket 0 = the most work
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 256 counts: four per lane, a wave scan across the lanes
+    const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+    unsigned v = c0 + c1 + c2 + c3, incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = (unsigned)__shfl_up((int)incl, o); if (tid >= o) incl += u; }
+    const unsigned ex = incl - v;
+    hist[4 * tid] = ex; hist[4 * tid + 1] = ex + c0; hist[4 * tid + 2] = ex + c0 + c1; hist[4 * tid + 3] = ex + c0 + c1 + c2;
+  }
+  __syncthreads();
+  for (int i = tid; i < B; i += 1024) order[atomicAdd(&hist[255 - min(255, (int)((float)work[i] * scale))], 1u)] = i;
+}
 // ---- host-side helpers ---------------------------------------------------------------------------
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -238,6 +265,8 @@ struct cfear_scan {
 };
 struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
+  int* d_order = nullptr; unsigned* d_work = nullptr;  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): see order_kernel
+  bool order_ready = false;  // d_work holds the keys of a registration launch
   int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells (only allocated when cap_cells < cap_points)
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
   ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
@@ -343,19 +372,33 @@ static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
   OP.scans_base = o->d_scans; OP.scan_stride = o->scan_stride;
   OP.records = nullptr;
   OP.flags = o->d_flags;
+  OP.order = nullptr; OP.work = o->d_work;
   return OP;
 }
 // features -> registration of one sweep of every sequence on `st`, from the filter's slots
 // the registration step kernel of a sweep. register_step.hip holds the production instantiations (one per cost metric, registrations of
 // up to CFEAR_STEP_SMALL_SCANS scans: a bigger LDS match array); a larger submap runs the instantiation of this file (any cost, 64 scans)
-static void launch_register_step(const OdoParams& P, int count, hipStream_t st, cfear_odometry* o) {
+static void launch_register_step(const OdoParams& P_in, int count, hipStream_t st, cfear_odometry* o) {
+  OdoParams P = P_in;
+  if (o->d_order && count == o->B && P.seq0 == 0) {  // (whole-batch launches only: the sub-batches of the overlap mode keep their ranges)
+    if (o->order_ready) {
+      hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, o->d_work, o->B, o->d_order);
+      P.order = o->d_order;
+    }
+    o->order_ready = true;  // this launch records the keys of the next one
+  }
   if (P.submap + 1 <= CFEAR_STEP_SMALL_SCANS) {
     cfear_launch_register_step_small(&P, count, st, o->d_states, reinterpret_cast<void* const*>(o->d_scan_ptrs), o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
     return;
   }
 #define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs, \
                                                   o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out)
-  if (P.phase_times) CFEAR_LAUNCH_REG(true, -1); else CFEAR_LAUNCH_REG(false, -1);
+  // one instantiation per cost metric here too (the evaluation inline, no run-time dispatch): a ten- or fifty-keyframe submap
+  // evaluates thousands of residual blocks 30-80 times per registration
+  if (P.phase_times) CFEAR_LAUNCH_REG(true, -1);
+  else if (P.rp.cost == CFEAR_COST_P2L) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2L);
+  else if (P.rp.cost == CFEAR_COST_P2D) CFEAR_LAUNCH_REG(false, CFEAR_COST_P2D);
+  else CFEAR_LAUNCH_REG(false, CFEAR_COST_P2P);
 #undef CFEAR_LAUNCH_REG
 }
 static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoParams& P, const uint32_t* d_slots, int seq_count, hipStream_t st) {
@@ -880,7 +923,7 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times,
-                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records, o->d_flags};
+                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records, o->d_flags, o->d_order, o->d_work};
   for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1], o->rp_in}) if (e) (void)hipEventDestroy(e);
   if (o->rp_stream) (void)hipStreamDestroy(o->rp_stream);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -906,6 +949,7 @@ int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_poses_out, 0, sizeof(double) * 3 * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_cov_work, 0, sizeof(double) * 36 * (size_t)o->B, ctx->stream));
   if (o->d_flags) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int), ctx->stream));
+  o->order_ready = false;
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }
@@ -953,6 +997,9 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   if (ok && o->cap_cells < o->cap_points) ok = hipMalloc(&o->d_flags, sizeof(int)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int)) == hipSuccess;
+  if (ok && ctx->tune_reg_order && B >= 2)
+    ok = hipMalloc(&o->d_order, sizeof(int) * (size_t)B) == hipSuccess && hipMalloc(&o->d_work, sizeof(unsigned) * (size_t)B) == hipSuccess &&
+         hipMemset(o->d_work, 0, sizeof(unsigned) * (size_t)B) == hipSuccess;
   if (!ok) { cfear_odometry_destroy(ctx, o); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc odometry state"); }
   o->scan_stride = SL.total;
   std::vector<ScanDev*> ptrs((size_t)B * o->nslots);

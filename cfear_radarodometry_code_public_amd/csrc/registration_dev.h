@@ -970,10 +970,13 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       cnt += (ti >= 0) ? 1 : 0;
     }
     int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
-    mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 0;
+    // more residual blocks than the LDS array holds (ten keyframes of a dense scene, fifty of any): its capacity stays in LDS, the
+    // rest goes to memory (mode 2, as on the fast path) - every evaluation of a solve reads the matches again
+    const int lcap = match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+    mode = M <= lcap ? 1 : 2;
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];
-      if (ti >= 0) emit_match(scans, src, sh, nsrc, p, ti, o++, mode == 1);
+      if (ti >= 0) { emit_match(scans, src, sh, nsrc, p, ti, o, mode == 1 || o < lcap); o++; }
     }
   }
   if (tid == 0) sh->lds_match = mode;

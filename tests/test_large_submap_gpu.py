@@ -184,3 +184,29 @@ def test_max_cells_capacity_is_loud_and_otherwise_invisible():
         ctx.tune(capi.TUNE_MAX_CELLS, 0)
         ctx.odometry(200000)
     ctx.close()
+
+
+def test_registration_launch_order_does_not_change_results():
+    """cfear_tune REGISTRATION_ORDER: the registration workgroups take the sequences longest first (a counting sort on the device
+    over the previous sweep's work). Which workgroup slot a sequence gets must not show in any result."""
+    A, R, rr = 400, 3360, np.float32(0.0595238)
+    T, U, B = 14, 3, 301
+    uniq = np.empty((T, U, A, R), dtype=np.uint8)
+    for u, kind in enumerate(("blocks", "canyon", "field")):
+        for t0, chunk in synth.drive_chunks(T, kind, 70 + u, 80 + u, A, R, rr, ccw=False):
+            uniq[t0:t0 + len(chunk), u] = chunk
+    kinds = np.random.default_rng(5).integers(0, U, B)
+    out = {}
+    for order in (0, 1):
+        kw = dict(drive_parity.BASE, range_res=rr)
+        ctx = capi.Context(capi.default_params(**kw), A, R)
+        odo = ctx.odometry(B, reg_order=order)
+        for t in range(T):
+            odo.step_host(uniq[t][kinds])
+        S = [odo.summary(q) for q in range(0, B, 7)]
+        out[order] = (odo.poses(), odo.covariances(), [(s[0].outer_iterations, list(s[0].inner_iterations[:8]), s[0].num_residuals, s[0].final_cost, s[1], s[2]) for s in S])
+        odo.release()
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    for u in range(U):  # and the replicas of one stream agree among themselves
+        assert np.all(out[1][0][kinds == u] == out[1][0][kinds == u][0])

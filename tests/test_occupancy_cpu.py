@@ -31,9 +31,9 @@ def remarks(src, tmp_path):
 def test_step_kernels_keep_their_occupancy(tmp_path):
     k = remarks("pipeline.hip", tmp_path)
     feat = [v for n, v in k.items() if "features_step_kernelILb0" in n][0]
-    regs = {n: v for n, v in k.items() if "register_step_kernelILb0" in n}  # the instantiation for large submaps (any cost, 64 scans)
-    regs.update({n: v for n, v in remarks("register_step.hip", tmp_path).items() if "register_step_kernelILb0" in n})  # production: one per cost metric
-    assert len(regs) == 4, sorted(regs)
+    regs = {"large:" + n: v for n, v in k.items() if "register_step_kernelILb0" in n}  # the instantiations for large submaps (64 scans), one per cost metric
+    regs.update({"small:" + n: v for n, v in remarks("register_step.hip", tmp_path).items() if "register_step_kernelILb0" in n})  # production (<= 8 scans): one per cost metric
+    assert len(regs) == 6, sorted(regs)
     for n, reg in regs.items():
         assert reg["Occupancy"] >= 3 and reg["LDS"] <= 53760, (n, reg)      # three 256-thread workgroups per CU
     assert feat["Occupancy"] >= 4 and feat["LDS"] <= 80384 and feat["ScratchSize"] <= 16, feat  # two 512-thread workgroups per CU; at most two registers parked in scratch once per workgroup
