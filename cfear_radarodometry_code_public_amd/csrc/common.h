@@ -39,7 +39,7 @@ struct cfear_ctx {
   // whether a batched odometry object created from now on runs its filter one sweep ahead on a stream of its own
   int tune_k1_occ = 7, tune_k1_rows = 0 /* 0 = by launch size: 4, or 6 from 1536 scans up */, tune_odo_overlap = 0;
   int tune_filter_cus = 0;  // with ODOMETRY_OVERLAP: compute units reserved for the filter stream (CU-masked streams); 0 = no masks
-  int tune_reg_order = 0;  // batched odometry objects created afterwards launch their registration workgroups longest first (keys: the previous sweep's work)
+  int tune_reg_order = 1;  // batched odometry objects created afterwards launch their registration workgroups longest first (keys: the previous sweep's work)
   int tune_max_cells = 0;  // batched odometry: oriented surface points per scan the scan blocks / match scratch are sized for (0 = A * k: every filtered point)
   int tune_repeat_shortcut = 1;  // registration: an outer iteration that would repeat the previous one bit for bit is not recomputed (0: it is - tests)
   int tune_replay_persistent_max = 256;  // cfear_odometry_replay_host: up to this many sequences run as persistent workgroups (replay.hip)

@@ -662,7 +662,9 @@ __device__ __forceinline__ int assoc_get(const Assoc4& a, int i) { return i == 0
 // candidate update uses selects and non-short-circuit predicates: a load whose only use sits in a conditional block gets sunk
 // into it and waited for alone. Returns the four matches 16 bits each (0xFFFF = none, 0xFFFE = left to
 // the caller), which needs <= 65533 cells per keyframe (else that keyframe is left to the caller).
-__device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh, int nk, int j, double curr_radius) {
+// kbase, nk: the (up to four) keyframes kbase .. kbase + nk - 1 of the registration (a submap of more than four keyframes is
+// searched in groups of four)
+__device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh, int k0, int nk, int j, double curr_radius) {
   typedef __attribute__((address_space(1))) const double g_cf64;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(1))) const u32x2 g_cu32x2;
@@ -682,7 +684,7 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
   u32x2 L[4], H[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) {  // windows and bucket bounds of all keyframes: one round trip
-    const int i = min(u, nk - 1);
+    const int i = k0 + min(u, nk - 1);
     const auto* T = sh->Trel[i];
     qx[u] = (float)((T[0] * mx + T[1] * my) + T[4]);
     qy[u] = (float)((T[2] * mx + T[3] * my) + T[5]);
@@ -729,7 +731,7 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
       f32x4 c[2][NC];
 #pragma unroll
       for (int v = 0; v < 2; v++) {
-        g_cf32x4* gp = (g_cf32x4*)sh->kf[min(u0 + v, nk - 1)].gp;
+        g_cf32x4* gp = (g_cf32x4*)sh->kf[k0 + min(u0 + v, nk - 1)].gp;
 #pragma unroll
         for (int w = 0; w < NC; w++) {
           const int kk = k + w;
@@ -759,13 +761,13 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
   };
   auto gate_load = [&](int u0) {
 #pragma unroll
-    for (int v = 0; v < 2; v++) tn[v] = ((g_cf64x2*)(sh->kf[min(u0 + v, nk - 1)].rtar + 8 * (size_t)(ti[u0 + v] >= 0 ? ti[u0 + v] : 0)))[1];
+    for (int v = 0; v < 2; v++) tn[v] = ((g_cf64x2*)(sh->kf[k0 + min(u0 + v, nk - 1)].rtar + 8 * (size_t)(ti[u0 + v] >= 0 ? ti[u0 + v] : 0)))[1];
   };
   auto gate = [&](int u0) {
 #pragma unroll
     for (int v = 0; v < 2; v++) {
       const int u = u0 + v;
-      const auto* T = sh->Trel[min(u, nk - 1)];
+      const auto* T = sh->Trel[k0 + min(u, nk - 1)];
       const double nx = T[0] * snx + T[1] * sny;
       const double ny = T[2] * snx + T[3] * sny;
       const double sim = fmax(nx * tn[v].x + ny * tn[v].y, 0.0);
@@ -789,19 +791,19 @@ __device__ __noinline__ unsigned long long associate_cell4(const LRegShared* sh,
   for (int u = 0; u < 4; u++) r |= (unsigned long long)(unsigned)(ti[u] & 0xFFFF) << (16 * u);
   return r;
 }
-__device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegShared* sh, int nk, int j, double curr_radius) {
+__device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegShared* sh, int k0, int nk, int j, double curr_radius) {
   Assoc4 a;
   {
-    const unsigned long long p = associate_cell4(sh, nk, j, curr_radius);
+    const unsigned long long p = associate_cell4(sh, k0, nk, j, curr_radius);
     auto un = [](unsigned v) -> int { return v >= 0xFFFEu ? (int)v - 0x10000 : (int)v; };  // 0xFFFF -> -1, 0xFFFE -> -2
     a.t0 = un((unsigned)(p & 0xFFFF)); a.t1 = un((unsigned)((p >> 16) & 0xFFFF)); a.t2 = un((unsigned)((p >> 32) & 0xFFFF)); a.t3 = un((unsigned)(p >> 48));
   }
   if (a.t0 == -2 || a.t1 == -2 || a.t2 == -2 || a.t3 == -2) {  // rare: the general search for those pairs
     const int nsrc = src->n_cells;
-    if (a.t0 == -2) a.t0 = associate_pair(src, sh, nsrc, 0 * nsrc + j, curr_radius);
-    if (a.t1 == -2) a.t1 = associate_pair(src, sh, nsrc, 1 * nsrc + j, curr_radius);
-    if (a.t2 == -2) a.t2 = associate_pair(src, sh, nsrc, 2 * nsrc + j, curr_radius);
-    if (a.t3 == -2) a.t3 = associate_pair(src, sh, nsrc, 3 * nsrc + j, curr_radius);
+    if (a.t0 == -2) a.t0 = associate_pair(src, sh, nsrc, (k0 + 0) * nsrc + j, curr_radius);
+    if (a.t1 == -2) a.t1 = associate_pair(src, sh, nsrc, (k0 + 1) * nsrc + j, curr_radius);
+    if (a.t2 == -2) a.t2 = associate_pair(src, sh, nsrc, (k0 + 2) * nsrc + j, curr_radius);
+    if (a.t3 == -2) a.t3 = associate_pair(src, sh, nsrc, (k0 + 3) * nsrc + j, curr_radius);
   }
   return a;
 }
@@ -811,7 +813,7 @@ __device__ __forceinline__ Assoc4 associate_cell(const ScanDev* src, const LRegS
 // flat stores through the address unit). Same arithmetic as write_match.
 template <int KCOST = -1>
 __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh,
-                                          int nsrc, int nk, int j, Assoc4 a, unsigned long long pos, int mode /* RegShared::lds_match */) {
+                                          int nsrc, int k0, int nk, int j, Assoc4 a, unsigned long long pos, int mode /* RegShared::lds_match */) {
   // block-uniform values in scalar registers: read from LDS they sit in vector registers, and every branch on them is compiled as
   // a divergent one (save the exec mask, branch, restore)
   const int cost = KCOST >= 0 ? KCOST : __builtin_amdgcn_readfirstlane(sh->rp.cost), weight_opt = __builtin_amdgcn_readfirstlane(sh->rp.weight_opt);
@@ -838,14 +840,14 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int tu = assoc_get(a, i + u);
-        g_cf64x2* r = (g_cf64x2*)(sh->kf[min(i + u, nk - 1)].rtar + 8 * (size_t)(tu >= 0 ? tu : 0));
+        g_cf64x2* r = (g_cf64x2*)(sh->kf[k0 + min(i + u, nk - 1)].rtar + 8 * (size_t)(tu >= 0 ? tu : 0));
         R0[u] = r[0]; R1[u] = r[1]; R2[u] = r[2];  // mean, normal, (samples, scale)
       }
     }
     const int ti = assoc_get(a, i);
     const bool on = ti >= 0 && i < nk;
     const int tix = on ? ti : 0;
-    const int ki = min(i, nk - 1);
+    const int ki = k0 + min(i, nk - 1);
     const int o = (int)((pos >> (16 * i)) & 0xFFFF);
     lds_double* lm = (lds_double*)lds_match_base() + o;
     double* gm = sh->rw.tmx + o;
@@ -902,32 +904,33 @@ __device__ __forceinline__ unsigned long long assoc_counts(const Assoc4& a) {
   return (unsigned long long)(a.t0 >= 0) | ((unsigned long long)(a.t1 >= 0) << 16) | ((unsigned long long)(a.t2 >= 0) << 32) |
          ((unsigned long long)(a.t3 >= 0) << 48);
 }
-__device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int itr, int b) {
+// block b of the source cells against the keyframes k0 .. k0 + nk - 1 (group g of four); park: the matches wait in W.assoc (slot
+// g * nsrc + j) for the totals of all blocks and groups
+__device__ __forceinline__ AssocBlock assoc_block(const ScanDev* src, const LRegShared* sh, int k0, int nk, int nsrc, int itr, int b, int g, bool park) {
   AssocBlock R;
   R.a.t0 = R.a.t1 = R.a.t2 = R.a.t3 = -1;
   const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
   if (j < nsrc) {
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
-    R.a = associate_cell(src, sh, nk, j, curr_radius);
+    R.a = associate_cell(src, sh, k0, nk, j, curr_radius);
   }
   R.e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(R.a), reinterpret_cast<unsigned long long*>(sh->rw.red), &R.tb);
-  // more source cells than threads: the matches wait in W.assoc for the totals of all blocks
-  if (nsrc > CFEAR_REG_BLOCK && j < nsrc) reinterpret_cast<int4*>(sh->rw.assoc)[j] = make_int4(R.a.t0, R.a.t1, R.a.t2, R.a.t3);
+  if (park && j < nsrc) reinterpret_cast<int4*>(sh->rw.assoc)[(size_t)g * nsrc + j] = make_int4(R.a.t0, R.a.t1, R.a.t2, R.a.t3);
   return R;
 }
-// residual blocks of block b of the source cells; before = matches in front of this block, per keyframe. Returns the
-// matches of the block per keyframe (0 when the block is the only one: nothing follows it).
+// residual blocks of block b of the source cells for the keyframes of group g; before = positions the group's keyframes start at
+// plus their matches in earlier blocks. Returns the matches of the block per keyframe (0 when nothing was parked: nothing follows).
 template <int KCOST = -1>
-__device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nk, int nsrc, int b,
-                                                      Assoc4 a, unsigned long long e, unsigned long long before, int mode) {
+__device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int k0, int nk, int nsrc, int b, int g,
+                                                      bool parked, Assoc4 a, unsigned long long e, unsigned long long before, int mode) {
   const int j = b * CFEAR_REG_BLOCK + threadIdx.x;
   unsigned long long tb = 0;
-  if (nsrc > CFEAR_REG_BLOCK) {  // positions inside the block: the same scan again (cheaper than keeping them)
+  if (parked) {  // positions inside the block: the same scan again (cheaper than keeping them)
     a.t0 = a.t1 = a.t2 = a.t3 = -1;
-    if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
+    if (j < nsrc) { const int4 v = reinterpret_cast<const int4*>(sh->rw.assoc)[(size_t)g * nsrc + j]; a.t0 = v.x; a.t1 = v.y; a.t2 = v.z; a.t3 = v.w; }
     e = block_exclusive_scan64<CFEAR_REG_BLOCK>(assoc_counts(a), reinterpret_cast<unsigned long long*>(sh->rw.red), &tb);
   }
-  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell<KCOST>(scans, src, sh, nsrc, nk, j, a, before + e, mode);
+  if (a.t0 >= 0 || a.t1 >= 0 || a.t2 >= 0 || a.t3 >= 0) emit_cell<KCOST>(scans, src, sh, nsrc, k0, nk, j, a, before + e, mode);
   return tb;
 }
 
@@ -940,26 +943,50 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   int M;
   int mode;  // RegShared::lds_match
   const int nk = n - 1;
-  const bool can_park = 4 * (long long)nsrc <= (long long)sh->rw.cap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
-  if (nk <= 4 && (nsrc <= nt || (nsrc <= 4 * nt && can_park))) {
-    const Assoc4 none = {-1, -1, -1, -1};
-    if (nsrc <= nt) {  // one block of cells: its matches stay in registers
-      const AssocBlock R = assoc_block(src, sh, nk, nsrc, itr, 0);
-      const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
-      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
-      M = (int)(t0 + t1 + t2 + t3);
-      mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 2;
-      (void)emit_block<KCOST>(scans, src, sh, nk, nsrc, 0, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
-    } else {
+  const int ngroups = (nk + 3) >> 2;
+  const int lcap = match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+  const bool can_park = 4 * (long long)ngroups * nsrc <= (long long)sh->rw.cap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
+  bool done = false;
+  if (nk <= 4 && nsrc <= nt) {  // one group of keyframes, one block of cells: the matches stay in registers
+    const AssocBlock R = assoc_block(src, sh, 0, nk, nsrc, itr, 0, 0, false);
+    const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
+    const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+    M = (int)(t0 + t1 + t2 + t3);
+    mode = M <= lcap ? 1 : 2;
+    (void)emit_block<KCOST>(scans, src, sh, 0, nk, nsrc, 0, 0, false, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
+    done = true;
+  } else if (nsrc <= 4 * nt && can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
+    // several blocks of cells and / or several groups of four keyframes (a submap of 5 .. 63 keyframes: the reference's s10 and s50
+    // presets): every (group, block) is searched with the four-keyframes-at-once association and parked; the residual blocks are
+    // numbered as the reference does - pair index keyframe * nsrc + cell ascending - from the per-keyframe totals (16-bit fields:
+    // at most 65535 residual blocks)
+    unsigned long long* gt = reinterpret_cast<unsigned long long*>(sh->rw.red_i);  // totals of up to 16 groups (the general path's scan scratch: free here)
+    int Mt = 0;
+    for (int g = 0; g < ngroups; g++) {
+      const int k0 = 4 * g, nkg = min(4, nk - k0);
       unsigned long long T = 0;
-      for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, nk, nsrc, itr, b).tb;  // every field <= nsrc <= 4 * blockDim
-      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
-      M = (int)(t0 + t1 + t2 + t3);
-      mode = M <= match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost) ? 1 : 2;
-      unsigned long long before = (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48);  // matches of earlier keyframes
-      for (int b = 0; b * nt < nsrc; b++) before += emit_block<KCOST>(scans, src, sh, nk, nsrc, b, none, 0, before, mode);
+      for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, k0, nkg, nsrc, itr, b, g, true).tb;  // every field <= nsrc <= 4 * blockDim
+      if (tid == 0) gt[g] = T;
+      Mt += (int)((T & 0xFFFF) + ((T >> 16) & 0xFFFF) + ((T >> 32) & 0xFFFF) + ((T >> 48) & 0xFFFF));
     }
-  } else {  // many keyframes / cells: contiguous pair ranges per thread, associations parked in global memory
+    M = Mt;
+    mode = M <= lcap ? 1 : 2;
+    __syncthreads();  // the group totals (and every parked match) are visible
+    unsigned long long base = 0;
+    for (int g = 0; g < ngroups; g++) {
+      const int k0 = 4 * g, nkg = min(4, nk - k0);
+      const unsigned long long T = gt[g];
+      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+      unsigned long long before = base | ((base + t0) << 16) | ((base + t0 + t1) << 32) | ((base + t0 + t1 + t2) << 48);  // where the group's keyframes start
+      for (int b = 0; b * nt < nsrc; b++) {
+        const Assoc4 none = {-1, -1, -1, -1};
+        before += emit_block<KCOST>(scans, src, sh, k0, nkg, nsrc, b, g, true, none, 0, before, mode);
+      }
+      base += t0 + t1 + t2 + t3;
+    }
+    done = true;
+  }
+  if (!done) {  // anything else (thousands of cells per scan): contiguous pair ranges per thread, associations parked in global memory
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
     const int ipt = (pairs + nt - 1) / nt;
     const int p0 = tid * ipt, p1 = min(pairs, p0 + ipt);
@@ -970,9 +997,8 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       cnt += (ti >= 0) ? 1 : 0;
     }
     int o = block_exclusive_scan<CFEAR_REG_BLOCK>(cnt, sh->rw.red_i, &M);
-    // more residual blocks than the LDS array holds (ten keyframes of a dense scene, fifty of any): its capacity stays in LDS, the
-    // rest goes to memory (mode 2, as on the fast path) - every evaluation of a solve reads the matches again
-    const int lcap = match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
+    // more residual blocks than the LDS array holds: its capacity stays in LDS, the rest goes to memory (mode 2, as on the fast
+    // paths) - every evaluation of a solve reads the matches again
     mode = M <= lcap ? 1 : 2;
     for (int p = p0; p < p1; p++) {
       const int ti = sh->rw.assoc[p];

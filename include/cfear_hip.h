@@ -96,7 +96,7 @@ int cfear_synchronize(cfear_ctx* ctx);
  * 9 MB at submap_scan_size 4, k 12, but 280 MB at submap_scan_size 50, k 40 (launch/oxford_demo:62-71) - where real scans have a
  * few hundred to ~1500 cells. A scan that produces more cells than n keeps the first n (ascending voxel index) and the reading
  * calls (poses / covariances / summary / replay_host) return CFEAR_ERR_CAPACITY from then on: never silently.
- * REGISTRATION_ORDER (default 0): batched odometry objects created afterwards hand their sequences to the registration workgroups
+ * REGISTRATION_ORDER (default 1; 0 = in sequence order): batched odometry objects created afterwards hand their sequences to the registration workgroups
  * longest first - sorted on the device by the work each sequence's registration took in the previous sweep - so that the last
  * round of workgroups of a launch is not left to the slowest ones (results do not depend on it). */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
