@@ -1,4 +1,5 @@
-"""Driving-like replay parity (tests/drive_parity.py) with a log of every disagreement: python tests/run_drive_parity.py kind sweeps [out.json]"""
+"""Driving-like replay parity (tests/drive_parity.py) with a log of every disagreement: python tests/run_drive_parity.py kind sweeps [out.json] [preset]
+preset: one of PRESETS below (the reference's large-submap settings, tests/test_large_submap_gpu.py), default = BASELINE configs[1]"""
 import json
 import os
 import sys
@@ -7,17 +8,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (a checker script: it lives in tests/ because it runs the oracle)
 
 
+S10 = dict(k_strongest=40, cost=0, loss=2, loss_limit=0.1, submap_scan_size=10, res=3.0, weight_intensity=1, weight_opt=4, regularization=0.1, covar_scale=1.0)
+PRESETS = {"s10_p2p": S10, "s10_p2d": dict(S10, cost=2), "s50_cfear3": dict(S10, submap_scan_size=50),
+           "s8_p2l": dict(k_strongest=12, cost=1, loss=1, loss_limit=0.1, res=3.0, weight_intensity=0, weight_opt=0, submap_scan_size=8)}
+
+
 def main():
     import numpy as np
     import drive_parity
     from oracle import binding
     kind, T = sys.argv[1], int(sys.argv[2])
     pm = os.environ.get("CFEAR_REPLAY_PERSISTENT_MAX")
+    preset = sys.argv[4] if len(sys.argv) > 4 else None
     out = drive_parity.run(binding, T, kind, log=lambda s: print(s, flush=True), persistent_max=int(pm) if pm else None,
-                           piece=int(os.environ.get("CFEAR_REPLAY_PIECE", "250")))
+                           piece=int(os.environ.get("CFEAR_REPLAY_PIECE", "250")), params=PRESETS[preset] if preset else None)
     reg = drive_parity.regimes(out["motions"])
     bad = sorted(set(m[0] for m in out["mismatches"]))
-    rep = {"kind": kind, "sweeps": T, "disagreeing_sweeps": len(bad), "first": [list(map(str, m)) for m in out["mismatches"][:20]],
+    rep = {"kind": kind, "sweeps": T, "preset": preset or "configs[1]", "keyframes_max": out["keyframes_max"], "disagreeing_sweeps": len(bad), "first": [list(map(str, m)) for m in out["mismatches"][:20]],
            "by_regime": {k: int(np.sum(v[bad])) if bad else 0 for k, v in reg.items()}, "regime_sizes": {k: int(v.sum()) for k, v in reg.items()},
            "cells_median": float(np.median(out["cells"])), "seconds_device": out["seconds_device"], "seconds_oracle": out["seconds_oracle"],
            "sweeps_per_s_device": T / out["seconds_device"], "drift_dev": out["drift_dev"], "drift_cpu": out["drift_cpu"]}

@@ -17,3 +17,9 @@ cd $R; python tools/rocpd_summary.py $(find /tmp/pmc_odo_r -name "*.db" | head -
 # the k sweep (general cloud / feature paths beyond k = 12) and the driving-like replay parity with its replay rate
 cd $R; timeout 600 python tools/gpu_k_sweep.py > $O/${P}_k_sweep.txt 2>&1
 for k in blocks canyon field; do timeout 600 python tests/run_drive_parity.py $k ${DRIVE_SWEEPS:-2000} $O/${P}_drive_$k.json > /dev/null 2>&1; done
+# round 4: the filter by input family (S-uniform / S-world / S-ties) and by phase (stop-variant builds: tools/build_k1_stop_variants.sh, run before gpurun),
+# the large-submap presets on long drives (every sweep against the oracle), the launch-order A/B
+bash $R/tools/pmc_k1_inputs.sh $O/${P}_k1_inputs.txt > /dev/null 2>&1
+[ -f $R/tools/_stop/libcfear_hip_k1stop1.so ] && bash $R/tools/pmc_k1_phases.sh $O/${P}_k1_phases.txt > /dev/null 2>&1
+cd $R; for ps in s10_p2p s10_p2d s50_cfear3; do timeout 900 python tests/run_drive_parity.py canyon ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_canyon_$ps.json $ps > /dev/null 2>&1; done
+bash $R/tools/ab_reg_order.sh $O/${P}_ab_reg_order.txt > /dev/null 2>&1
