@@ -153,24 +153,30 @@ __device__ __forceinline__ int count_mask(const uint4 (&v)[NCH], int T, uint32_t
   return cnt;
 }
 
-// per-lane maximum row byte, re-read from the LDS window (rare fallback: keeps the hot path's
-// register footprint small). v_pk_max_u16 on the odd bytes and on the even bytes << 8.
+// per-lane maximum row byte, from the registers the row is held in (the cold / cluttered-row paths). Only the first chunk group and
+// the group holding the row end can have bytes outside the row; their validity flags (candidate-mask layout: bit 8b + d <-> byte b
+// of dword d) are widened to byte masks - t = the flags of dword d in bit 0 of every byte, (t << 8) - t = 0xFF in every flagged
+// byte - and the rest is v_pk_max_u16 on the odd bytes and on the even bytes << 8. (Until round 4 the row was read back from LDS
+// and every chunk masked by byte ranges: twice the instructions.)
 template <int NCH>
-__device__ __forceinline__ int lane_max_byte_lds(const uint8_t* win, int lane, int head, int R) {
+__device__ __forceinline__ int lane_max_byte_regs(const uint4 (&v)[NCH], uint32_t vhead, int jt, uint32_t vtail) {
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   us2 ao = {0, 0}, ae = {0, 0};
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < NCH; j++) {
-    const int c = j * 64 + lane;
-    uint4 t = reinterpret_cast<const uint4*>(win)[c];
-    const int rlo = head - 16 * c, rhi = head + R - 16 * c;
-    t = chunk_keep(t, rlo > 16 ? 16 : rlo, rhi < 0 ? 0 : rhi);
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    if (j == 0 || j >= jt) {  // (jt is wave-uniform)
+      const uint32_t f = j > jt ? 0u : (j == jt ? vtail : vhead);  // (vtail includes vhead when the row ends in the first group)
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t t = (f >> d) & 0x01010101u;
+        w[d] &= (t << 8) - t;
+      }
+    }
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-      const uint32_t o = w[d], e = w[d] << 8;
-      ao = __builtin_elementwise_max(ao, __builtin_bit_cast(us2, o));
-      ae = __builtin_elementwise_max(ae, __builtin_bit_cast(us2, e));
+      ao = __builtin_elementwise_max(ao, __builtin_bit_cast(us2, w[d]));
+      ae = __builtin_elementwise_max(ae, __builtin_bit_cast(us2, w[d] << 8));
     }
   }
   const int m0 = ao.x >> 8, m1 = ao.y >> 8, m2 = ae.x >> 8, m3 = ae.y >> 8;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     if (cnt < k && lo > Tfloor) {
       // too few: restart from the floor, bounded below by the k-th largest per-lane maximum
       lo = Tfloor;
-      int lm = lane_max_byte_lds<NCH>(win, lane, head, R);
+      int lm = lane_max_byte_regs<NCH>(v, vhead, jt, vtail);
       if (lm < Tfloor) lm = 0;
       int tl = 0, th = 256;
       while (th - tl > 1) {
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
       // far too many (a wave's first row starts from z_min; a cluttered row after a quiet one): jump to the k-th largest per-lane
       // maximum - at least k lanes hold a byte that large, so count(>= it) >= k - instead of bisecting with a full recount per
       // step (eight recounts on uniformly distributed bytes, where ~76 % of the bins pass z_min)
-      int lm = lane_max_byte_lds<NCH>(win, lane, head, R);
+      int lm = lane_max_byte_regs<NCH>(v, vhead, jt, vtail);
       int tl = lo, th = 256;
       while (th - tl > 1) {
         const int mid = (tl + th) >> 1;
