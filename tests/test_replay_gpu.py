@@ -161,3 +161,34 @@ def test_replay_device_is_asynchronous_and_equals_replay_host():
             assert np.array_equal(rec_d[f], rec_h[f]), f
         assert np.array_equal(a.poses(), b.poses())
         ctx.close()
+
+
+def test_rccl_backend_runs_the_throughput_reduction_on_the_device():
+    """The collective of the N-GPU run - {scans: SUM, seconds: MAX} as two 8-byte all-reduces of float64 device tensors over the
+    "nccl" backend (= RCCL on ROCm) - on the one GPU of the test box: a process group of world size 1, the same
+    init_process_group(device_id=...) call, the same dist.reduce_throughput and the all_gather of bench.py's per-rank figures.
+    Everything of the 8-GPU run that does not need a second device."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from cfear_radarodometry_code_public_amd.dist import reduce_throughput, shard_sequences\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "t = torch.tensor([2.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "s = torch.tensor([7.0], dtype=torch.float64, device=dev); dist.all_reduce(s, op=dist.ReduceOp.SUM)\n"
+        "g = [torch.zeros(2, dtype=torch.float64, device=dev)]; dist.all_gather(g, torch.tensor([1.0, 2.0], dtype=torch.float64, device=dev))\n"
+        "dist.barrier(); torch.cuda.synchronize()\n"
+        "assert float(t.item()) == 2.5 and float(s.item()) == 7.0 and g[0].tolist() == [1.0, 2.0]\n"
+        "assert shard_sequences(5, 0, 1) == [0, 1, 2, 3, 4]\n"
+        "print('backend', dist.get_backend(), 'ok')\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "backend nccl ok" in out.stdout
