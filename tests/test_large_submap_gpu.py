@@ -101,6 +101,7 @@ def _batched_parity(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0
     ("s8_p2p", "blocks", 60, dict(SWEEP, cost=0, submap_scan_size=8), "replay"),
     ("s7_p2l", "blocks", 60, dict(SWEEP, cost=1, submap_scan_size=7), "step"),   # the last size of the production instantiations
     ("s50_cfear3", "canyon", 140, S50, "step"),
+    ("s63_p2l", "blocks", 170, dict(SWEEP, cost=1, submap_scan_size=63), "step"),  # the most a sequence keeps (64 scans with the current one): sixteen groups of four keyframes
 ])
 def test_large_submap_batched_route_matches_oracle(oracle, name, kind, sweeps, params, route):
     """batched route: features_step_kernel + register_step_kernel per sweep, three sequences side by side"""
