@@ -123,6 +123,15 @@ int main(int argc, char** argv) {
     w.f64("world3_cells_mean", mean, {n, 2}); w.f64("world3_cells_cov", cov, {n, 3}); w.f64("world3_cells_normal", normal, {n, 2});
     w.f64("world3_cells_lambda_min", lmin, {n}); w.f64("world3_cells_lambda_max", lmax, {n}); w.f64("world3_cells_scale", scale, {n});
     w.i32("world3_cells_nsamples", ns, {n});
+    // which cell the reference's 1-NN search (KdTreeFLANN<PointXY>::nearestKSearch behind GetClosestIdx, pointnormal.cpp:238-254)
+    // returns for a query AT every cell mean: its own index where the float mean is unique, and FLANN's choice among the cells that
+    // share a float mean (1-5 % of a scan's cells: DESIGN.md section 2, [3P] sensitivity) - the one thing that pins the tie order
+    std::vector<int32_t> self(n, -1);
+    for (uint32_t i = 0; i < n; i++) {
+      const std::vector<int> r = map.GetClosestIdx(Eigen::Vector2d(cells[i].u_(0), cells[i].u_(1)), 0.5);
+      self[i] = r.empty() ? -1 : (int32_t)r[0];
+    }
+    w.i32("world3_closest_self", self, {n});
   }
   for (int pass = 0; pass < 2; pass++) {  // offline_odometry.cpp:103-108 with the fixture's parameters
     OdometryKeyframeFuser::Parameters par;

@@ -40,6 +40,25 @@ def test_world_clouds_compensation_and_cells(oracle, ref):
     assert np.allclose(cells["normal"], ref["world3_cells_normal"], atol=1e-7)  # iterative vs closed-form eigenvectors
 
 
+def test_nearest_cell_tie_order(oracle, ref):
+    """GetClosestIdx (pointnormal.cpp:238-254) queried AT every cell mean: its own index where the float mean is unique; among the
+    cells that share a float mean the reference returns FLANN's first visit, the oracle (and the HIP path) the lowest index - the
+    `[3P]` row DESIGN.md section 2 shows is worth up to centimetres per registration. If this fails, the tie rule of
+    cfo_scan_closest / scan_closest has to follow what the file shows."""
+    if "world3_closest_self" not in ref:
+        pytest.skip("ref_golden.npz predates the tie-order dump (oracle/ref_recipe/dump_ref_golden.cpp)")
+    p = oracle.default_params(range_res=RR, res=3.0, weight_intensity=1)
+    s = oracle.Scan(ref["world3_cloud_comp"], p)
+    means = s.cells()["mean"]
+    got = np.array([s.closest(x, y, 0.5) for x, y in means])
+    want = ref["world3_closest_self"]
+    m32 = means.astype(np.float32)
+    _, inv, cnt = np.unique(m32, axis=0, return_inverse=True, return_counts=True)
+    dup = cnt[inv.ravel()] > 1
+    assert np.array_equal(got[~dup], want[~dup]) and np.array_equal(want[~dup], np.arange(len(means))[~dup])
+    assert np.array_equal(got[dup], want[dup]), "FLANN's choice among cells with equal float means: %r, lowest index: %r" % (want[dup].tolist(), got[dup].tolist())
+
+
 @pytest.mark.parametrize("tag,cost", [("p2l", 1), ("p2d", 2)])
 def test_trajectory_and_iteration_counts(oracle, ref, tag, cost):
     kw = dict(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, submap_scan_size=4)
