@@ -221,7 +221,9 @@ class Context:
         self._check(self._L.cfear_synchronize(self._h), "cfear_synchronize")
 
     def tune(self, key, value):
-        """cfear_tune: TUNE_FILTER_OCCUPANCY / TUNE_FILTER_ROWS_PER_WAVE / TUNE_ODOMETRY_OVERLAP (results do not depend on them)"""
+        """cfear_tune (include/cfear_hip.h): launch-shape knobs - TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP,
+        TUNE_FILTER_CUS, TUNE_REPLAY_PERSISTENT_MAX, TUNE_REPEAT_SHORTCUT, TUNE_REGISTRATION_ORDER: results do not depend on them - and
+        TUNE_MAX_CELLS, the cell capacity batched odometry objects created afterwards are sized for (an overflow is reported, never silent)"""
         self._check(self._L.cfear_tune(self._h, int(key), int(value)), "cfear_tune")
 
     # ---- stage 1 ----
