@@ -175,6 +175,7 @@ def _addr(a):
 
 
 TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER = 1, 2, 3, 4, 5, 6, 7, 8
+TUNE_DEFAULTS = {TUNE_ODOMETRY_OVERLAP: 0, TUNE_FILTER_CUS: 0, TUNE_MAX_CELLS: 0, TUNE_REGISTRATION_ORDER: 1}  # include/cfear_hip.h
 
 
 class Context:
@@ -185,6 +186,7 @@ class Context:
         self._h = C.c_void_p()
         self.params = params
         self.A, self.R = int(A), int(R)
+        self._tuned = {}
         rc = self._L.cfear_create(C.byref(self._h), int(device), C.c_void_p(stream or 0), C.byref(params),
                                   self.A, self.R)
         if rc != 0:
@@ -225,6 +227,7 @@ class Context:
         TUNE_FILTER_CUS, TUNE_REPLAY_PERSISTENT_MAX, TUNE_REPEAT_SHORTCUT, TUNE_REGISTRATION_ORDER: results do not depend on them - and
         TUNE_MAX_CELLS, the cell capacity batched odometry objects created afterwards are sized for (an overflow is reported, never silent)"""
         self._check(self._L.cfear_tune(self._h, int(key), int(value)), "cfear_tune")
+        self._tuned[int(key)] = int(value)
 
     # ---- stage 1 ----
     def kstrongest_host(self, polar):
@@ -380,16 +383,20 @@ class Context:
 
     def odometry(self, n_sequences, overlap=None, filter_cus=None, max_cells=None, reg_order=None):
         """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
-        sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams"""
-        if overlap is not None:
-            self.tune(TUNE_ODOMETRY_OVERLAP, int(overlap))
-        if filter_cus is not None:
-            self.tune(TUNE_FILTER_CUS, int(filter_cus))
-        if reg_order is not None:  # registration workgroups longest first (keys: the previous sweep's work)
-            self.tune(TUNE_REGISTRATION_ORDER, int(reg_order))
-        if max_cells is not None:  # oriented surface points per scan the object is sized for (0: every filtered point)
-            self.tune(TUNE_MAX_CELLS, int(max_cells))
-        return Odometry(self, n_sequences)
+        sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams.
+        The keyword settings apply to THIS object only: the context's own cfear_tune values are put back afterwards (an object
+        created later without the keyword does not inherit them)."""
+        want = [(TUNE_ODOMETRY_OVERLAP, overlap), (TUNE_FILTER_CUS, filter_cus), (TUNE_REGISTRATION_ORDER, reg_order), (TUNE_MAX_CELLS, max_cells)]
+        saved = []
+        try:
+            for key, v in want:
+                if v is not None:
+                    saved.append((key, self._tuned.get(key, TUNE_DEFAULTS[key])))
+                    self.tune(key, int(v))
+            return Odometry(self, n_sequences)
+        finally:
+            for key, v in reversed(saved):
+                self.tune(key, v)
 
 
 class Cloud:

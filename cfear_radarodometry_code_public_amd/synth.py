@@ -258,13 +258,15 @@ def _box(ctr, hw, hh, ang):
     return [[cs[i], cs[(i + 1) % 4]] for i in range(4)]
 
 
-DRIVE_KINDS = ("blocks", "canyon", "field")
+DRIVE_KINDS = ("blocks", "canyon", "field", "thicket")
 
 
 class DriveWorld:
     """kind 'blocks': yard with an outer wall and scattered buildings (the family of World, ~200 surface points per sweep);
     'canyon': streets lined with facades (broken by gaps and alcoves), parked boxes and buildings behind them, several
     echoes per azimuth (>= 500 surface points per sweep); 'field': open ground, a few small objects and a far fence
+    'thicket': the canyon's streets through a forest of 1500 small objects, ten equally strong echoes per azimuth - with k = 40 and
+    a small `res` more than a thousand surface points per sweep (the reference's resolution sweep, params/resolution/oxford_cfear-3:16);
     (marginal registrations). render: keyword arguments of render_scan for this family."""
 
     def __init__(self, kind="blocks", seed=0):
@@ -279,11 +281,14 @@ class DriveWorld:
             self.render = dict(hits=2, p_extra=0.5, sigma=2.0)
             n_obj, size, clear = 46, (2.0, 7.5), 6.0
             lim = (W - 8, H - 8)
-        elif kind == "canyon":
+        elif kind in ("canyon", "thicket"):
             self.track = Track(60.0, 40.0, (10.0, 12.0, 10.0, 16.0))
             self.render = dict(hits=5, p_extra=0.85, sigma=1.0, amp_extra=0.7)
             n_obj, size, clear = 320, (1.5, 6.0), 7.0
             lim = (150.0, 130.0)
+            if kind == "thicket":  # the canyon's streets in a forest of small objects, every echo as strong as the first
+                self.render = dict(hits=10, p_extra=1.0, sigma=1.5, amp_extra=0.95)
+                n_obj, size, clear = 1500, (0.4, 1.6), 5.0
         else:
             self.track = Track(70.0, 45.0, (12.0, 25.0, 40.0, 10.0))
             W, H = 150.0, 120.0
@@ -296,7 +301,7 @@ class DriveWorld:
             n_obj, size, clear = 30, (0.6, 2.5), 5.0
             lim = (W - 10, H - 10)
         path = self.track.polyline(1.0)
-        if kind == "canyon":  # facades 9-12 m left and right of the centre line, in pieces of 6-25 m with gaps and set-backs
+        if kind in ("canyon", "thicket"):  # facades 9-12 m left and right of the centre line, in pieces of 6-25 m with gaps and set-backs
             for side in (-1.0, 1.0):
                 s = 0.0
                 while s < self.track.length:

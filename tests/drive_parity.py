@@ -81,3 +81,52 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
                seconds_device=t_dev, seconds_oracle=t_cpu, keyframes_max=int(max(nkfs)) if nkfs else 0,
                drift_dev=kitti.drift(gtk, kitti.poses_from_xyt(dev_poses)), drift_cpu=kitti.drift(gtk, kitti.poses_from_xyt(cpu_poses)))
     return out
+
+
+def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.0595238), persistent_max=0, route="step", max_cells=None, stats=None):
+    """B sequences (different drives) through the batched route - cfear_odometry_step_host, or cfear_odometry_replay_host with the
+    persistent workgroups switched off (two launches per sweep) - against B oracle fusers, every sweep. stats: optional dict that
+    receives the largest cell / residual counts seen (what a test asserts to know which code path it drove)"""
+    kw = dict(BASE, range_res=rr)
+    kw.update(params)
+    fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
+    ctx = capi.Context(capi.default_params(**kw), A, R)
+    ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
+    odo = ctx.odometry(B, max_cells=max_cells)
+    cmax = rmax = 0
+    gens = [synth.drive_chunks(T, kind, 10 + q, 20 + q, A, R, rr, ccw=False) for q in range(B)]
+    frames = np.empty((T, B, A, R), dtype=np.uint8)
+    for q, g in enumerate(gens):
+        for t0, chunk in g:
+            frames[t0:t0 + len(chunk), q] = chunk
+    recs = None
+    if route == "replay":
+        recs = odo.replay_host(frames)
+    kmax = 0
+    for t in range(T):
+        if route == "step":
+            odo.step_host(frames[t])
+            got = odo.poses()
+        for q in range(B):
+            exp = fus[q].process_polar(frames[t, q])
+            So = fus[q].last_summary()
+            no = max(int(So.outer_iterations), 0)
+            e = (int(So.outer_iterations), [int(v) for v in So.inner_iterations[:min(no, 8)]], int(So.num_residuals), int(fus[q].num_keyframes), len(fus[q].last_cells()))
+            if route == "step":
+                S, nc, nk = odo.summary(q)
+                g = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(max(int(S.outer_iterations), 0), 8)]], int(S.num_residuals), nk, nc)
+                pose = got[q]
+            else:
+                r = recs[t, q]
+                g = (int(r["outer_iterations"]), [int(v) for v in r["inner_iterations"][:min(max(int(r["outer_iterations"]), 0), 8)]], int(r["num_residuals"]),
+                     int(r["n_keyframes"]), int(r["n_cells"]))
+                pose = r["pose"]
+            if t > 0:
+                assert g == e, (t, q, g, e)
+            assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
+            kmax = max(kmax, e[3]); cmax = max(cmax, e[4]); rmax = max(rmax, e[2])
+    if stats is not None:
+        stats.update(cells_max=cmax, residuals_max=rmax, keyframes_max=kmax)
+    odo.release()
+    ctx.close()
+    return kmax

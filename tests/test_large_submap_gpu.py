@@ -49,49 +49,7 @@ def test_large_submap_replay_matches_oracle_at_every_sweep(oracle, name, kind, s
         assert out["keyframes_max"] == s
 
 
-def _batched_parity(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.0595238), persistent_max=0, route="step"):
-    """B sequences (different drives) through the batched route - cfear_odometry_step_host, or cfear_odometry_replay_host with the
-    persistent workgroups switched off (two launches per sweep) - against B oracle fusers, every sweep"""
-    kw = dict(drive_parity.BASE, range_res=rr)
-    kw.update(params)
-    fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
-    ctx = capi.Context(capi.default_params(**kw), A, R)
-    ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
-    odo = ctx.odometry(B)
-    gens = [synth.drive_chunks(T, kind, 10 + q, 20 + q, A, R, rr, ccw=False) for q in range(B)]
-    frames = np.empty((T, B, A, R), dtype=np.uint8)
-    for q, g in enumerate(gens):
-        for t0, chunk in g:
-            frames[t0:t0 + len(chunk), q] = chunk
-    recs = None
-    if route == "replay":
-        recs = odo.replay_host(frames)
-    kmax = 0
-    for t in range(T):
-        if route == "step":
-            odo.step_host(frames[t])
-            got = odo.poses()
-        for q in range(B):
-            exp = fus[q].process_polar(frames[t, q])
-            So = fus[q].last_summary()
-            no = max(int(So.outer_iterations), 0)
-            e = (int(So.outer_iterations), [int(v) for v in So.inner_iterations[:min(no, 8)]], int(So.num_residuals), int(fus[q].num_keyframes), len(fus[q].last_cells()))
-            if route == "step":
-                S, nc, nk = odo.summary(q)
-                g = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(max(int(S.outer_iterations), 0), 8)]], int(S.num_residuals), nk, nc)
-                pose = got[q]
-            else:
-                r = recs[t, q]
-                g = (int(r["outer_iterations"]), [int(v) for v in r["inner_iterations"][:min(max(int(r["outer_iterations"]), 0), 8)]], int(r["num_residuals"]),
-                     int(r["n_keyframes"]), int(r["n_cells"]))
-                pose = r["pose"]
-            if t > 0:
-                assert g == e, (t, q, g, e)
-            assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
-            kmax = max(kmax, e[3])
-    odo.release()
-    ctx.close()
-    return kmax
+_batched_parity = drive_parity.run_batched
 
 
 @pytest.mark.parametrize("name,kind,sweeps,params,route", [
@@ -106,7 +64,7 @@ def _batched_parity(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0
 def test_large_submap_batched_route_matches_oracle(oracle, name, kind, sweeps, params, route):
     """batched route: features_step_kernel + register_step_kernel per sweep, three sequences side by side"""
     kmax = _batched_parity(oracle, params, kind, sweeps, route=route)
-    assert kmax == min(params["submap_scan_size"], kmax)  # (the ring never exceeds submap_scan_size)
+    assert kmax <= params["submap_scan_size"]  # the ring never exceeds submap_scan_size
     if sweeps >= 3 * params["submap_scan_size"]:
         assert kmax == params["submap_scan_size"]
 
@@ -182,8 +140,7 @@ def test_max_cells_capacity_is_loud_and_otherwise_invisible():
     odo.reset()  # a reset clears the condition
     odo.release()
     with pytest.raises(capi.CfearError, match=r"rc=-5.*sequences fit.*CFEAR_TUNE_MAX_CELLS"):
-        ctx.tune(capi.TUNE_MAX_CELLS, 0)
-        ctx.odometry(200000)
+        ctx.odometry(200000)  # (sized for every filtered point again: max_cells = 200 above applied to that object only)
     ctx.close()
 
 
