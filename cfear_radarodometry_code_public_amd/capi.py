@@ -27,9 +27,14 @@ class Params(C.Structure):
         ("use_keyframe", C.c_int32),
         ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
         ("max_itr_association", C.c_int32), ("min_itr", C.c_int32),
-        ("max_solver_iterations", C.c_int32), ("reserved0", C.c_int32),
+        ("max_solver_iterations", C.c_int32), ("filter_type", C.c_int32),
         ("assoc_radius", C.c_double),
+        ("cfar_window_size", C.c_int32), ("cfar_nb_guard_cells", C.c_int32), ("cfar_false_alarm_rate", C.c_float), ("cfar_max_points", C.c_int32),
+        ("cfar_max_distance", C.c_double),
     ]
+
+
+FILTER_KSTRONG, FILTER_CACFAR = 0, 1
 
 
 class Cell(C.Structure):
@@ -69,7 +74,7 @@ EXPORTS = [
     "cfear_cloud_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
-    "cfear_odometry_step_device", "cfear_odometry_step_host", "cfear_odometry_poses",
+    "cfear_odometry_step_device", "cfear_odometry_step_cloud_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_replay_host", "cfear_odometry_replay_device", "cfear_host_alloc", "cfear_host_free",
     "cfear_odometry_covariances", "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
@@ -133,6 +138,7 @@ def lib():
         "cfear_odometry_reset": (C.c_int, [vp, vp]),
         "cfear_odometry_step_device": (C.c_int, [vp, vp, u8p]),
         "cfear_odometry_step_host": (C.c_int, [vp, vp, u8p]),
+        "cfear_odometry_step_cloud_device": (C.c_int, [vp, vp, f32p, C.c_int, i32p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_covariances": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
@@ -491,6 +497,11 @@ class Odometry:
     def step_device(self, d_polar):
         self._ctx._check(self._ctx._L.cfear_odometry_step_device(self._ctx._h, self._h, _addr(d_polar)),
                          "cfear_odometry_step_device")
+
+    def step_cloud_device(self, d_xyi, capacity, d_counts):
+        """clouds on the device (raw pointers): [B][capacity][3] floats, [B] int32 counts"""
+        self._ctx._check(self._ctx._L.cfear_odometry_step_cloud_device(self._ctx._h, self._h, C.c_void_p(int(d_xyi)), int(capacity), C.c_void_p(int(d_counts))),
+                         "cfear_odometry_step_cloud_device")
 
     def step_host(self, polar):
         polar = np.ascontiguousarray(polar, dtype=np.uint8)

@@ -33,6 +33,11 @@ void cfear_default_params(cfear_params* p) {
   p->min_itr = 3;               // n_scan_normal.h:75
   p->max_solver_iterations = 20; // n_scan_normal.cpp:9
   p->assoc_radius = 2.0;        // registration.h:122
+  p->filter_type = CFEAR_FILTER_KSTRONG;  // radar_driver.h:48
+  p->cfar_window_size = 10; p->cfar_nb_guard_cells = 20;  // radar_driver.h:43
+  p->cfar_false_alarm_rate = 0.01f;                       // radar_driver.h:44
+  p->cfar_max_distance = 400.0;                           // radar_driver.cpp:54
+  p->cfar_max_points = 0;
 }
 
 static int validate_params(cfear_ctx* ctx, const cfear_params* p) {
@@ -47,6 +52,9 @@ static int validate_params(cfear_ctx* ctx, const cfear_params* p) {
   // the cell-mean grid is sized by assoc_radius (a non-positive or non-finite value would never let the grid fit)
   if (!(p->assoc_radius > 0) || !isfinite(p->assoc_radius)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "assoc_radius must be finite and > 0");
   if (p->max_solver_iterations < 1) return cfear_fail(ctx, CFEAR_ERR_INVALID, "max_solver_iterations must be >= 1");
+  if (p->filter_type != CFEAR_FILTER_KSTRONG && p->filter_type != CFEAR_FILTER_CACFAR) return cfear_fail(ctx, CFEAR_ERR_INVALID, "unknown filter_type");
+  if (p->filter_type == CFEAR_FILTER_CACFAR && (p->cfar_window_size < 1 || p->cfar_nb_guard_cells < 0 || !(p->cfar_false_alarm_rate > 0.f) || p->cfar_max_points < 0))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "CA-CFAR: cfar_window_size >= 1, cfar_nb_guard_cells >= 0, cfar_false_alarm_rate > 0, cfar_max_points >= 0 required");
   if (p->min_itr < 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "min_itr must be >= 0");
   if (!(p->min_distance >= 0.f) || !isfinite(p->min_distance)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "min_distance must be finite and >= 0");
   if (!isfinite(p->z_min) || !isfinite(p->range_res) || !isfinite(p->res) || !isfinite(p->loss_limit))

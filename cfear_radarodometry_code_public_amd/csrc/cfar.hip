@@ -162,6 +162,34 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, long long alloc_bytes, int 
 
 }  // namespace
 
+// the batched filter on `stream` with the caller's row scratch (2 * n_scans * A ints: row counts, row bases): count pass, one row
+// scan per image, emit pass (cfear_filter_cfar_batch_device; the CA-CFAR stage of the batched odometry objects, pipeline.hip)
+__attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
+                                                                  float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts,
+                                                                  int* d_rows, hipStream_t stream) {
+  if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: polar buffer must be 4-byte aligned");
+  if (window_size < 1 || nb_guard_cells < 0 || !(false_alarm_rate > 0.f))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: window_size >= 1, nb_guard_cells >= 0, false_alarm_rate > 0 required");
+  if (ctx->R > CFAR_MAX_R) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: more than 16384 range bins");
+  if ((long long)n_scans * ctx->A > 0x7FFFFFFFLL) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: too many rows");
+  const size_t rows = (size_t)n_scans * ctx->A;
+  CfarParams P;
+  P.A = ctx->A; P.R = ctx->R; P.window = window_size; P.guard = nb_guard_cells;
+  P.range_res = (double)ctx->par.range_res; P.static_threshold = (double)ctx->par.z_min; P.min_distance = (double)ctx->par.min_distance;
+  P.max_distance = max_distance;
+  const double N = (double)(window_size * 2);
+  P.scaling = N * (pow((double)false_alarm_rate, -1. / N) - 1.);
+  int* d_count = d_rows; int* d_base = d_count + rows;
+  const long long alloc = (long long)rows * ctx->R;
+  hipLaunchKernelGGL((cfar_kernel<false>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
+                     (float*)nullptr, 0);
+  hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, d_count, P.A, d_base, d_counts);
+  hipLaunchKernelGGL((cfar_kernel<true>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
+                     d_xyi, capacity);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
 extern "C" {
 
 int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_guard_cells, float false_alarm_rate,
@@ -174,10 +202,6 @@ int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_
 int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
                                    float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts) {
   if (!ctx || !d_polar || !d_xyi || !d_counts || n_scans <= 0 || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: bad argument");
-  if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: polar buffer must be 4-byte aligned");
-  if (window_size < 1 || nb_guard_cells < 0 || !(false_alarm_rate > 0.f))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: window_size >= 1, nb_guard_cells >= 0, false_alarm_rate > 0 required");
-  if (ctx->R > CFAR_MAX_R) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: more than 16384 range bins");
   if ((long long)n_scans * ctx->A > 0x7FFFFFFFLL) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: too many rows");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t rows = (size_t)n_scans * ctx->A;
@@ -187,21 +211,8 @@ int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n
     if (hipMalloc(&ctx->d_cfar_rows, sizeof(int) * 2 * rows) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
     ctx->cfar_rows_cap = 2 * rows;
   }
-  CfarParams P;
-  P.A = ctx->A; P.R = ctx->R; P.window = window_size; P.guard = nb_guard_cells;
-  P.range_res = (double)ctx->par.range_res; P.static_threshold = (double)ctx->par.z_min; P.min_distance = (double)ctx->par.min_distance;
-  P.max_distance = max_distance;
-  const double N = (double)(window_size * 2);
-  P.scaling = N * (pow((double)false_alarm_rate, -1. / N) - 1.);
-  int* d_count = ctx->d_cfar_rows; int* d_base = d_count + rows;
-  const long long alloc = (long long)rows * ctx->R;
-  hipLaunchKernelGGL((cfar_kernel<false>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
-                     (float*)nullptr, 0);
-  hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_counts);
-  hipLaunchKernelGGL((cfar_kernel<true>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
-                     d_xyi, capacity);
-  CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  return CFEAR_OK;
+  return cfear_launch_cfar_batch(ctx, d_polar, n_scans, window_size, nb_guard_cells, false_alarm_rate, max_distance, d_xyi, capacity, d_counts,
+                                 ctx->d_cfar_rows, ctx->stream);
 }
 
 int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, int nb_guard_cells, float false_alarm_rate,

@@ -76,6 +76,11 @@ extern "C" __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx
 // kstrongest.hip
 __attribute__((visibility("hidden"))) int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, uint32_t* d_slots, hipStream_t stream);
 
+// cfar.hip
+__attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
+                                                                  float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts,
+                                                                  int* d_rows /* 2 * n_scans * A ints */, hipStream_t stream);
+
 // scans (keyframes + current) the batched registration kernels of register_step.hip are compiled for: pipeline.hip launches them
 // when submap_scan_size + 1 fits, its own 64-scan instantiation otherwise
 #define CFEAR_STEP_SMALL_SCANS 8

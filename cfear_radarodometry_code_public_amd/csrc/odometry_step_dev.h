@@ -70,7 +70,8 @@ struct OdoParams {
   // seq0 + blockIdx.x), work[q] = what sequence q's registration of THIS sweep cost (evaluations x residual blocks + associations),
   // the key the next sweep's order is sorted by (null: not recorded)
   const int* order; unsigned* work;
-  int* flags;  // one word per odometry object: bit 0 = some scan had more cells than its block holds (CFEAR_ERR_CAPACITY); null: cannot happen
+  int* flags;  // one word per odometry object: bit 0 = some scan had more cells than its block holds, bit 1 = some cloud had more points
+               // than the object is sized for (both CFEAR_ERR_CAPACITY); null: cannot happen
 };
 
 __device__ inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
@@ -144,6 +145,43 @@ __device__ __forceinline__ void features_step_body(unsigned char* lds /* FeatLds
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR, true);  // :161
   if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) atomicOr(OP.flags, 1);  // (thread 0 wrote the status itself)
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
+}
+
+// The same stage from a CLOUD on the device (filter_type CA-CFAR, radar_driver.cpp:52-56, or cfear_odometry_step_cloud_device): sequence
+// q's points are xyi_all + q * cap * 3, min(counts[q], cap) of them. Compensate (odometrykeyframefuser.cpp:146-150, utils.cpp:96-113:
+// atan2 / sin / cos per point as written - a detector's points do not sit on bearing rays the per-bearing table of cloud_step_block
+// could expand around) and MapPointNormal (:161) through the same dispatch as cfear_scan_create: the compact path when the cloud fits
+// it (byte intensities, <= 4864 points), the general path in the sequence's global arrays otherwise.
+__device__ __forceinline__ void features_cloud_step_body(unsigned char* lds /* FeatLdsC::total bytes */, int q, const float* xyi_all, int cap, const int* counts,
+                                                         const OdoParams& OP, const SeqState* states, const BlockScratch* scratch) {
+  const SeqState* st = &states[q];
+  const BlockScratch B = scratch[q];
+  ScanDev* cur = reinterpret_cast<ScanDev*>(OP.scans_base + OP.scan_stride * ((size_t)q * (OP.submap + 1) + st->free_slot));
+  const Aff2 TprevMot = st->Tmot;  // :146
+  if (OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32] = (long long)wall_clock64();
+  int n = counts[q];
+  bool clipped = false;
+  if (n > cap) { n = cap; clipped = true; }
+  if (n > cur->cap_points) { n = cur->cap_points; clipped = true; }
+  if (n < 0) n = 0;
+  if (clipped && OP.flags && threadIdx.x == 0) atomicOr(OP.flags, 2);  // more detections than the object is sized for (cfar_max_points)
+  const float* src = xyi_all + 3 * (size_t)q * cap;
+  int bytes = 1;
+  for (int i = threadIdx.x; i < n; i += BLOCK_F) {
+    const float x = src[3 * i], y = src[3 * i + 1], w = src[3 * i + 2];
+    cur->xyi[3 * i] = x; cur->xyi[3 * i + 1] = y; cur->xyi[3 * i + 2] = w;
+    bytes &= (w >= 0.f && w <= 255.f && w == (float)(int)w) ? 1 : 0;
+  }
+  const bool byte_intensities = __syncthreads_and(bytes) != 0;  // (the barrier also makes the copy visible to the whole block)
+  if (OP.compensate) {
+    double mot[3]; aff_to_xyt(TprevMot, mot);
+    compensate_block(cur->xyi, n, mot[0], mot[1], mot[2], OP.ccw);  // :147 (the peaks cloud of :149 is empty and never read)
+  }
+  PointRegs PR;
+  point_regs_from_global(cur->xyi, n, PR);
+  features_dispatch(cur, n, OP.fp, B, lds, nullptr, nullptr, false, byte_intensities, PR);  // :161
+  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) atomicOr(OP.flags, 1);
+  if (OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 
 template <bool TIMED, int KCOST = -1>

@@ -128,6 +128,12 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
+// the same stage from clouds on the device (filter_type CA-CFAR / cfear_odometry_step_cloud_device)
+__global__ __launch_bounds__(BLOCK_F, 4) void features_cloud_step_kernel(const float* xyi_all, int cap, const int* counts, OdoParams OP,
+                                                                         const SeqState* states, const BlockScratch* scratch) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
+  features_cloud_step_body(lds, OP.seq0 + (int)blockIdx.x, xyi_all, cap, counts, OP, states, scratch);
+}
 // Registration workgroups longest first: sequences ordered by the work their registration took in the previous sweep (a sequence's
 // scene changes slowly), as a counting sort over 256 buckets of the key - one workgroup, a few microseconds. The order inside a
 // bucket is whatever the atomics give: results do not depend on which workgroup slot a sequence takes.
@@ -267,7 +273,7 @@ struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
   int* d_order = nullptr; unsigned* d_work = nullptr;  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): see order_kernel
   bool order_ready = false;  // d_work holds the keys of a registration launch
-  int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells (only allocated when cap_cells < cap_points)
+  int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells, bit 1: a cloud had more points than cap_points (only allocated when either can happen)
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
   ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
   size_t scan_stride = 0;              // bytes between consecutive scan slots of d_scans
@@ -280,6 +286,14 @@ struct cfear_odometry {
   double* d_poses_out = nullptr;
   uint32_t* d_slots[2] = {nullptr, nullptr};  // filter output, double-buffered: the filter runs one sweep ahead
   uint8_t* d_polar = nullptr;  // staging for step_host
+  // filter_type CA-CFAR (radar_driver.cpp:52-56): the filter's output is a cloud per sequence instead of A * k slots
+  int filter = CFEAR_FILTER_KSTRONG;
+  float* d_cloud = nullptr;      // [B][cap_points][3]
+  int* d_cloud_n = nullptr;      // [B] detections per sequence (may exceed cap_points: the cloud keeps the first cap_points)
+  int* d_cfar_rows = nullptr;    // [2][B * A] row counts / row bases of one sweep
+  float* rp_cloud[2] = {nullptr, nullptr};  // replay: clouds of a chunk of sweeps, double-buffered like rp_slots
+  int* rp_cloud_n[2] = {nullptr, nullptr};
+  int* rp_cfar_rows = nullptr;   // [2][chunk * B * A] (the replay stream runs one filter at a time)
   // cfear_odometry_replay_host: chunks of sweeps are copied and filtered on a stream of their own (rp_stream), two chunks
   // in flight (staging + slots double-buffered), while the context stream runs features -> registration sweep after sweep
   hipStream_t rp_stream = nullptr;
@@ -358,6 +372,12 @@ __attribute__((visibility("hidden"))) void cfear_launch_register_step_small(cons
 __attribute__((visibility("hidden"))) void cfear_launch_replay_chunk(const uint32_t* d_slots, int cnt, int B, const double* d_trig, const void* odo_params,
                                                                     void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
                                                                     double* poses_out, cfear_sweep_record* records, hipStream_t stream);
+// ... from the clouds of a chunk ([cnt][B][cap][3] floats, [cnt][B] counts) instead of slots
+__attribute__((visibility("hidden"))) void cfear_launch_replay_chunk_cloud(const float* d_xyi, int cap, const int* d_counts, int cnt, int B, const void* odo_params,
+                                                                          void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
+                                                                          double* poses_out, cfear_sweep_record* records, hipStream_t stream);
+// has the object the shape the context's parameters ask for? (k_strongest / submap_scan_size / the filter cannot change under an object)
+static bool odo_shape_ok(const cfear_ctx* ctx, const cfear_odometry* o);
 
 // the kernel parameters of one odometry step of `o` under the context's current settings
 static OdoParams odo_params(const cfear_ctx* ctx, const cfear_odometry* o) {
@@ -409,6 +429,21 @@ static void odo_launch_sweep(const cfear_ctx* ctx, cfear_odometry* o, const OdoP
     hipLaunchKernelGGL(features_step_kernel<false>, dim3(seq_count), dim3(BLOCK_F), 0, st, d_slots, ctx->d_trig, P, o->d_states,
                        o->d_scan_ptrs, o->d_scratch_hdr);
   launch_register_step(P, seq_count, st, o);
+}
+
+static void odo_launch_sweep_cloud(cfear_odometry* o, const OdoParams& P, const float* d_xyi, int cap, const int* d_counts, int seq_count, hipStream_t st) {
+  hipLaunchKernelGGL(features_cloud_step_kernel, dim3(seq_count), dim3(BLOCK_F), 0, st, d_xyi, cap, d_counts, P, o->d_states, o->d_scratch_hdr);
+  launch_register_step(P, seq_count, st, o);
+}
+static int odo_cfar_points(const cfear_ctx* ctx) { return ctx->par.cfar_max_points > 0 ? ctx->par.cfar_max_points : 32768; }
+static bool odo_shape_ok(const cfear_ctx* ctx, const cfear_odometry* o) {
+  if (o->nslots != ctx->par.submap_scan_size + 1 || o->filter != ctx->par.filter_type) return false;
+  return o->cap_points == (o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest);
+}
+// the CA-CFAR stage of n_scans sweeps (radar_driver.cpp:52-56) into clouds of o->cap_points points each
+static int odo_launch_cfar(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_polar, int n_scans, float* d_xyi, int* d_counts, int* d_rows, hipStream_t st) {
+  return cfear_launch_cfar_batch(ctx, d_polar, n_scans, ctx->par.cfar_window_size, ctx->par.cfar_nb_guard_cells, ctx->par.cfar_false_alarm_rate,
+                                 ctx->par.cfar_max_distance, d_xyi, o->cap_points, d_counts, d_rows, st);
 }
 
 // per-context scratch of the per-call API, sized for up to MAX_SCANS-1 keyframes
@@ -923,7 +958,8 @@ void cfear_odometry_destroy(cfear_ctx* ctx, cfear_odometry* o) {
   }
   void* ptrs[] = {o->d_scans, o->d_scan_ptrs, o->d_scratch, o->d_scratch_hdr, o->d_states, o->d_poses_work, o->d_cov_work,
                   o->d_summaries, o->d_poses_out, o->d_slots[0], o->d_slots[1], o->d_polar, o->d_phase_times,
-                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records, o->d_flags, o->d_order, o->d_work};
+                  o->rp_polar[0], o->rp_polar[1], o->rp_slots[0], o->rp_slots[1], o->d_records, o->d_flags, o->d_order, o->d_work,
+                  o->d_cloud, o->d_cloud_n, o->d_cfar_rows, o->rp_cloud[0], o->rp_cloud[1], o->rp_cloud_n[0], o->rp_cloud_n[1], o->rp_cfar_rows};
   for (hipEvent_t e : {o->rp_filt[0], o->rp_filt[1], o->rp_used[0], o->rp_used[1], o->rp_in}) if (e) (void)hipEventDestroy(e);
   if (o->rp_stream) (void)hipStreamDestroy(o->rp_stream);
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -963,7 +999,8 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   cfear_odometry* o = new (std::nothrow) cfear_odometry();
   if (!o) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "odometry alloc");
   const int B = n_sequences, s = ctx->par.submap_scan_size;
-  o->B = B; o->nslots = s + 1; o->cap_points = ctx->A * ctx->par.k_strongest;
+  o->filter = ctx->par.filter_type;
+  o->B = B; o->nslots = s + 1; o->cap_points = o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest;
   o->cap_cells = ctx->tune_max_cells > 0 ? std::min(ctx->tune_max_cells, o->cap_points) : o->cap_points;
   // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,
   // n_scan_normal.cpp:242,258); the association parks four results per source cell in the same scratch
@@ -994,9 +1031,16 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = ok && hipMalloc(&o->d_cov_work, sizeof(double) * 36 * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_summaries, sizeof(cfear_reg_summary) * (size_t)B) == hipSuccess;
   ok = ok && hipMalloc(&o->d_poses_out, sizeof(double) * 3 * (size_t)B) == hipSuccess;
-  ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
-  ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
-  if (ok && o->cap_cells < o->cap_points) ok = hipMalloc(&o->d_flags, sizeof(int)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int)) == hipSuccess;
+  if (o->filter == CFEAR_FILTER_CACFAR) {
+    ok = ok && hipMalloc(&o->d_cloud, sizeof(float) * 3 * (size_t)B * o->cap_points) == hipSuccess;
+    ok = ok && hipMalloc(&o->d_cloud_n, sizeof(int) * (size_t)B) == hipSuccess;
+    ok = ok && hipMalloc(&o->d_cfar_rows, sizeof(int) * 2 * (size_t)B * ctx->A) == hipSuccess;
+  } else {
+    ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+    ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
+  }
+  // (a sweep's CA-CFAR detections may exceed the points the object holds; cfear_odometry_step_cloud_device allocates the word when first used)
+  if (ok && (o->cap_cells < o->cap_points || o->filter == CFEAR_FILTER_CACFAR)) ok = hipMalloc(&o->d_flags, sizeof(int)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int)) == hipSuccess;
   if (ok && ctx->tune_reg_order && B >= 2)
     ok = hipMalloc(&o->d_order, sizeof(int) * (size_t)B) == hipSuccess && hipMalloc(&o->d_work, sizeof(unsigned) * (size_t)B) == hipSuccess &&
          hipMemset(o->d_work, 0, sizeof(unsigned) * (size_t)B) == hipSuccess;
@@ -1022,6 +1066,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   ok = hipEventCreateWithFlags(&o->ev_copied, hipEventDisableTiming) == hipSuccess;
   o->overlap = ctx->tune_odo_overlap < 0 ? 0 : (ctx->tune_odo_overlap > 8 ? 8 : ctx->tune_odo_overlap);
   if (o->overlap > B) o->overlap = B;
+  if (o->filter == CFEAR_FILTER_CACFAR) o->overlap = 0;  // (the filter-ahead streams are the k-strongest filter's)
   if (ok && o->overlap) {
     int least = 0, greatest = 0;  // numerically lower = higher priority
     ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
@@ -1066,11 +1111,55 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   return CFEAR_OK;
 }
 
+// one sweep of every sequence from clouds on the device, on the context stream
+static int odo_step_clouds(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi, int capacity, const int* d_counts, bool filter_events) {
+  const OdoParams OP = odo_params(ctx, o);
+  int rc = CFEAR_OK;
+  if (o->profile && !filter_events) {  // (keeps filter_events / stage_events paired per step for the profile readers)
+    if ((rc = odo_timed_event(ctx, o, o->filter_events, ctx->stream)) != CFEAR_OK) return rc;
+    if ((rc = odo_timed_event(ctx, o, o->filter_events, ctx->stream)) != CFEAR_OK) return rc;
+  }
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, ctx->stream)) != CFEAR_OK) return rc;
+  hipLaunchKernelGGL(features_cloud_step_kernel, dim3(o->B), dim3(BLOCK_F), 0, ctx->stream, d_xyi, capacity, d_counts, OP, o->d_states, o->d_scratch_hdr);
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, ctx->stream)) != CFEAR_OK) return rc;
+  launch_register_step(OP, o->B, ctx->stream, o);
+  if (o->profile && (rc = odo_timed_event(ctx, o, o->stage_events, ctx->stream)) != CFEAR_OK) return rc;
+  o->step_no++;
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi, int capacity, const int* d_counts) {
+  if (!ctx || !o || !d_xyi || !d_counts || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: bad argument");
+  if (!odo_shape_ok(ctx, o)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: submap_scan_size / k_strongest / filter_type changed after odometry_create");
+  if (capacity > o->cap_points) {
+    char msg[256];
+    snprintf(msg, sizeof(msg), "odometry_step_cloud: capacity %d exceeds the %d points per scan this object was created for (A * k_strongest, or cfar_max_points with "
+             "filter_type CA-CFAR)", capacity, o->cap_points);
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, msg);
+  }
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+  if (!o->d_flags) {  // counts beyond `capacity` are reported like every other truncation
+    CFEAR_HIP_CHECK(ctx, hipMalloc(&o->d_flags, sizeof(int)));
+    CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int), ctx->stream));
+  }
+  return odo_step_clouds(ctx, o, d_xyi, capacity, d_counts, false);
+}
+
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_polar) {
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
-  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest changed after odometry_create");
+  if (!odo_shape_ok(ctx, o))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest / filter_type changed after odometry_create");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (o->filter == CFEAR_FILTER_CACFAR) {  // radar_driver.cpp:52-56, then the cloud route
+    int rc = CFEAR_OK;
+    if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, ctx->stream)) != CFEAR_OK) return rc;
+    rc = odo_launch_cfar(ctx, o, d_polar, o->B, o->d_cloud, o->d_cloud_n, o->d_cfar_rows, ctx->stream);
+    if (rc != CFEAR_OK) return rc;
+    if (o->profile && (rc = odo_timed_event(ctx, o, o->filter_events, ctx->stream)) != CFEAR_OK) return rc;
+    return odo_step_clouds(ctx, o, o->d_cloud, o->cap_points, o->d_cloud_n, true);
+  }
   const OdoParams OP = odo_params(ctx, o);
   const int buf = o->overlap ? (int)(o->step_no & 1) : 0;
   hipStream_t sf = o->overlap ? o->sf : ctx->stream;
@@ -1247,13 +1336,22 @@ static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, bool stag
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(o->rp_stream));
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 2; i++) {
-      if (o->rp_slots[i]) (void)hipFree(o->rp_slots[i]);
-      o->rp_slots[i] = nullptr;
+      for (void** q : {(void**)&o->rp_slots[i], (void**)&o->rp_cloud[i], (void**)&o->rp_cloud_n[i]}) { if (*q) (void)hipFree(*q); *q = nullptr; }
       o->rp_used_pending[i] = false;
     }
+    if (o->rp_cfar_rows) (void)hipFree(o->rp_cfar_rows);
+    o->rp_cfar_rows = nullptr;
     o->rp_chunk = 0;
-    for (int i = 0; i < 2; i++)
-      if (hipMalloc(&o->rp_slots[i], sizeof(uint32_t) * slots * chunk) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay slot buffers");
+    for (int i = 0; i < 2; i++) {
+      if (o->filter == CFEAR_FILTER_CACFAR) {  // a cloud of cap_points points + its count per sweep and sequence
+        if (hipMalloc(&o->rp_cloud[i], sizeof(float) * 3 * slots * chunk) != hipSuccess || hipMalloc(&o->rp_cloud_n[i], sizeof(int) * (size_t)o->B * chunk) != hipSuccess)
+          return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay cloud buffers");
+      } else if (hipMalloc(&o->rp_slots[i], sizeof(uint32_t) * slots * chunk) != hipSuccess) {
+        return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay slot buffers");
+      }
+    }
+    if (o->filter == CFEAR_FILTER_CACFAR && hipMalloc(&o->rp_cfar_rows, sizeof(int) * 2 * (size_t)o->B * ctx->A * chunk) != hipSuccess)
+      return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay cfar rows");
     o->rp_chunk = chunk;
   }
   if (staging && chunk > o->rp_polar_chunk) {
@@ -1285,7 +1383,9 @@ static int replay_impl_queue(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* f
   // chunk: enough sweeps for the filter to run at its streaming rate (>= ~16 k azimuth rows per launch) and for the copy of the
   // next chunk to hide behind the odometry kernels of this one, at most 256 MB per buffer (host route: of staged sweeps; device
   // route: of filter slots - there is no staging)
-  const size_t per_sweep = on_device ? sizeof(uint32_t) * slots : sweep;
+  const bool cfar = o->filter == CFEAR_FILTER_CACFAR;
+  const size_t filt_bytes = cfar ? sizeof(float) * 3 * slots : sizeof(uint32_t) * slots;  // the filter's output per sweep
+  const size_t per_sweep = on_device ? filt_bytes : std::max(sweep, filt_bytes);
   int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)64, ((size_t)256 << 20) / per_sweep));
   chunk = std::min(chunk, n_sweeps);
   {  // buffers of an earlier call may hold more sweeps per chunk: at least as good
@@ -1309,7 +1409,8 @@ static int replay_impl_queue(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* f
       CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(o->rp_polar[b], src, sweep * (size_t)cnt, hipMemcpyHostToDevice, o->rp_stream));
       src = o->rp_polar[b];
     }
-    const int frc = cfear_launch_kstrongest(ctx, src, cnt * o->B, o->rp_slots[b], o->rp_stream);  // radar_driver.cpp:58, pose-independent
+    const int frc = cfar ? odo_launch_cfar(ctx, o, src, cnt * o->B, o->rp_cloud[b], o->rp_cloud_n[b], o->rp_cfar_rows, o->rp_stream)  // radar_driver.cpp:52-56
+                         : cfear_launch_kstrongest(ctx, src, cnt * o->B, o->rp_slots[b], o->rp_stream);  // radar_driver.cpp:58, pose-independent
     if (frc != CFEAR_OK) return frc;
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_filt[b], o->rp_stream));
     return CFEAR_OK;
@@ -1322,13 +1423,17 @@ static int replay_impl_queue(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* f
     // odometrykeyframefuser.cpp:143-259 sweep after sweep. Few sequences: one persistent workgroup per sequence walks the whole
     // chunk (no launch in between; a workgroup needs a compute unit's LDS to itself, so this pays while the sequences fit the
     // chip at one per compute unit). Many sequences: the batched kernels, two launches per sweep, whose occupancy is what counts.
-    if (persistent) {
+    if (persistent && cfar) {
+      cfear_launch_replay_chunk_cloud(o->rp_cloud[b], o->cap_points, o->rp_cloud_n[b], cnt, o->B, &OP, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries,
+                                      o->d_poses_out, d_records ? d_records + (size_t)t0 * o->B : nullptr, ctx->stream);
+    } else if (persistent) {
       cfear_launch_replay_chunk(o->rp_slots[b], cnt, o->B, ctx->d_trig, &OP, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries,
                                 o->d_poses_out, d_records ? d_records + (size_t)t0 * o->B : nullptr, ctx->stream);
     } else {
       for (int t = 0; t < cnt; t++) {
         OP.records = d_records ? d_records + (size_t)(t0 + t) * o->B : nullptr;
-        odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
+        if (cfar) odo_launch_sweep_cloud(o, OP, o->rp_cloud[b] + 3 * slots * (size_t)t, o->cap_points, o->rp_cloud_n[b] + (size_t)o->B * t, o->B, ctx->stream);
+        else odo_launch_sweep(ctx, o, OP, o->rp_slots[b] + slots * (size_t)t, o->B, ctx->stream);
       }
     }
     CFEAR_HIP_CHECK(ctx, hipEventRecord(o->rp_used[b], ctx->stream));
@@ -1354,8 +1459,8 @@ static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames,
 
 static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, int n_sweeps) {
   if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
-  if (o->nslots != ctx->par.submap_scan_size + 1 || o->cap_points != ctx->A * ctx->par.k_strongest)
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest changed after odometry_create");
+  if (!odo_shape_ok(ctx, o))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type changed after odometry_create");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return odo_join(ctx, o);
 }
@@ -1382,6 +1487,13 @@ static int odo_capacity_check(cfear_ctx* ctx, cfear_odometry* o, const char* wha
   if (!o->d_flags) return CFEAR_OK;  // sized for every filtered point: cannot happen
   int f = 0;
   CFEAR_HIP_CHECK(ctx, hipMemcpy(&f, o->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+  if (f & 2) {
+    char msg[320];
+    snprintf(msg, sizeof(msg), "%s: a sweep's cloud had more points than the %d this object is sized for (cfear_params.cfar_max_points with filter_type CA-CFAR; the "
+             "capacity argument of cfear_odometry_step_cloud_device): the first %d in (azimuth, range) order were kept, the results of that sequence are those "
+             "of a truncated cloud", what, o->cap_points, o->cap_points);
+    return cfear_fail(ctx, CFEAR_ERR_CAPACITY, msg);
+  }
   if (f & 1) {
     char msg[256];
     snprintf(msg, sizeof(msg), "%s: a scan produced more than %d oriented surface points (cfear_tune CFEAR_TUNE_MAX_CELLS): its first %d were kept, "

@@ -25,6 +25,10 @@ __device__ __noinline__ void features_stage(unsigned char* lds, int q, const uin
                                             const BlockScratch* scratch) {
   features_step_body<false>(lds, q, slots, trig, *P, states, scratch);
 }
+__device__ __noinline__ void features_cloud_stage(unsigned char* lds, int q, const float* xyi, int cap, const int* counts, const OdoParams* P, const SeqState* states,
+                                                  const BlockScratch* scratch) {
+  features_cloud_step_body(lds, q, xyi, cap, counts, *P, states, scratch);
+}
 __device__ __noinline__ void register_stage(unsigned char* lds, int q, const OdoParams* P, SeqState* states, const BlockScratch* scratch, double* cov_work,
                                             cfear_reg_summary* summaries, double* poses_out) {
   register_step_body<false>(lds, q, *P, states, scratch, cov_work, summaries, poses_out);
@@ -47,7 +51,32 @@ __global__ __launch_bounds__(BLOCK_F) void replay_chunk_kernel(const uint32_t* s
     __syncthreads();  // the state of the sequence (motion, keyframe ring, free slot) is written before the next sweep reads it
   }
 }
+// the same chunk from clouds (filter_type CA-CFAR): [cnt][B][cap][3] floats and [cnt][B] counts
+__global__ __launch_bounds__(BLOCK_F) void replay_chunk_cloud_kernel(const float* xyi_chunk, int cap, const int* counts_chunk, int cnt, int B, OdoParams OP, SeqState* states,
+                                                                     const BlockScratch* scratch, double* cov_work, cfear_reg_summary* summaries, double* poses_out,
+                                                                     cfear_sweep_record* records /*[cnt][B] or null*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kChunkLds];
+  const int q = OP.seq0 + (int)blockIdx.x;
+  __shared__ OdoParams P;
+  if (threadIdx.x == 0) P = OP;
+  for (int t = 0; t < cnt; t++) {
+    if (threadIdx.x == 0) P.records = records ? records + (size_t)t * B : nullptr;
+    __syncthreads();
+    features_cloud_stage(lds, q, xyi_chunk + 3 * (size_t)cap * B * t, cap, counts_chunk + (size_t)B * t, &P, states, scratch);
+    __syncthreads();
+    register_stage(lds, q, &P, states, scratch, cov_work, summaries, poses_out);
+    __syncthreads();
+  }
+}
 }  // namespace
+
+__attribute__((visibility("hidden"))) void cfear_launch_replay_chunk_cloud(const float* d_xyi, int cap, const int* d_counts, int cnt, int B, const void* odo_params,
+                                                                          void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
+                                                                          double* poses_out, cfear_sweep_record* records, hipStream_t stream) {
+  const OdoParams& OP = *static_cast<const OdoParams*>(odo_params);
+  hipLaunchKernelGGL(replay_chunk_cloud_kernel, dim3(B), dim3(BLOCK_F), 0, stream, d_xyi, cap, d_counts, cnt, B, OP, static_cast<SeqState*>(states),
+                     static_cast<const BlockScratch*>(scratch), cov_work, summaries, poses_out, records);
+}
 
 // pipeline.hip (cfear_odometry_replay_host): launches the chunk kernel on `stream`
 __attribute__((visibility("hidden"))) void cfear_launch_replay_chunk(const uint32_t* d_slots, int cnt, int B, const double* d_trig, const void* odo_params,

@@ -83,6 +83,11 @@ int main(int argc, char** argv) {
       q.loss = (int)Str2loss(par.loss_type_); q.loss_limit = par.loss_limit_; q.weight_opt = (int)par.weight_opt;
       q.covar_scale = par.covar_scale_; q.regularization = par.regularization_;
       q.compensate = par.compensate ? 1 : 0; q.radar_ccw = par.radar_ccw ? 1 : 0; q.min_keyframe_dist = par.min_keyframe_dist_;
+      if (rad_par.filter_type_ == filtertype::CACFAR) {  // radar_driver.cpp:52-56 in front of the device fuser
+        q.filter_type = CFEAR_FILTER_CACFAR; q.cfar_window_size = rad_par.window_size; q.cfar_nb_guard_cells = rad_par.nb_guard_cells;
+        q.cfar_false_alarm_rate = rad_par.false_alarm_rate; q.cfar_max_distance = 400.0;
+        q.cfar_max_points = atoi(arg(argc, argv, "--cfar_max_points", "0"));
+      }
       dev->set_params(q);
       cfear_odometry* odo = nullptr;
       dev->check(cfear_odometry_create(dev->ctx(), 1, &odo), "cfear_odometry_create");

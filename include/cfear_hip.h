@@ -32,6 +32,9 @@ enum { CFEAR_COST_P2P = 0, CFEAR_COST_P2L = 1, CFEAR_COST_P2D = 2 };
 enum { CFEAR_LOSS_NONE = 0, CFEAR_LOSS_HUBER = 1, CFEAR_LOSS_CAUCHY = 2, CFEAR_LOSS_SOFTLONE = 3,
        CFEAR_LOSS_COMBINED = 4, CFEAR_LOSS_TUKEY = 5 };
 
+/* radar_driver.h:24 */
+enum { CFEAR_FILTER_KSTRONG = 0, CFEAR_FILTER_CACFAR = 1 };
+
 /* Union of radarDriver::Parameters (radar_driver.h:35-48), OdometryKeyframeFuser::Parameters
  * (odometrykeyframefuser.h:72-114) and the n_scan_normal_reg knobs (n_scan_normal.h:72-81,
  * n_scan_normal.cpp:9, registration.h:117-122) that are on the path. */
@@ -58,8 +61,18 @@ typedef struct cfear_params {
   int32_t max_itr_association; /* n_scan_normal.h:75 (8) */
   int32_t min_itr;             /* n_scan_normal.h:75 (3) */
   int32_t max_solver_iterations; /* n_scan_normal.cpp:9 (20) */
-  int32_t reserved0;
+  int32_t filter_type;         /* CFEAR_FILTER_* (radarDriver::Parameters::filter_type_, radar_driver.h:24,48): the stage-1 filter of the
+                                  batched odometry objects (cfear_odometry_*); the per-call entry points name their filter themselves */
   double assoc_radius;         /* registration.h:122 (2.0) */
+  /* filter_type CA-CFAR (radar_driver.cpp:52-56: AzimuthCACFAR(window_size, false_alarm_rate, nb_guard_cells, range_res, z_min,
+   * min_distance, 400.0)); z_min is the static threshold there, k_strongest is not used */
+  int32_t cfar_window_size;    /* radar_driver.h:43 (10) */
+  int32_t cfar_nb_guard_cells; /* radar_driver.h:43 (20) */
+  float cfar_false_alarm_rate; /* radar_driver.h:44 (0.01) */
+  int32_t cfar_max_points;     /* detections per sweep a batched odometry object is sized for (0 = 32768; a pcl cloud grows, device
+                                  memory is sized up front: a sweep with more detections keeps the first ones in (azimuth, range) order
+                                  and the reading calls fail with CFEAR_ERR_CAPACITY) */
+  double cfar_max_distance;    /* radar_driver.cpp:54 (400.0) */
 } cfear_params;
 
 void cfear_default_params(cfear_params* p);
@@ -242,7 +255,9 @@ int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const
                           int num_residuals, double* cov6, int* success, double* sample_costs);
 
 /* ---- Batched odometry: OdometryKeyframeFuser::pointcloudCallback for B independent sequences ---
- * (odometrykeyframefuser.cpp:143-259, :397-411) with the filter of radar_driver.cpp:48-70 in front.
+ * (odometrykeyframefuser.cpp:143-259, :397-411) with the filter of radar_driver.cpp:48-70 in front: k-strongest, or - with
+ * cfear_params.filter_type = CFEAR_FILTER_CACFAR at creation - azimuth CA-CFAR (radar_driver.cpp:52-56; the peaks cloud stays empty
+ * there and nothing on this path reads it).
  * All state (T_prev, Tmot, keyframe ring) lives on the device; one call = one radar sweep of every
  * sequence. */
 typedef struct cfear_odometry cfear_odometry;
@@ -255,6 +270,13 @@ int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* odo);
  * filter of sweep t+1 beside the features / registration kernels of sweep t) that the context stream joins for the results only
  * in the reading calls below (poses / summary / profile_read / reset) and in cfear_synchronize(). */
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* d_polar);
+/* The same step from clouds that are already on the device instead of polar sweeps - whatever produced them (cfear_filter_cfar_batch_device,
+ * a caller's own detector): sequence q's cloud is d_xyi + q * capacity * 3 (x, y, intensity floats, as cfear_cloud_upload takes them),
+ * its size min(d_counts[q], capacity). What pointcloudCallback does with a cloud follows: Compensate (odometrykeyframefuser.cpp:146-150),
+ * MapPointNormal (:161), Register, keyframe logic. capacity must not exceed the points the object's scans are sized for (A * k_strongest,
+ * or cfar_max_points with filter_type CA-CFAR). Asynchronous on the context stream; d_xyi / d_counts are read by the first kernel only.
+ * With filter_type CA-CFAR, cfear_odometry_step_device / _step_host / _replay_* run AzimuthCACFAR in front of exactly this. */
+int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* odo, const float* d_xyi, int capacity, const int* d_counts);
 /* Same from a host buffer (n_sequences * A * R bytes): the sweeps are copied to a staging buffer on the device; the call
  * returns when that copy has completed (h_polar may be reused or freed at once), the kernels run asynchronously as above. */
 int cfear_odometry_step_host(cfear_ctx* ctx, cfear_odometry* odo, const uint8_t* h_polar);

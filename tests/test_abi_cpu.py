@@ -31,12 +31,17 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_pod_layouts_and_defaults_match_oracle(hip_lib, oracle):
     from cfear_radarodometry_code_public_amd import capi
-    assert C.sizeof(capi.Params) == C.sizeof(oracle.Params) == 128
+    # cfear_params = the oracle's parameter block (the path's settings) + the stage-1 filter choice of the batched objects (filter_type in
+    # the oracle's reserved word, the CA-CFAR knobs behind it: the oracle's detector takes them as arguments)
+    assert C.sizeof(oracle.Params) == 128 and C.sizeof(capi.Params) == 128 + 24
     assert C.sizeof(capi.Cell) == C.sizeof(oracle.Cell) == 120
     assert C.sizeof(capi.RegSummary) == C.sizeof(oracle.RegSummary)
     a, b = capi.default_params(), oracle.default_params()
-    for f, _ in capi.Params._fields_:
-        assert getattr(a, f) == getattr(b, f), f
+    for (f, _), (g, _) in zip(capi.Params._fields_, oracle.Params._fields_):
+        assert getattr(capi.Params, f).offset == getattr(oracle.Params, g).offset
+        assert getattr(a, f) == getattr(b, g), f
+    assert (a.filter_type, a.cfar_window_size, a.cfar_nb_guard_cells, a.cfar_max_distance) == (capi.FILTER_KSTRONG, 10, 20, 400.0)  # radar_driver.h:43-48, radar_driver.cpp:54
+    assert abs(a.cfar_false_alarm_rate - 0.01) < 1e-9
 
 
 def test_no_cpu_fallback(hip_lib):
