@@ -3,12 +3,21 @@
 // min_distance, 400.0).getFilteredPointCloud, cfar.cpp:27-87).
 //
 // Per range bin that passes the static test, the detector compares the squared intensity with a scaled mean of the
-// squared intensities in a trailing and a forwarding window (guard cells in between). One 256-thread workgroup
-// owns one azimuth row: the row is staged in LDS with aligned dword loads, the windows become differences of an
-// LDS prefix sum of squares (integers, exact), and the decision replays the reference's double arithmetic
-// (sum / N per window, (t + f) / 2, scaling * mean, I^2 > threshold; an empty window gives 0/0 = NaN and no
-// detection). The output cloud is row-major over (azimuth, range bin) like the reference's push_back order:
-// pass 1 counts per row, a scan turns the counts into row offsets, pass 2 writes.
+// squared intensities in a trailing and a forwarding window (guard cells in between). Three launches per batch:
+//   cfar_detect_kernel  one 256-thread workgroup per azimuth row: the row is staged in LDS with aligned dword loads, the windows
+//                       become differences of an LDS prefix sum of squares (integers, exact); the image is read ONCE and what comes
+//                       out is a bit per range bin (the row's hit mask) and the row's count;
+//   cfar_row_scan_kernel  row counts -> row offsets of every image (the output cloud is row-major over (azimuth, range bin) like
+//                       the reference's push_back order);
+//   cfar_emit_kernel    one wave per row walks the mask and writes the points (the intensity is a gather of the hit bytes).
+// The decision replays the reference's double arithmetic (sum / N per window, (t + f) / 2, scaling * mean, I^2 > threshold; an empty
+// window gives 0/0 = NaN and no detection) - but only where it has to: with z_min = 20 (the reference's own CA-CFAR preset,
+// params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar:27) nearly every bin passes the static test, and two double divisions per bin made
+// the detector 40 x slower than the whole k-strongest pipeline. For a bin whose two windows are complete the threshold is
+// scaling / (2 w) * (sum of both windows), a u32 times a constant: it is formed in float first (relative error < 2e-7), and only a bin
+// whose I^2 lies within 2e-6 of that threshold - or whose windows are clipped by the row's ends - goes through the reference's
+// expressions in double. The result is the same bit for bit (tests/test_cfar_gpu.py); LDS is sized by the row length (17 KB at 3360
+// bins: nine rows in flight per compute unit instead of one).
 #include <math.h>
 
 #include "blockops.h"
@@ -22,18 +31,36 @@ constexpr int CFAR_MAX_R = 16384;  // range bins per azimuth the LDS row / prefi
 
 struct CfarParams {
   int A, R, window, guard;
-  double range_res, static_threshold, min_distance, max_distance, scaling;
+  int ilo, ihi;     // bins that pass the range test (cfar.cpp:45: range > min_distance && range < max_distance), found on the host with the
+                    // reference's own double expressions: ilo <= i <= ihi
+  int iv_min;       // smallest intensity with (double)I > static_threshold (256: none)
+  int mask_words;   // 32-bit words of a row's hit mask (even: a wave's ballot is two words)
+  int ipt;          // consecutive bins per thread of the prefix pass (odd: conflict-free LDS strides)
+  float kf;         // scaling / (2 w) in float
+  double range_res, scaling;
 };
 
-template <bool EMIT>
-__global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restrict__ polar, long long alloc_bytes, CfarParams P,
-                                                          const double* __restrict__ trig, int* __restrict__ row_count,
-                                                          const int* __restrict__ row_base, float* __restrict__ xyi, int cap) {
-  __shared__ uint32_t prefix[CFAR_MAX_R + 1];                        // prefix[i] = sum of squares of bins < i
-  __shared__ __attribute__((aligned(16))) uint8_t rowbuf[CFAR_MAX_R + 8];
+// the reference's decision as written (cfar.cpp:47-60), windows clipped by the row's ends
+__device__ __noinline__ bool cfar_exact(const uint32_t* prefix, int i, int iv, int R, int guard, int window, double scaling) {
+  const int t0 = max(0, i - guard - window), t1 = i - guard;                           // :48-49
+  const int f0 = i + guard, f1 = min(R, i + guard + window);                           // :52-53
+  const double tn = t1 > t0 ? (double)(t1 - t0) : 0.0, fn = f1 > f0 ? (double)(f1 - f0) : 0.0;
+  const double ts = t1 > t0 ? (double)(prefix[t1] - prefix[t0]) : 0.0;
+  const double fs = f1 > f0 ? (double)(prefix[f1] - prefix[f0]) : 0.0;
+  const double mean = (ts / tn + fs / fn) / 2.0;  // empty window: 0/0 = NaN -> no detection (:56)
+  const double threshold = scaling * mean;
+  return (double)(iv * iv) > threshold;                                                // :58-60
+}
+
+__global__ __launch_bounds__(CFAR_BLOCK) void cfar_detect_kernel(const uint8_t* __restrict__ polar, long long alloc_bytes, CfarParams P,
+                                                                 int* __restrict__ row_count, uint32_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cfar_lds[];  // prefix[R + 1] (prefix[i] = sum of squares of bins < i), then the row's bytes
   __shared__ int red_i[64];
-  // batches: image blockIdx.x / A, azimuth blockIdx.x % A; the images lie back to back, so row blockIdx.x starts at blockIdx.x * R
-  const int grow = blockIdx.x, img = grow / P.A, az = grow - img * P.A, tid = threadIdx.x, R = P.R;
+  const int R = P.R, tid = threadIdx.x;
+  uint32_t* prefix = cfar_lds;
+  uint8_t* rowbuf = reinterpret_cast<uint8_t*>(cfar_lds + (R + 1));
+  // the images lie back to back, so row blockIdx.x starts at blockIdx.x * R
+  const int grow = blockIdx.x;
   // ---- stage the row with aligned dword loads (the bytes around the row belong to the neighbouring rows) ----
   const long long row_off = (long long)grow * R;
   const int first = (int)(row_off & 3);
@@ -43,7 +70,7 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restr
     const long long o = base + 4LL * i;
     uint32_t v;
     if (o + 4 <= alloc_bytes) {
-      v = *reinterpret_cast<const uint32_t*>(polar + o);
+      v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(polar + o));
     } else {  // last dword of the allocation: bytewise
       v = 0;
       for (int b = 0; b < 4; b++)
@@ -54,55 +81,77 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_kernel(const uint8_t* __restr
   __syncthreads();
   const uint8_t* row = rowbuf + first;
   // ---- prefix sum of squares: consecutive bins per thread ----
-  const int ipt = (R + CFAR_BLOCK - 1) / CFAR_BLOCK;
-  const int b0 = tid * ipt, b1 = min(R, b0 + ipt);
   {
+    const int b0 = min(R, tid * P.ipt), b1 = min(R, b0 + P.ipt);
     int s = 0;
     for (int i = b0; i < b1; i++) { const int v = row[i]; s += v * v; }
     int tot;
-    int o = block_exclusive_scan(s, red_i, &tot);
+    int o = block_exclusive_scan<CFAR_BLOCK>(s, red_i, &tot);
     for (int i = b0; i < b1; i++) { prefix[i] = (uint32_t)o; const int v = row[i]; o += v * v; }
     if (tid == 0) prefix[R] = (uint32_t)tot;
     __syncthreads();
   }
-  // ---- detections of this thread's bins (ascending) ----
+  // ---- decisions: thread <-> bin, 64 consecutive bins per wave and trip (the ballot is the mask) ----
+  const int lane = tid & 63, g = P.guard, w = P.window;
+  uint32_t* mrow = mask + (size_t)grow * P.mask_words;
+  int cnt = 0;  // lane 0 of every wave: hits of the wave's trips
+  for (int i0 = (tid >> 6) * 64; i0 < R; i0 += CFAR_BLOCK) {
+    const int i = i0 + lane;
+    const bool in = i < R && i >= P.ilo && i <= P.ihi;
+    const int iv = row[i < R ? i : R - 1];
+    const bool cand = in && iv >= P.iv_min;  // cfar.cpp:45
+    const int t0 = i - g - w, f1 = i + g + w;
+    const bool interior = t0 >= 0 && f1 <= R;  // both windows complete: N = w each
+    bool hit = false, unsure = cand && !interior;
+    if (cand && interior) {
+      const uint32_t S = (prefix[i - g] - prefix[t0]) + (prefix[f1] - prefix[i + g]);
+      const float thr = (float)S * P.kf, I2 = (float)(iv * iv);
+      hit = I2 > thr * 1.000002f;
+      unsure = !hit && I2 >= thr * 0.999998f;
+    }
+    if (unsure) hit = cfar_exact(prefix, i, iv, R, g, w, P.scaling);
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) {
+      mrow[i0 >> 5] = (uint32_t)m; mrow[(i0 >> 5) + 1] = (uint32_t)(m >> 32);
+      cnt += __popcll(m);
+    }
+  }
+  if (lane == 0) red_i[32 + (tid >> 6)] = cnt;
+  __syncthreads();
+  if (tid == 0) row_count[grow] = red_i[32] + red_i[33] + red_i[34] + red_i[35];
+}
+
+// one wave per row: the row's mask -> its points, in range-bin order, at the row's offset of its image's cloud
+__global__ __launch_bounds__(64) void cfar_emit_kernel(const uint8_t* __restrict__ polar, CfarParams P, const double* __restrict__ trig,
+                                                       const int* __restrict__ row_count, const int* __restrict__ row_base,
+                                                       const uint32_t* __restrict__ mask, float* __restrict__ xyi, int cap) {
+  const int grow = blockIdx.x, lane = threadIdx.x;
+  if (row_count[grow] == 0) return;
+  const int img = grow / P.A, az = grow - img * P.A;
+  const uint32_t* mrow = mask + (size_t)grow * P.mask_words;
+  const int wpl = (P.mask_words + 63) >> 6;  // consecutive mask words per lane
+  const int w0 = min(P.mask_words, lane * wpl), w1 = min(P.mask_words, w0 + wpl);
+  int c = 0;
+  for (int k = w0; k < w1; k++) c += __popc(mrow[k]);
+  int o = wave_inclusive_scan(c) - c + row_base[grow];
+  if (c == 0) return;
   const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];  // theta = (az + 1) / A * 2 pi, host libm (cfar.cpp:40)
-  int cnt = 0;
-  unsigned long long hit = 0;  // ipt <= 64 bins per thread (R <= 16384)
-  for (int i = b0; i < b1; i++) {
-    const double range = P.range_res * (double)i;
-    const int iv = row[i];
-    const double intensity = (double)iv;
-    if (range > P.min_distance && range < P.max_distance && intensity > P.static_threshold) {  // cfar.cpp:45
-      const int t0 = max(0, i - P.guard - P.window), t1 = i - P.guard;                           // :48-49
-      const int f0 = i + P.guard, f1 = min(R, i + P.guard + P.window);                           // :52-53
-      const double tn = t1 > t0 ? (double)(t1 - t0) : 0.0, fn = f1 > f0 ? (double)(f1 - f0) : 0.0;
-      const double ts = t1 > t0 ? (double)(prefix[t1] - prefix[t0]) : 0.0;
-      const double fs = f1 > f0 ? (double)(prefix[f1] - prefix[f0]) : 0.0;
-      const double mean = (ts / tn + fs / fn) / 2.0;  // empty window: 0/0 = NaN -> no detection (:56)
-      const double threshold = P.scaling * mean;
-      if ((double)(iv * iv) > threshold) { hit |= 1ull << (i - b0); cnt++; }                     // :58-60
-    }
-  }
-  int total;
-  int o = block_exclusive_scan(cnt, red_i, &total);
-  if (!EMIT) {
-    if (tid == 0) row_count[grow] = total;
-    return;
-  }
-  o += row_base[grow];
+  const uint8_t* row = polar + (long long)grow * P.R;
   xyi += 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
-  while (hit) {
-    const int b = __ffsll((long long)hit) - 1;
-    hit &= hit - 1;
-    const int i = b0 + b;
-    if (o < cap) {
-      const double range = P.range_res * (double)i;
-      xyi[3 * (size_t)o + 0] = (float)(range * cos_t);  // :63-65
-      xyi[3 * (size_t)o + 1] = (float)(range * sin_t);
-      xyi[3 * (size_t)o + 2] = (float)row[i];
+  for (int k = w0; k < w1; k++) {
+    uint32_t m = mrow[k];
+    while (m) {
+      const int b = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int i = 32 * k + b;
+      if (o < cap) {
+        const double range = P.range_res * (double)i;
+        xyi[3 * (size_t)o + 0] = (float)(range * cos_t);  // :63-65
+        xyi[3 * (size_t)o + 1] = (float)(range * sin_t);
+        xyi[3 * (size_t)o + 2] = (float)row[i];
+      }
+      o++;
     }
-    o++;
   }
 }
 
@@ -121,37 +170,67 @@ __global__ __launch_bounds__(1024) void cfar_row_scan_kernel(const int* __restri
   if (threadIdx.x == 0) *d_total = tot;
 }
 
-int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, long long alloc_bytes, int window_size, int nb_guard_cells,
-             float false_alarm_rate, double max_distance, cfear_cloud** out) {
-  if (!out) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: null output");
-  *out = nullptr;
+// kernel parameters from the context's settings: the gates of cfar.cpp:45 as integer bounds (evaluated here with the reference's own
+// double expressions - both are monotone in the bin / the intensity), the CA scaling factor (cfar.cpp:12-16, :32) by host libm
+int cfar_params(cfear_ctx* ctx, int window_size, int nb_guard_cells, float false_alarm_rate, double max_distance, CfarParams* out) {
   if (window_size < 1 || nb_guard_cells < 0 || !(false_alarm_rate > 0.f))
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: window_size >= 1, nb_guard_cells >= 0, false_alarm_rate > 0 required");
   if (ctx->R > CFAR_MAX_R) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar: more than 16384 range bins");
-  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (window_size > (1 << 20) || nb_guard_cells > (1 << 20)) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar: window_size / nb_guard_cells beyond 2^20");
   CfarParams P;
   P.A = ctx->A; P.R = ctx->R; P.window = window_size; P.guard = nb_guard_cells;
   // float members of radarDriver::Parameters bound to const double& (radar_driver.cpp:54)
-  P.range_res = (double)ctx->par.range_res; P.static_threshold = (double)ctx->par.z_min; P.min_distance = (double)ctx->par.min_distance;
-  P.max_distance = max_distance;
-  const double N = (double)(window_size * 2);  // CFARFilter::getCAScalingFactor (cfar.cpp:12-16, :32), host libm
+  P.range_res = (double)ctx->par.range_res;
+  const double static_threshold = (double)ctx->par.z_min, min_distance = (double)ctx->par.min_distance;
+  const double N = (double)(window_size * 2);  // CFARFilter::getCAScalingFactor
   P.scaling = N * (pow((double)false_alarm_rate, -1. / N) - 1.);
-  int* d_tmp = nullptr;  // row counts, row bases, total
-  if (hipMalloc(&d_tmp, sizeof(int) * (2 * (size_t)P.A + 1)) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
+  P.kf = (float)(P.scaling * 0.5 / (double)window_size);
+  P.ilo = P.R; P.ihi = -1;
+  for (int i = 0; i < P.R; i++) {
+    const double range = P.range_res * (double)i;
+    if (range > min_distance && range < max_distance) { if (P.ilo == P.R) P.ilo = i; P.ihi = i; }
+  }
+  P.iv_min = 256;
+  for (int v = 255; v >= 0; v--) if ((double)v > static_threshold) P.iv_min = v;
+  P.mask_words = 2 * ((P.R + 63) / 64);
+  P.ipt = (P.R + CFAR_BLOCK - 1) / CFAR_BLOCK;
+  P.ipt |= 1;
+  *out = P;
+  return CFEAR_OK;
+}
+size_t cfar_lds_bytes(const CfarParams& P) { return sizeof(uint32_t) * (size_t)(P.R + 1) + (size_t)((P.R + 3 + 7) & ~3); }
+int cfar_launch_detect(cfear_ctx* ctx, const CfarParams& P, const uint8_t* d_polar, size_t rows, int* d_count, uint32_t* d_mask, hipStream_t stream) {
+  const size_t lds = cfar_lds_bytes(P);
+  if (lds > 64 * 1024)
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(cfar_detect_kernel, dim3((unsigned)rows), dim3(CFAR_BLOCK), lds, stream, d_polar, (long long)rows * P.R, P, d_count, d_mask);
+  return CFEAR_OK;
+}
+
+int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_guard_cells,
+             float false_alarm_rate, double max_distance, cfear_cloud** out) {
+  if (!out) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: null output");
+  *out = nullptr;
+  CfarParams P;
+  int rc = cfar_params(ctx, window_size, nb_guard_cells, false_alarm_rate, max_distance, &P);
+  if (rc != CFEAR_OK) return rc;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int* d_tmp = nullptr;  // row counts, row bases, total, masks
+  if (hipMalloc(&d_tmp, sizeof(int) * ((2 + (size_t)P.mask_words) * P.A + 1)) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
   int* d_count = d_tmp; int* d_base = d_tmp + P.A; int* d_total = d_tmp + 2 * P.A;
-  hipLaunchKernelGGL((cfar_kernel<false>), dim3(P.A), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc_bytes, P, ctx->d_trig, d_count,
-                     d_base, (float*)nullptr, 0);
+  uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_total + 1);
+  rc = cfar_launch_detect(ctx, P, d_polar, (size_t)P.A, d_count, d_mask, ctx->stream);
+  if (rc != CFEAR_OK) { (void)hipFree(d_tmp); return rc; }
   hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_total);
   int total = 0;
   hipError_t e = hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { (void)hipFree(d_tmp); return cfear_fail(ctx, CFEAR_ERR_HIP, "filter_cfar count pass", e); }
+  if (e != hipSuccess) { (void)hipFree(d_tmp); return cfear_fail(ctx, CFEAR_ERR_HIP, "filter_cfar detect pass", e); }
   cfear_cloud* c = nullptr;
-  int rc = cfear_cloud_alloc(ctx, total, &c);
+  rc = cfear_cloud_alloc(ctx, total, &c);
   if (rc != CFEAR_OK) { (void)hipFree(d_tmp); return rc; }
   if (total > 0)
-    hipLaunchKernelGGL((cfar_kernel<true>), dim3(P.A), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, alloc_bytes, P, ctx->d_trig, d_count,
-                       d_base, c->d_xyi, c->cap);
+    hipLaunchKernelGGL(cfar_emit_kernel, dim3(P.A), dim3(64), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask, c->d_xyi, c->cap);
   e = hipMemcpyAsync(c->d_n, d_total, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_tmp);
@@ -162,30 +241,27 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, long long alloc_bytes, int 
 
 }  // namespace
 
-// the batched filter on `stream` with the caller's row scratch (2 * n_scans * A ints: row counts, row bases): count pass, one row
-// scan per image, emit pass (cfear_filter_cfar_batch_device; the CA-CFAR stage of the batched odometry objects, pipeline.hip)
+// ints of row scratch the batched filter needs for n_scans images: row counts, row bases, hit masks
+__attribute__((visibility("hidden"))) size_t cfear_cfar_scratch_ints(const cfear_ctx* ctx, size_t n_scans) {
+  return n_scans * (size_t)ctx->A * (2 + 2 * (size_t)((ctx->R + 63) / 64));
+}
+// the batched filter on `stream` with the caller's row scratch (cfear_cfar_scratch_ints): detect pass (the only one that reads the
+// images), one row scan per image, emit pass (cfear_filter_cfar_batch_device; the CA-CFAR stage of the batched odometry objects)
 __attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
                                                                   float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts,
                                                                   int* d_rows, hipStream_t stream) {
   if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: polar buffer must be 4-byte aligned");
-  if (window_size < 1 || nb_guard_cells < 0 || !(false_alarm_rate > 0.f))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: window_size >= 1, nb_guard_cells >= 0, false_alarm_rate > 0 required");
-  if (ctx->R > CFAR_MAX_R) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: more than 16384 range bins");
   if ((long long)n_scans * ctx->A > 0x7FFFFFFFLL) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: too many rows");
-  const size_t rows = (size_t)n_scans * ctx->A;
   CfarParams P;
-  P.A = ctx->A; P.R = ctx->R; P.window = window_size; P.guard = nb_guard_cells;
-  P.range_res = (double)ctx->par.range_res; P.static_threshold = (double)ctx->par.z_min; P.min_distance = (double)ctx->par.min_distance;
-  P.max_distance = max_distance;
-  const double N = (double)(window_size * 2);
-  P.scaling = N * (pow((double)false_alarm_rate, -1. / N) - 1.);
+  int rc = cfar_params(ctx, window_size, nb_guard_cells, false_alarm_rate, max_distance, &P);
+  if (rc != CFEAR_OK) return rc;
+  const size_t rows = (size_t)n_scans * ctx->A;
   int* d_count = d_rows; int* d_base = d_count + rows;
-  const long long alloc = (long long)rows * ctx->R;
-  hipLaunchKernelGGL((cfar_kernel<false>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
-                     (float*)nullptr, 0);
+  uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_base + rows);
+  rc = cfar_launch_detect(ctx, P, d_polar, rows, d_count, d_mask, stream);
+  if (rc != CFEAR_OK) return rc;
   hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, d_count, P.A, d_base, d_counts);
-  hipLaunchKernelGGL((cfar_kernel<true>), dim3((unsigned)rows), dim3(CFAR_BLOCK), 0, stream, d_polar, alloc, P, ctx->d_trig, d_count, d_base,
-                     d_xyi, capacity);
+  hipLaunchKernelGGL(cfar_emit_kernel, dim3((unsigned)rows), dim3(64), 0, stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask, d_xyi, capacity);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -196,7 +272,7 @@ int cfear_filter_cfar_device(cfear_ctx* ctx, const uint8_t* d_polar, int window_
                              double max_distance, cfear_cloud** cloud) {
   if (!ctx || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: bad argument");
   if ((reinterpret_cast<uintptr_t>(d_polar) & 3) != 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar: polar buffer must be 4-byte aligned");
-  return cfar_run(ctx, d_polar, (long long)ctx->A * ctx->R, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
+  return cfar_run(ctx, d_polar, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
 }
 
 int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
@@ -204,12 +280,12 @@ int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n
   if (!ctx || !d_polar || !d_xyi || !d_counts || n_scans <= 0 || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "filter_cfar_batch: bad argument");
   if ((long long)n_scans * ctx->A > 0x7FFFFFFFLL) return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar_batch: too many rows");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const size_t rows = (size_t)n_scans * ctx->A;
-  if (2 * rows > ctx->cfar_rows_cap) {  // row counts and row bases of the whole batch
+  const size_t need = cfear_cfar_scratch_ints(ctx, (size_t)n_scans);
+  if (need > ctx->cfar_rows_cap) {  // row counts, row bases and hit masks of the whole batch
     if (ctx->d_cfar_rows) { CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_cfar_rows); }
     ctx->d_cfar_rows = nullptr; ctx->cfar_rows_cap = 0;
-    if (hipMalloc(&ctx->d_cfar_rows, sizeof(int) * 2 * rows) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
-    ctx->cfar_rows_cap = 2 * rows;
+    if (hipMalloc(&ctx->d_cfar_rows, sizeof(int) * need) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
+    ctx->cfar_rows_cap = need;
   }
   return cfear_launch_cfar_batch(ctx, d_polar, n_scans, window_size, nb_guard_cells, false_alarm_rate, max_distance, d_xyi, capacity, d_counts,
                                  ctx->d_cfar_rows, ctx->stream);
@@ -222,7 +298,7 @@ int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, i
   int rc = cfear_ensure_staging(ctx, 1);
   if (rc != CFEAR_OK) return rc;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R, hipMemcpyHostToDevice, ctx->stream));
-  return cfar_run(ctx, ctx->d_polar, (long long)ctx->A * ctx->R, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
+  return cfar_run(ctx, ctx->d_polar, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
 }
 
 }  // extern "C"

@@ -79,7 +79,8 @@ __attribute__((visibility("hidden"))) int cfear_launch_kstrongest(cfear_ctx* ctx
 // cfar.hip
 __attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans, int window_size, int nb_guard_cells,
                                                                   float false_alarm_rate, double max_distance, float* d_xyi, int capacity, int* d_counts,
-                                                                  int* d_rows /* 2 * n_scans * A ints */, hipStream_t stream);
+                                                                  int* d_rows /* cfear_cfar_scratch_ints(ctx, n_scans) ints */, hipStream_t stream);
+__attribute__((visibility("hidden"))) size_t cfear_cfar_scratch_ints(const cfear_ctx* ctx, size_t n_scans);
 
 // scans (keyframes + current) the batched registration kernels of register_step.hip are compiled for: pipeline.hip launches them
 // when submap_scan_size + 1 fits, its own 64-scan instantiation otherwise

@@ -290,10 +290,10 @@ struct cfear_odometry {
   int filter = CFEAR_FILTER_KSTRONG;
   float* d_cloud = nullptr;      // [B][cap_points][3]
   int* d_cloud_n = nullptr;      // [B] detections per sequence (may exceed cap_points: the cloud keeps the first cap_points)
-  int* d_cfar_rows = nullptr;    // [2][B * A] row counts / row bases of one sweep
+  int* d_cfar_rows = nullptr;    // row counts / row bases / hit masks of one sweep (cfear_cfar_scratch_ints)
   float* rp_cloud[2] = {nullptr, nullptr};  // replay: clouds of a chunk of sweeps, double-buffered like rp_slots
   int* rp_cloud_n[2] = {nullptr, nullptr};
-  int* rp_cfar_rows = nullptr;   // [2][chunk * B * A] (the replay stream runs one filter at a time)
+  int* rp_cfar_rows = nullptr;   // ... of a chunk (the replay stream runs one filter at a time)
   // cfear_odometry_replay_host: chunks of sweeps are copied and filtered on a stream of their own (rp_stream), two chunks
   // in flight (staging + slots double-buffered), while the context stream runs features -> registration sweep after sweep
   hipStream_t rp_stream = nullptr;
@@ -1034,7 +1034,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   if (o->filter == CFEAR_FILTER_CACFAR) {
     ok = ok && hipMalloc(&o->d_cloud, sizeof(float) * 3 * (size_t)B * o->cap_points) == hipSuccess;
     ok = ok && hipMalloc(&o->d_cloud_n, sizeof(int) * (size_t)B) == hipSuccess;
-    ok = ok && hipMalloc(&o->d_cfar_rows, sizeof(int) * 2 * (size_t)B * ctx->A) == hipSuccess;
+    ok = ok && hipMalloc(&o->d_cfar_rows, sizeof(int) * cfear_cfar_scratch_ints(ctx, (size_t)B)) == hipSuccess;
   } else {
     ok = ok && hipMalloc(&o->d_slots[0], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
     ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
@@ -1350,7 +1350,7 @@ static int replay_ensure(cfear_ctx* ctx, cfear_odometry* o, int chunk, bool stag
         return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay slot buffers");
       }
     }
-    if (o->filter == CFEAR_FILTER_CACFAR && hipMalloc(&o->rp_cfar_rows, sizeof(int) * 2 * (size_t)o->B * ctx->A * chunk) != hipSuccess)
+    if (o->filter == CFEAR_FILTER_CACFAR && hipMalloc(&o->rp_cfar_rows, sizeof(int) * cfear_cfar_scratch_ints(ctx, (size_t)o->B * chunk)) != hipSuccess)
       return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc replay cfar rows");
     o->rp_chunk = chunk;
   }
