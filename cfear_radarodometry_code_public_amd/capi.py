@@ -180,8 +180,8 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER = 1, 2, 3, 4, 5, 6, 7, 8
-TUNE_DEFAULTS = {TUNE_ODOMETRY_OVERLAP: 0, TUNE_FILTER_CUS: 0, TUNE_MAX_CELLS: 0, TUNE_REGISTRATION_ORDER: 1}  # include/cfear_hip.h
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER, TUNE_LARGE_SUBMAP_KERNEL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+TUNE_DEFAULTS = {TUNE_ODOMETRY_OVERLAP: 0, TUNE_FILTER_CUS: 0, TUNE_MAX_CELLS: 0, TUNE_REGISTRATION_ORDER: 1, TUNE_LARGE_SUBMAP_KERNEL: 0}  # include/cfear_hip.h
 
 
 class Context:
@@ -387,12 +387,13 @@ class Context:
         if self._h:
             self._L.cfear_host_free(self._h, ptr)
 
-    def odometry(self, n_sequences, overlap=None, filter_cus=None, max_cells=None, reg_order=None):
+    def odometry(self, n_sequences, overlap=None, filter_cus=None, max_cells=None, reg_order=None, large_kernel=None):
         """overlap: None = the context's setting; 0 / False = the three kernels in turn on the context stream; n >= 1 = the filter one
         sweep ahead on a low-priority stream, features / registration of n ranges of the sequences on n high-priority streams.
         The keyword settings apply to THIS object only: the context's own cfear_tune values are put back afterwards (an object
         created later without the keyword does not inherit them)."""
-        want = [(TUNE_ODOMETRY_OVERLAP, overlap), (TUNE_FILTER_CUS, filter_cus), (TUNE_REGISTRATION_ORDER, reg_order), (TUNE_MAX_CELLS, max_cells)]
+        want = [(TUNE_ODOMETRY_OVERLAP, overlap), (TUNE_FILTER_CUS, filter_cus), (TUNE_REGISTRATION_ORDER, reg_order), (TUNE_MAX_CELLS, max_cells),
+                (TUNE_LARGE_SUBMAP_KERNEL, large_kernel)]
         saved = []
         try:
             for key, v in want:

@@ -40,7 +40,7 @@ struct BlockScratch {
   int* tmpi;        // [2 * cap_points + 16]
   float* samples;   // [cap_points * 3]
   double* match;    // [8][pair_cap]
-  int* assoc;       // [pair_cap]
+  int* assoc;       // [3 * pair_cap]
   int cap_points, p2cap, pair_cap;
 };
 
@@ -106,7 +106,7 @@ __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char*
   const size_t c = (size_t)B.pair_cap;
   W.tmx = B.match; W.tmy = B.match + c; W.a0 = B.match + 2 * c; W.a1 = B.match + 3 * c; W.a2 = B.match + 4 * c;
   W.sx = B.match + 5 * c; W.sy = B.match + 6 * c; W.w = B.match + 7 * c;
-  W.assoc = B.assoc; W.cap = B.pair_cap;
+  W.assoc = B.assoc; W.cap = B.pair_cap; W.acap = 3 * B.pair_cap;  // (scratch_layout: three ints per pair)
   W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
   W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
   return W;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BLOCK_R, 3) void get_cost_samples_kernel(ScanDev* c
   const size_t c = (size_t)cap;
   double* m = match_base + (size_t)b * 8 * c;
   W.tmx = m; W.tmy = m + c; W.a0 = m + 2 * c; W.a1 = m + 3 * c; W.a2 = m + 4 * c; W.sx = m + 5 * c; W.sy = m + 6 * c; W.w = m + 7 * c;
-  W.assoc = assoc_base + (size_t)b * c; W.cap = cap;
+  W.assoc = assoc_base + (size_t)b * c; W.cap = cap; W.acap = cap;
   W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
   W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
   get_cost_block(sp, n, my_poses, P, W, reinterpret_cast<double*>(lds + RegLds::par), reinterpret_cast<RegShared*>(lds + RegLds::regsh), itr,
@@ -238,7 +238,7 @@ ScratchLayout scratch_layout(int cap_points, int pair_cap) {
   L.tmpi = o; o = align_up(o + sizeof(int) * (2 * (size_t)cap_points + 16), 256);
   L.samples = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
   L.match = o; o = align_up(o + sizeof(double) * 8 * (size_t)pair_cap, 256);
-  L.assoc = o; o = align_up(o + sizeof(int) * (size_t)pair_cap, 256);
+  L.assoc = o; o = align_up(o + sizeof(int) * 3 * (size_t)pair_cap, 256);  // registration_dev.h build_problem_block: six ints per (group of four keyframes, source cell) <= 3 per pair
   L.total = o;
   return L;
 }
@@ -273,6 +273,7 @@ struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
   int* d_order = nullptr; unsigned* d_work = nullptr;  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): see order_kernel
   bool order_ready = false;  // d_work holds the keys of a registration launch
+  int large_kernel = 0, n_cus = 256;  // cfear_tune LARGE_SUBMAP_KERNEL at creation; compute units of the device
   int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells, bit 1: a cloud had more points than cap_points (only allocated when either can happen)
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
   ScanDev** d_scan_ptrs = nullptr;     // [B * nslots]
@@ -369,6 +370,9 @@ static int odo_join(cfear_ctx* ctx, cfear_odometry* o) {
 __attribute__((visibility("hidden"))) void cfear_launch_register_step_small(const void* odo_params, int count, hipStream_t st, void* states, void* const* scan_slots,
                                                                            const void* scratch, double* poses_work, double* cov_work,
                                                                            cfear_reg_summary* summaries, double* poses_out);
+// register_step_large.hip: ... of more scans (submap_scan_size 8 .. 63)
+__attribute__((visibility("hidden"))) void cfear_launch_register_step_large(const void* odo_params, int count, hipStream_t st, void* states, const void* scratch,
+                                                                           double* cov_work, cfear_reg_summary* summaries, double* poses_out);
 __attribute__((visibility("hidden"))) void cfear_launch_replay_chunk(const uint32_t* d_slots, int cnt, int B, const double* d_trig, const void* odo_params,
                                                                     void* states, const void* scratch, double* cov_work, cfear_reg_summary* summaries,
                                                                     double* poses_out, cfear_sweep_record* records, hipStream_t stream);
@@ -409,6 +413,16 @@ static void launch_register_step(const OdoParams& P_in, int count, hipStream_t s
   }
   if (P.submap + 1 <= CFEAR_STEP_SMALL_SCANS) {
     cfear_launch_register_step_small(&P, count, st, o->d_states, reinterpret_cast<void* const*>(o->d_scan_ptrs), o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out);
+    return;
+  }
+  // a larger submap (8 .. 63 keyframes). Few sequences - at most one per compute unit - or a very large submap (>= 24 keyframes):
+  // register_step_large.hip, a unit's threads and LDS for each registration (2 x faster per registration at fifty keyframes); otherwise the
+  // production shape compiled for 64 scans, three workgroups per unit. In aggregate both shapes are bound by the same thing, the vector
+  // instructions of the evaluation and the association (0.7-0.8 of the issue slots at fifty keyframes), so they differ by
+  // < 10 % at 768 sequences and the small shape is the better one at ten keyframes. cfear_tune LARGE_SUBMAP_KERNEL forces either.
+  const bool large = o->large_kernel == 2 || (o->large_kernel == 0 && (count <= o->n_cus || P.submap >= 24));
+  if (large) {
+    cfear_launch_register_step_large(&P, count, st, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries, o->d_poses_out);
     return;
   }
 #define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs, \
@@ -1000,6 +1014,8 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   if (!o) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "odometry alloc");
   const int B = n_sequences, s = ctx->par.submap_scan_size;
   o->filter = ctx->par.filter_type;
+  o->large_kernel = ctx->tune_large_kernel;
+  { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && ncu > 0) o->n_cus = ncu; }
   o->B = B; o->nslots = s + 1; o->cap_points = o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest;
   o->cap_cells = ctx->tune_max_cells > 0 ? std::min(ctx->tune_max_cells, o->cap_points) : o->cap_points;
   // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,

@@ -28,8 +28,10 @@ struct RegScratch {
   double* a0; double* a1; double* a2;  // P2L: (n_x, n_y, -) ; P2D: (l00, l10, l11)
   double* sx; double* sy;    // source mean (local frame)
   double* w;                 // weight after loss
-  int* assoc;                // [pairs] target cell index or -1
-  int cap;                   // capacity in pairs
+  int* assoc;                // [acap] ints: the general path's target cell index per pair; the grouped path's parked matches (four ints per
+                             // (group of four keyframes, source cell)) and, behind them, their positions (two ints each)
+  int cap;                   // capacity of the match arrays in pairs
+  int acap;                  // ints of `assoc`
   double* red;               // LDS, >= 10 * 32 doubles
   int* red_i;                // LDS, >= 64 ints (also used as 32 x u64 scan scratch)
 };
@@ -82,6 +84,26 @@ __device__ __forceinline__ double sqrt_well_scaled(double s) {
   y = y * __builtin_fma(-0.5 * s, y * y, 1.5);
   const double r = s * y;
   return s > 0.0 ? __builtin_fma(0.5 * y, __builtin_fma(-r, r, s), r) : 0.0;
+}
+// natural logarithm of a finite x >= 1 (the Cauchy loss takes log(1 + s / a^2)): x = m 2^e with m in [sqrt(1/2), sqrt(2)), log m =
+// 2 atanh((m - 1) / (m + 1)) by its series in z^2 <= 0.0295 (ten terms: 2e-17), e ln 2 added in two parts. About forty instructions where
+// the library's correctly rounded logarithm takes twice as many (and a thousand residual blocks per keyframe pair evaluate it ~45 times
+// per registration); within an ulp or two of it - the same order as the summation-order differences between this code and the oracle.
+__device__ __forceinline__ double log_ge1(double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double z = div_well_scaled(f, m + 1.0), z2 = z * z;
+  double p = 1.0 / 21.0;
+  p = __builtin_fma(p, z2, 1.0 / 19.0); p = __builtin_fma(p, z2, 1.0 / 17.0); p = __builtin_fma(p, z2, 1.0 / 15.0);
+  p = __builtin_fma(p, z2, 1.0 / 13.0); p = __builtin_fma(p, z2, 1.0 / 11.0); p = __builtin_fma(p, z2, 1.0 / 9.0);
+  p = __builtin_fma(p, z2, 1.0 / 7.0); p = __builtin_fma(p, z2, 1.0 / 5.0); p = __builtin_fma(p, z2, 1.0 / 3.0);
+  const double lm = __builtin_fma(z * z2, p + p, z + z);  // 2 z + 2 z^3 (1/3 + ...)
+  const double ef = (double)e;
+  return __builtin_fma(ef, 6.93147180369123816490e-01, __builtin_fma(ef, 1.90821492927058770002e-10, lm));  // ln 2 = hi + lo
 }
 __device__ inline double get_weight(int opt, double n1, double n2, double sim, double p1, double p2) {  // registration.cpp:67-76
   switch (opt) {
@@ -138,7 +160,10 @@ struct SolveSummary { int num_iterations; int termination; double final_cost; do
                                 // preset of the reference) and spends the 10 KB of LDS that frees on the match array
 #endif
 #define CFEAR_RED_STRIDE 8  // partial sums of up to 8 waves per quantity (W.red)
-#define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers
+#ifndef CFEAR_EVAL_WAVES
+#define CFEAR_EVAL_WAVES 4  // waves that evaluate residuals (one per SIMD); the rest only keep the barriers (register_step_large.hip: all eight of its
+                            // 512-thread workgroups - a fifty-keyframe submap evaluates ~6000 residual blocks ~45 times per registration)
+#endif
 #ifndef CFEAR_REG_BLOCK
 #define CFEAR_REG_BLOCK 256 // threads of every workgroup that runs this code (pipeline.hip BLOCK_R; replay.hip compiles it for 512): a compile-time constant,
                             // because blockDim.x is a load from the dispatch packet - a round trip to memory wherever an
@@ -259,7 +284,10 @@ __device__ __forceinline__ MatchPtrs match_ptrs_lds(int cost) {  // null where t
 // sums in W.red[i * 32 + wave].
 // SRC: where the matches are - 0: the arrays in memory, 1: the LDS array, 2: the first match_lds_cap(COST) of them in the LDS array
 // and the rest in memory (a problem with more residual blocks than the LDS array holds: dense scenes)
-template <int SRC, int COST, bool HUBER>
+// LOSSK: how the loss is evaluated - 1 Huber and 2 Cauchy inline (every preset of the reference uses one of the two), 0 any loss through
+// loss_eval
+enum { CFEAR_LOSSK_ANY = 0, CFEAR_LOSSK_HUBER = 1, CFEAR_LOSSK_CAUCHY = 2 };
+template <int SRC, int COST, int LOSSK>
 __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, double x0, double x1, double c, double s,
                                                    double* res_out, int res_cap) {
   const int wave = threadIdx.x >> 6;
@@ -276,6 +304,7 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
   } rd;
   rd.l = (lds_cdouble*)lds_match_base(); rd.g = ls->rw.tmx; rd.cap = (size_t)ls->rw.cap;
   const double loss_limit = ls->rp.loss_limit;  // parameters through the LDS-typed pointer: ds_read instead of a flat load to wait for
+  const double cauchy_b = loss_limit * loss_limit, cauchy_c = 1.0 / cauchy_b;  // (used by the Cauchy instantiations only)
   const int nthr = min(CFEAR_REG_BLOCK, CFEAR_EVAL_WAVES * 64);
   NormalEq a = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (!res_out) {
@@ -336,12 +365,18 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
       double sq = h.r[0] * h.r[0];
       if (nr == 2) sq += h.r[1] * h.r[1];
       double rho_v, rho_d1;  // rho'' <= 0 for every loss here: the corrector's alpha is 0
-      if (HUBER) {
+      if (LOSSK == CFEAR_LOSSK_HUBER) {
         const double la = loss_limit, lb = la * la;
         const bool out = sq > lb;
         const double rs = rsqrt(out ? sq : 1.0), rt = sq * rs;  // 1 / sqrt(s), sqrt(s)
         rho_v = out ? 2.0 * la * rt - lb : sq;
         rho_d1 = out ? fmax(CFEAR_DBL_MIN, la * rs) : 1.0;
+      } else if (LOSSK == CFEAR_LOSSK_CAUCHY) {
+        // rho = b log(1 + s / b), rho' = 1 / (1 + s / b) (ceres::CauchyLoss): 1 / b once per evaluation, the reciprocal by Newton steps
+        // (the sum is >= 1), the logarithm by log_ge1 - a third of the instructions of the out-of-line general version
+        const double sum = 1.0 + sq * cauchy_c;
+        rho_v = cauchy_b * log_ge1(sum);
+        rho_d1 = fmax(CFEAR_DBL_MIN, div_well_scaled(1.0, sum));
       } else {
         const Rho rho = loss_eval(ls->rp.loss, loss_limit, sq);
         rho_v = rho.v; rho_d1 = rho.d1;
@@ -352,6 +387,17 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     };
     auto add = [&](const Head& h) {
       a.cost += h.cost;
+      if (COST == CFEAR_COST_P2P) {
+        // J = [-1 0 -dtx; 0 -1 -dty] (n_scan_normal.h:336-350): the general loop below multiplies by those zeros and ones (the compiler
+        // may not drop a product with zero) - 36 operations of which these 14 change a sum. Same operations in the same order on the
+        // sums that do change, so the results are the general loop's bit for bit: x * -1 and x + (+-0) are exact.
+        const double nw = -h.w2, j2a = h.w2 * h.J[0][2], j2b = h.w2 * h.J[1][2];
+        a.g0 += nw * h.r[0]; a.g2 += j2a * h.r[0];
+        a.h00 += h.w2; a.h02 += nw * h.J[0][2]; a.h22 += j2a * h.J[0][2];
+        a.g1 += nw * h.r[1]; a.g2 += j2b * h.r[1];
+        a.h11 += h.w2; a.h12 += nw * h.J[1][2]; a.h22 += j2b * h.J[1][2];
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < nr; k++) {
         const double j0 = h.w2 * h.J[k][0], j1 = h.w2 * h.J[k][1], j2 = h.w2 * h.J[k][2];
@@ -414,7 +460,7 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     double sq = r[0] * r[0];
     if (nr == 2) sq += r[1] * r[1];
     Rho rho;
-    if (HUBER) {
+    if (LOSSK == CFEAR_LOSSK_HUBER) {
       const double la = loss_limit, lb = la * la;
       if (sq > lb) { const double r = sqrt(sq); rho.v = 2.0 * la * r - lb; rho.d1 = fmax(CFEAR_DBL_MIN, la / r); }
       else { rho.v = sq; rho.d1 = 1.0; }
@@ -445,12 +491,12 @@ __device__ __forceinline__ void evaluate_partial_t(const LRegShared* ls, int M, 
     if ((lane & 2) == 0) red[(first + 2) * CFEAR_RED_STRIDE + wave] = t[2];
   }
 }
-template <int COST, bool HUBER>
+template <int COST, int LOSSK>
 __device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                 double* res_out, int res_cap) {
-  if (lds_match == 1) evaluate_partial_t<1, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
-  else if (lds_match == 2) evaluate_partial_t<2, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
-  else evaluate_partial_t<0, COST, HUBER>(ls, M, x0, x1, c, s, res_out, res_cap);
+  if (lds_match == 1) evaluate_partial_t<1, COST, LOSSK>(ls, M, x0, x1, c, s, res_out, res_cap);
+  else if (lds_match == 2) evaluate_partial_t<2, COST, LOSSK>(ls, M, x0, x1, c, s, res_out, res_cap);
+  else evaluate_partial_t<0, COST, LOSSK>(ls, M, x0, x1, c, s, res_out, res_cap);
 }
 // KCOST: the cost metric when the kernel is compiled for one (CFEAR_COST_*; the batched registration kernel exists once per cost:
 // no dispatch, and Huber with the matches in LDS - every preset of the reference - evaluates inline whatever the cost), -1: read
@@ -458,32 +504,36 @@ __device__ __noinline__ void evaluate_partial_c(const LRegShared* ls, int M, int
 template <int KCOST = -1>
 __device__ __forceinline__ void evaluate_partial(const LRegShared* ls, int M, int lds_match, double x0, double x1, double c, double s,
                                                  double* res_out = nullptr, int res_cap = 0) {
+  const int loss = ls->rp.loss;
   if (KCOST >= 0) {
     constexpr int KC = KCOST >= 0 ? KCOST : CFEAR_COST_P2L;
-    if (ls->rp.loss == CFEAR_LOSS_HUBER) {
-      if (lds_match == 1 && !res_out) evaluate_partial_t<1, KC, true>(ls, M, x0, x1, c, s, nullptr, 0);
-      else evaluate_partial_c<KC, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    if (loss == CFEAR_LOSS_HUBER) {
+      if (lds_match == 1 && !res_out) evaluate_partial_t<1, KC, CFEAR_LOSSK_HUBER>(ls, M, x0, x1, c, s, nullptr, 0);
+      else evaluate_partial_c<KC, CFEAR_LOSSK_HUBER>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+    } else if (loss == CFEAR_LOSS_CAUCHY && !res_out) {  // (GetCost's residuals keep the general form)
+      evaluate_partial_c<KC, CFEAR_LOSSK_CAUCHY>(ls, M, lds_match, x0, x1, c, s, nullptr, 0);
     } else {
-      evaluate_partial_c<KC, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
+      evaluate_partial_c<KC, CFEAR_LOSSK_ANY>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
     }
     return;
   }
   const int cost = ls->rp.cost;
   // the default configuration (P2L, Huber, matches in LDS) inline in the kernel: out of line, its two interleaved chains reach
   // the callee-saved registers, whose save / restore through scratch is a round trip to memory per evaluation
-  if (ls->rp.loss == CFEAR_LOSS_HUBER && cost == CFEAR_COST_P2L && lds_match == 1 && !res_out) {
-    evaluate_partial_t<1, CFEAR_COST_P2L, true>(ls, M, x0, x1, c, s, nullptr, 0);
+  if (loss == CFEAR_LOSS_HUBER && cost == CFEAR_COST_P2L && lds_match == 1 && !res_out) {
+    evaluate_partial_t<1, CFEAR_COST_P2L, CFEAR_LOSSK_HUBER>(ls, M, x0, x1, c, s, nullptr, 0);
     return;
   }
-  if (ls->rp.loss == CFEAR_LOSS_HUBER) {
-    if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-    else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-    else evaluate_partial_c<CFEAR_COST_P2P, true>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-  } else {
-    if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-    else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-    else evaluate_partial_c<CFEAR_COST_P2P, false>(ls, M, lds_match, x0, x1, c, s, res_out, res_cap);
-  }
+#define CFEAR_EVAL_BY_COST(LK, RO, RC)                                                                                   \
+  do {                                                                                                                  \
+    if (cost == CFEAR_COST_P2L) evaluate_partial_c<CFEAR_COST_P2L, LK>(ls, M, lds_match, x0, x1, c, s, RO, RC);         \
+    else if (cost == CFEAR_COST_P2D) evaluate_partial_c<CFEAR_COST_P2D, LK>(ls, M, lds_match, x0, x1, c, s, RO, RC);    \
+    else evaluate_partial_c<CFEAR_COST_P2P, LK>(ls, M, lds_match, x0, x1, c, s, RO, RC);                                \
+  } while (0)
+  if (loss == CFEAR_LOSS_HUBER) CFEAR_EVAL_BY_COST(CFEAR_LOSSK_HUBER, res_out, res_cap);
+  else if (loss == CFEAR_LOSS_CAUCHY && !res_out) CFEAR_EVAL_BY_COST(CFEAR_LOSSK_CAUCHY, nullptr, 0);
+  else CFEAR_EVAL_BY_COST(CFEAR_LOSSK_ANY, res_out, res_cap);
+#undef CFEAR_EVAL_BY_COST
 }
 
 // W.red is an LDS array: reading it through an LDS-typed pointer gives independent ds_read instructions; through the
@@ -934,6 +984,15 @@ __device__ __noinline__ unsigned long long emit_block(ScanDev* const* scans, con
   return tb;
 }
 
+// the residual blocks of one (group of four keyframes, source cell) item of the grouped path; out of line like emit_block (inlined, the
+// emission's registers are the kernel's)
+template <int KCOST = -1>
+__device__ __noinline__ void emit_item(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nsrc, int k0, int nk, int j, int4 v,
+                                       unsigned long long pos, int mode) {
+  const Assoc4 a = {v.x, v.y, v.z, v.w};
+  emit_cell<KCOST>(scans, src, sh, nsrc, k0, nk, j, a, pos, mode);
+}
+
 template <int KCOST = -1>
 __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n, LRegShared* sh, int itr) {
   const ScanDev* src = scans[n - 1];
@@ -945,7 +1004,8 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   const int nk = n - 1;
   const int ngroups = (nk + 3) >> 2;
   const int lcap = match_lds_cap(KCOST >= 0 ? KCOST : sh->rp.cost);
-  const bool can_park = 4 * (long long)ngroups * nsrc <= (long long)sh->rw.cap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
+  // the grouped path parks four ints + two ints of positions per (group, source cell) in W.assoc
+  const bool can_park = 6 * (long long)ngroups * nsrc <= (long long)sh->rw.acap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
   bool done = false;
   if (nk <= 4 && nsrc <= nt) {  // one group of keyframes, one block of cells: the matches stay in registers
     const AssocBlock R = assoc_block(src, sh, 0, nk, nsrc, itr, 0, 0, false);
@@ -955,34 +1015,62 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
     mode = M <= lcap ? 1 : 2;
     (void)emit_block<KCOST>(scans, src, sh, 0, nk, nsrc, 0, 0, false, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
     done = true;
-  } else if (nsrc <= 4 * nt && can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
+  } else if (can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
     // several blocks of cells and / or several groups of four keyframes (a submap of 5 .. 63 keyframes: the reference's s10 and s50
-    // presets): every (group, block) is searched with the four-keyframes-at-once association and parked; the residual blocks are
-    // numbered as the reference does - pair index keyframe * nsrc + cell ascending - from the per-keyframe totals (16-bit fields:
-    // at most 65535 residual blocks)
-    unsigned long long* gt = reinterpret_cast<unsigned long long*>(sh->rw.red_i);  // totals of up to 16 groups (the general path's scan scratch: free here)
-    int Mt = 0;
-    for (int g = 0; g < ngroups; g++) {
-      const int k0 = 4 * g, nkg = min(4, nk - k0);
-      unsigned long long T = 0;
-      for (int b = 0; b * nt < nsrc; b++) T += assoc_block(src, sh, k0, nkg, nsrc, itr, b, g, true).tb;  // every field <= nsrc <= 4 * blockDim
-      if (tid == 0) gt[g] = T;
-      Mt += (int)((T & 0xFFFF) + ((T >> 16) & 0xFFFF) + ((T >> 32) & 0xFFFF) + ((T >> 48) & 0xFFFF));
+    // presets; a dense scan against four): the items (group g of four keyframes, source cell j), numbered g * nsrc + j, are dealt to
+    // the threads DENSELY - with 172 source cells and 13 groups a 512-thread workgroup makes 5 passes where group after group it made
+    // 13, each a chain of dependent memory round trips. A pass searches with the four-keyframes-at-once association and parks the
+    // matches; then one wave per group counts (ballots, no barrier) and leaves every item's position inside its keyframes; the residual
+    // blocks are numbered as the reference does - pair index keyframe * nsrc + cell ascending - from the per-keyframe totals (16-bit
+    // fields: at most 65535 residual blocks); the emission walks the items densely again.
+    const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
+    const int nitems = ngroups * nsrc;
+    int4* park = reinterpret_cast<int4*>(sh->rw.assoc);
+    unsigned long long* ppos = reinterpret_cast<unsigned long long*>(sh->rw.assoc + 4 * (size_t)nitems);  // (16-byte aligned base + 16 * nitems: 8-byte aligned)
+    unsigned long long* gt = reinterpret_cast<unsigned long long*>(sh->rw.red_i);  // [0..15] totals per group, [16..31] where a group's keyframes start
+    for (int it = tid; it < nitems; it += nt) {
+      const int g = it / nsrc, j = it - g * nsrc;
+      const Assoc4 a = associate_cell(src, sh, 4 * g, min(4, nk - 4 * g), j, curr_radius);
+      park[it] = make_int4(a.t0, a.t1, a.t2, a.t3);
     }
-    M = Mt;
-    mode = M <= lcap ? 1 : 2;
-    __syncthreads();  // the group totals (and every parked match) are visible
-    unsigned long long base = 0;
-    for (int g = 0; g < ngroups; g++) {
-      const int k0 = 4 * g, nkg = min(4, nk - k0);
-      const unsigned long long T = gt[g];
-      const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
-      unsigned long long before = base | ((base + t0) << 16) | ((base + t0 + t1) << 32) | ((base + t0 + t1 + t2) << 48);  // where the group's keyframes start
-      for (int b = 0; b * nt < nsrc; b++) {
-        const Assoc4 none = {-1, -1, -1, -1};
-        before += emit_block<KCOST>(scans, src, sh, k0, nkg, nsrc, b, g, true, none, 0, before, mode);
+    __syncthreads();  // every parked match is visible
+    {  // wave w counts the groups w, w + waves, ...: positions of a group's matches per keyframe, in cell order
+      const int lane = lane_id(), wv = tid >> 6, nwv = nt >> 6;
+      for (int g = wv; g < ngroups; g += nwv) {
+        unsigned long long run = 0;  // matches so far per keyframe, 16-bit fields
+        for (int j0 = 0; j0 < nsrc; j0 += 64) {
+          const int j = j0 + lane;
+          const bool in = j < nsrc;
+          const int4 v = in ? park[(size_t)g * nsrc + j] : make_int4(-1, -1, -1, -1);
+          const unsigned long long b0 = __ballot(v.x >= 0), b1 = __ballot(v.y >= 0), b2 = __ballot(v.z >= 0), b3 = __ballot(v.w >= 0);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          const unsigned long long e = (unsigned long long)__popcll(b0 & below) | ((unsigned long long)__popcll(b1 & below) << 16) |
+                                       ((unsigned long long)__popcll(b2 & below) << 32) | ((unsigned long long)__popcll(b3 & below) << 48);
+          if (in) ppos[(size_t)g * nsrc + j] = run + e;
+          run += (unsigned long long)__popcll(b0) | ((unsigned long long)__popcll(b1) << 16) | ((unsigned long long)__popcll(b2) << 32) |
+                 ((unsigned long long)__popcll(b3) << 48);
+        }
+        if (lane == 0) gt[g] = run;
       }
-      base += t0 + t1 + t2 + t3;
+    }
+    __syncthreads();
+    if (tid == 0) {  // where the keyframes of every group start (a handful of groups: serial)
+      unsigned long long base = 0;
+      for (int g = 0; g < ngroups; g++) {
+        const unsigned long long T = gt[g];
+        const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
+        gt[16 + g] = base | ((base + t0) << 16) | ((base + t0 + t1) << 32) | ((base + t0 + t1 + t2) << 48);
+        base += t0 + t1 + t2 + t3;
+      }
+      gt[0] = base;  // (the totals have been consumed)
+    }
+    __syncthreads();
+    M = (int)gt[0];
+    mode = M <= lcap ? 1 : 2;
+    for (int it = tid; it < nitems; it += nt) {
+      const int g = it / nsrc, j = it - g * nsrc;
+      const int4 v = park[it];
+      if (v.x >= 0 || v.y >= 0 || v.z >= 0 || v.w >= 0) emit_item<KCOST>(scans, src, sh, nsrc, 4 * g, min(4, nk - 4 * g), j, v, gt[16 + g] + ppos[it], mode);
     }
     done = true;
   }

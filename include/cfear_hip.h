@@ -111,10 +111,14 @@ int cfear_synchronize(cfear_ctx* ctx);
  * calls (poses / covariances / summary / replay_host) return CFEAR_ERR_CAPACITY from then on: never silently.
  * REGISTRATION_ORDER (default 1; 0 = in sequence order): batched odometry objects created afterwards hand their sequences to the registration workgroups
  * longest first - sorted on the device by the work each sequence's registration took in the previous sweep - so that the last
- * round of workgroups of a launch is not left to the slowest ones (results do not depend on it). */
+ * round of workgroups of a launch is not left to the slowest ones (results do not depend on it).
+ * LARGE_SUBMAP_KERNEL (default 0): with submap_scan_size > 7 the batched step has two registration kernels - the production shape compiled for
+ * 64 scans (256 threads, three workgroups per compute unit) and one that gives a registration a whole unit (512 threads, all of its LDS for
+ * the residual blocks, every wave evaluating: 2 x faster per registration at fifty keyframes). 0 = the second when the sequences fit the
+ * chip at one per unit or the submap has 24 keyframes or more, 1 = always the first, 2 = always the second. Poses agree to the summation order of the evaluation's partial sums. */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
        CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6, CFEAR_TUNE_MAX_CELLS = 7,
-       CFEAR_TUNE_REGISTRATION_ORDER = 8 };
+       CFEAR_TUNE_REGISTRATION_ORDER = 8, CFEAR_TUNE_LARGE_SUBMAP_KERNEL = 9 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

@@ -17,13 +17,22 @@ def main(db, out=None):
             q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
                  "group by kernel_name, counter_name order by kernel_name")
             pmc = list(c.execute(q))
+            import os
+            last = int(os.environ.get("ROCPD_LAST", "0"))  # average over the last N dispatches of every kernel only (a warm-up in front)
+            if last:
+                from collections import defaultdict
+                acc = defaultdict(list)
+                key = next((x for x in ("dispatch_id", "start", "id", "event_id") if x in cols), None)
+                for k, n, v in c.execute("select kernel_name, counter_name, value from counters_collection" + (" order by " + key if key else "")):
+                    acc[(k, n)].append(v)
+                pmc = [(k, n, sum(v[-last:]) / len(v[-last:]), len(v[-last:])) for (k, n), v in sorted(acc.items())]
             if pmc:
                 lines += ["", "| kernel | counter | avg per dispatch | dispatches |", "|---|---|---|---|"]
                 for k, n, v, cnt in pmc:
                     short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                     lines.append("| %s | %s | %.6g | %d |" % (short, n, v, cnt))
-    except sqlite3.Error:
-        pass
+    except sqlite3.Error as e:
+        lines.append("(counters: %s)" % e)
     txt = "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(txt)
