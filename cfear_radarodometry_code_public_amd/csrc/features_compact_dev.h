@@ -457,6 +457,7 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
+    const bool keep_cells = S->cells != nullptr;
     const int NE = listed ? NA : nv;
     for (int a0 = 0, round = 0; a0 < NE; a0 += nt, round++) {  // rounds over the active (or all) samples, in sample order
       const int ai = a0 + tid;
@@ -509,11 +510,15 @@ __device__ __forceinline__ bool features_block_c(ScanDev* __restrict__ S, int n,
         typedef __attribute__((address_space(1))) cfear_cell g_cell;
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(1))) f64x2 g_f64x2;
-        g_cell* gc = (g_cell*)S->cells + o;
-        gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
-        gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
-        gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
-        gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        if (keep_cells) {  // (block-uniform)
+          g_cell* gc = (g_cell*)S->cells + o;
+          gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
+          gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
+          gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
+          gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        }
+        g_f64* rc = (g_f64*)S->rcov + 3 * (size_t)o;
+        rc[0] = c.cov[0]; rc[1] = c.cov[1]; rc[2] = c.cov[2];
         g_f32* mf = (g_f32*)S->mean_f;
         mf[2 * o] = (float)c.mean[0];
         mf[2 * o + 1] = (float)c.mean[1];

@@ -22,7 +22,8 @@ struct ScanDev {
   int gw, gh;
   int cap_points, cap_cells, cap_grid;
   float* xyi;         // [cap_points][3]
-  cfear_cell* cells;  // [cap_cells]
+  cfear_cell* cells;  // [cap_cells], or null: the scans of a batched odometry object do not keep the 120-byte records - nothing on the path reads
+                      // them (the registration reads rsrc / rtar / rcov, the search gpts): 24 KB per scan that were written for nobody
   float* mean_f;      // [cap_cells][2]  (downsampled_, pointnormal.cpp:151-158)
   int* gstart;        // [cap_grid + 4] 32-bit bucket offsets (scans of more than CFEAR_GRID16_MAX cells), followed by the 16-bit offsets (grid_off16)
   float4* gpts;       // [cap_cells] (mean x, mean y, cell index bits, 0) in bucket order: the 1-NN scan reads contiguously
@@ -30,6 +31,7 @@ struct ScanDev {
   // so the fields it needs are packed): mean x, mean y, normal x, normal y, nsamples, scale
   double* rsrc;       // [6][cap_cells] SoA: read with consecutive cell indices when the scan is the source
   double* rtar;       // [cap_cells][8] 64-byte records: read at random cell indices when the scan is a target
+  double* rcov;       // [cap_cells][3] covariance xx, xy, yy: what the P2D cost reads of a target cell besides its rtar record (n_scan_normal.cpp:290-299)
 };
 #define CFEAR_GRID_CAP (128 * 128)  // buckets per scan (ScanDev::cap_grid)
 // Scans of up to CFEAR_GRID16_MAX cells (every scan the odometry builds) keep their bucket offsets as 16-bit values in the
@@ -836,6 +838,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
   {
     int base = 0;
     const int cap_cells = S->cap_cells;
+    const bool keep_cells = S->cells != nullptr;
     for (int v0 = 0; v0 < nv; v0 += nt) {
       const int v = v0 + tid;
       cfear_cell c;
@@ -885,11 +888,15 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
         typedef __attribute__((address_space(1))) cfear_cell g_cell;
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(1))) f64x2 g_f64x2;
-        g_cell* gc = (g_cell*)S->cells + o;
-        gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
-        gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
-        gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
-        gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        if (keep_cells) {  // (block-uniform)
+          g_cell* gc = (g_cell*)S->cells + o;
+          gc->mean[0] = c.mean[0]; gc->mean[1] = c.mean[1]; gc->cov[0] = c.cov[0]; gc->cov[1] = c.cov[1]; gc->cov[2] = c.cov[2];
+          gc->normal[0] = c.normal[0]; gc->normal[1] = c.normal[1]; gc->orth[0] = c.orth[0]; gc->orth[1] = c.orth[1];
+          gc->lambda_min = c.lambda_min; gc->lambda_max = c.lambda_max; gc->scale = c.scale;
+          gc->sum_intensity = c.sum_intensity; gc->avg_intensity = c.avg_intensity; gc->nsamples = c.nsamples; gc->valid = c.valid;
+        }
+        g_f64* rc = (g_f64*)S->rcov + 3 * (size_t)o;
+        rc[0] = c.cov[0]; rc[1] = c.cov[1]; rc[2] = c.cov[2];
         g_f32* mf = (g_f32*)S->mean_f;
         mf[2 * o] = (float)c.mean[0];
         mf[2 * o + 1] = (float)c.mean[1];

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(BLOCK_F) void scan_from_cells_kernel(ScanDev* S, in
     rs[0] = c.mean[0]; rs[cc] = c.mean[1]; rs[2 * cc] = c.normal[0]; rs[3 * cc] = c.normal[1]; rs[4 * cc] = (double)c.nsamples; rs[5 * cc] = c.scale;
     double* rt = S->rtar + 8 * (size_t)i;
     rt[0] = c.mean[0]; rt[1] = c.mean[1]; rt[2] = c.normal[0]; rt[3] = c.normal[1]; rt[4] = (double)c.nsamples; rt[5] = c.scale;
+    double* rc = S->rcov + 3 * (size_t)i;
+    rc[0] = c.cov[0]; rc[1] = c.cov[1]; rc[2] = c.cov[2];
   }
   if (threadIdx.x == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = n; S->status = n > 0 ? 0 : CFEAR_ERR_EMPTY; }
   __syncthreads();
@@ -185,31 +187,34 @@ RegParams reg_params(const cfear_ctx* ctx) {
 
 constexpr int GRID_CAP = CFEAR_GRID_CAP;
 
-struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, total; };
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, rcov, total; };
 // cap_cells <= cap_points: cells a scan can hold (every cell is the centroid neighbourhood of an occupied voxel, so never more than
-// points; the batched odometry may be sized for fewer: cfear_tune MAX_CELLS)
-ScanLayout scan_layout(int cap_points, int cap_cells) {
+// points; the batched odometry may be sized for fewer: cfear_tune MAX_CELLS). with_cells: the 120-byte cfear_cell records exist (the
+// per-call scans, whose cells can be downloaded); the scans of the batched odometry objects go without
+ScanLayout scan_layout(int cap_points, int cap_cells, bool with_cells = true) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
-  L.cells = o; o = align_up(o + sizeof(cfear_cell) * (size_t)cap_cells, 256);
+  L.cells = o; if (with_cells) o = align_up(o + sizeof(cfear_cell) * (size_t)cap_cells, 256);
   L.mean_f = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_cells, 256);
   L.gstart = o; o = align_up(o + (sizeof(int) + sizeof(uint2)) * (GRID_CAP + 4), 256);  // 32-bit offsets + the region of the 16-bit ones (grid_off16)
   L.gpts = o; o = align_up(o + sizeof(float4) * (size_t)cap_cells, 256);
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_cells, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_cells, 256);
+  L.rcov = o; o = align_up(o + sizeof(double) * 3 * (size_t)cap_cells, 256);
   L.total = o;
   return L;
 }
 // writes a ScanDev header for a flat device block at d_base
-ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells) {
-  const ScanLayout L = scan_layout(cap_points, cap_cells);
+ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells, bool with_cells = true) {
+  const ScanLayout L = scan_layout(cap_points, cap_cells, with_cells);
   ScanDev h;
   memset(&h, 0, sizeof(h));
   h.status = CFEAR_ERR_EMPTY;
   h.cap_points = cap_points; h.cap_cells = cap_cells; h.cap_grid = GRID_CAP;
   h.xyi = reinterpret_cast<float*>(d_base + L.xyi);
-  h.cells = reinterpret_cast<cfear_cell*>(d_base + L.cells);
+  h.cells = with_cells ? reinterpret_cast<cfear_cell*>(d_base + L.cells) : nullptr;
+  h.rcov = reinterpret_cast<double*>(d_base + L.rcov);
   h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
   h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
   h.gpts = reinterpret_cast<float4*>(d_base + L.gpts);
@@ -1017,11 +1022,14 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   o->large_kernel = ctx->tune_large_kernel;
   { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && ncu > 0) o->n_cus = ncu; }
   o->B = B; o->nslots = s + 1; o->cap_points = o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest;
-  o->cap_cells = ctx->tune_max_cells > 0 ? std::min(ctx->tune_max_cells, o->cap_points) : o->cap_points;
+  // cells per scan the blocks are sized for: cfear_tune MAX_CELLS; by default every filtered point (cannot overflow) - except for a submap of
+  // more than seven keyframes, where that default would be hundreds of MB per sequence (280 MB at submap_scan_size 50, k 40) for scans of a
+  // few hundred to ~1500 cells: 4096 then (launch/oxford_demo:62-71 works without a tune call; an overflow is loud, CFEAR_ERR_CAPACITY)
+  o->cap_cells = ctx->tune_max_cells > 0 ? std::min(ctx->tune_max_cells, o->cap_points) : (s > 7 ? std::min(o->cap_points, 4096) : o->cap_points);
   // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,
   // n_scan_normal.cpp:242,258); the association parks four results per source cell in the same scratch
   o->pair_cap = std::max(s, 4) * o->cap_cells;
-  const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells);
+  const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false);
   const ScratchLayout WL = scratch_layout(o->cap_points, o->pair_cap);
   {  // refuse what cannot fit with a message that names the numbers (a bare NOMEM after gigabytes of partial allocations helps nobody)
     size_t free_b = 0, total_b = 0;
@@ -1068,7 +1076,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   for (int q = 0; q < B; q++) {
     for (int j = 0; j < o->nslots; j++) {
       unsigned char* blk = o->d_scans + SL.total * ((size_t)q * o->nslots + j);
-      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points, o->cap_cells);
+      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points, o->cap_cells, false);
       ptrs[(size_t)q * o->nslots + j] = reinterpret_cast<ScanDev*>(blk);
     }
     hdrs[q] = scratch_header(o->d_scratch + WL.total * (size_t)q, o->cap_points, o->pair_cap);
@@ -1549,7 +1557,7 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfea
     CFEAR_HIP_CHECK(ctx, hipMemcpy(&st, o->d_states + sequence, sizeof(st), hipMemcpyDeviceToHost));
     if (n_keyframes) *n_keyframes = st.nkf;
     if (n_cells) {  // cells of the scan built by the last step
-      const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells);
+      const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false);
       ScanDev h;
       CFEAR_HIP_CHECK(ctx, hipMemcpy(&h, o->d_scans + SL.total * ((size_t)sequence * o->nslots + st.last_slot), sizeof(h), hipMemcpyDeviceToHost));
       *n_cells = h.n_cells;

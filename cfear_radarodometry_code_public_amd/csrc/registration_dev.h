@@ -624,7 +624,7 @@ __device__ __forceinline__ RCell rcell_tar(const ScanDev* S, int ti) {  // one 6
 
 // one match record (AddScanPairCost :266-320) written at position o of the destination SoA
 __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const RegParams& P, const double* T, const double* Tt,
-                                            const RCell& cs, const RCell& ct, const cfear_cell* ct_full) {
+                                            const RCell& cs, const RCell& ct, const double* ct_cov /* xx, xy, yy (P2D) */) {
   const double nx = T[0] * cs.nx + T[1] * cs.ny;
   const double ny = T[2] * cs.nx + T[3] * cs.ny;
   const double sim = fmax(nx * ct.nx + ny * ct.ny, 0.0);
@@ -633,7 +633,7 @@ __device__ __forceinline__ void write_match(const MatchPtrs& m, int o, const Reg
   m.tmy[o] = (Tt[2] * ct.mx + Tt[3] * ct.my) + Tt[5];
   m.sx[o] = cs.mx; m.sy[o] = cs.my;
   if (P.cost == CFEAR_COST_P2D) {  // :290-299
-    const double a = ct_full->cov[0], b = ct_full->cov[1], c = ct_full->cov[2];
+    const double a = ct_cov[0], b = ct_cov[1], c = ct_cov[2];
     const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
     const double m00 = r00 * a + r01 * b, m01 = r00 * b + r01 * c;
     const double m10 = r10 * a + r11 * b, m11 = r10 * b + r11 * c;
@@ -686,7 +686,7 @@ __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* sr
     const double2 r0 = r[0], r1 = r[1], r2 = r[2];
     ct.mx = r0.x; ct.my = r0.y; ct.nx = r1.x; ct.ny = r1.y; ct.ns = r2.x; ct.scale = r2.y;
   }
-  const cfear_cell* ctf = (P.cost == CFEAR_COST_P2D) ? &scans[i]->cells[ti] : nullptr;
+  const double* ctf = (P.cost == CFEAR_COST_P2D) ? scans[i]->rcov + 3 * (size_t)ti : nullptr;  // the target's covariance xx, xy, yy
   const double* Trel = (const double*)sh->Trel[i];  // generic views for the by-pointer interface of write_match
   const double* Ttar = (const double*)sh->Ttar[i];
   if (use_lds) write_match(match_ptrs_lds(P.cost), o, P, Trel, Ttar, cs, ct, ctf);
@@ -913,8 +913,8 @@ __device__ __forceinline__ void emit_cell(ScanDev* const* scans, const ScanDev* 
     const double wgt = get_weight(weight_opt, cs.ns, r2.x, sim, cs.scale, r2.y);
     double a0, a1, a2;
     if (cost == CFEAR_COST_P2D) {  // :290-299
-      const cfear_cell* ctf = &scans[ki]->cells[tix];
-      const double ca = ctf->cov[0], cb = ctf->cov[1], cc = ctf->cov[2];
+      const double* ctf = scans[ki]->rcov + 3 * (size_t)tix;
+      const double ca = ctf[0], cb = ctf[1], cc = ctf[2];
       const double r00 = Tt[0], r01 = Tt[1], r10 = Tt[2], r11 = Tt[3];
       const double m00 = r00 * ca + r01 * cb, m01 = r00 * cb + r01 * cc;
       const double m10 = r10 * ca + r11 * cb, m11 = r10 * cb + r11 * cc;

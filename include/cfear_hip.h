@@ -103,11 +103,11 @@ int cfear_synchronize(cfear_ctx* ctx);
  * REPEAT_SHORTCUT (default 1): an outer registration iteration (n_scan_normal.cpp:102-151) that starts from the pose, radius and
  * keyframes of the previous one - a solve that accepted no step - repeats it bit for bit, so its summary is taken from the
  * previous one instead of associating and solving again; 0 runs it again (the tests compare the two).
- * MAX_CELLS = n (default 0 = A * k_strongest, the number of filtered points: cannot overflow): oriented surface points per scan
- * the batched odometry objects created afterwards are sized for. A sequence's memory is (submap_scan_size + 1) scan blocks of
- * ~12 B per point + 256 B per cell, plus submap_scan_size * cells * 68 B of residual-block scratch: with the default that is
- * 9 MB at submap_scan_size 4, k 12, but 280 MB at submap_scan_size 50, k 40 (launch/oxford_demo:62-71) - where real scans have a
- * few hundred to ~1500 cells. A scan that produces more cells than n keeps the first n (ascending voxel index) and the reading
+ * MAX_CELLS = n (default 0 = A * k_strongest, the number of filtered points: cannot overflow - or 4096 if that is less and
+ * submap_scan_size > 7): oriented surface points per scan the batched odometry objects created afterwards are sized for. A sequence's
+ * memory is (submap_scan_size + 1) scan blocks of ~12 B per point + 160 B per cell, plus submap_scan_size * cells * 76 B of
+ * residual-block scratch: one cell per filtered point is 7 MB at submap_scan_size 4, k 12, but 200 MB at submap_scan_size 50, k 40
+ * (launch/oxford_demo:62-71) - where real scans have a few hundred to ~1500 cells; hence the 4096 for the large submaps. A scan that produces more cells than n keeps the first n (ascending voxel index) and the reading
  * calls (poses / covariances / summary / replay_host) return CFEAR_ERR_CAPACITY from then on: never silently.
  * REGISTRATION_ORDER (default 1; 0 = in sequence order): batched odometry objects created afterwards hand their sequences to the registration workgroups
  * longest first - sorted on the device by the work each sequence's registration took in the previous sweep - so that the last
