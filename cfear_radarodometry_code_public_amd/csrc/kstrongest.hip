@@ -75,6 +75,21 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
   return v;
 }
 
+// ... with OR: lane 63 ends up with the OR over the wave
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_i(int v) {
+  return v | __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_inclusive_or(int v) {
+  v = dpp_or_i<0x111, 0xF>(v);
+  v = dpp_or_i<0x112, 0xF>(v);
+  v = dpp_or_i<0x114, 0xF>(v);
+  v = dpp_or_i<0x118, 0xF>(v);
+  v = dpp_or_i<0x142, 0xA>(v);
+  v = dpp_or_i<0x143, 0xC>(v);
+  return v;
+}
+
 // wave-wide sum of a small non-negative per-lane integer: six DPP adds and a readlane (the ballot bit-slicing
 // it replaces cost two VALU instructions per bit)
 template <int BITS>
@@ -516,19 +531,37 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
     uint32_t covered = 0x7Fu;
     const bool edge_points = __ballot(kept && !interior) != 0;  // wave-uniform: a kept point within 3 bins of a row end (rare)
     if (edge_points) {
-      // scores exist only where a valid kept point's +-3 window put them in the map (:253-263);
-      // everything else reads as the unordered_map default 0 (:271-276)
-      covered = 0;
-      unsigned long long kb = __ballot(kept);
-      while (kb) {
-        const int i = __ffsll((long long)kb) - 1;
-        kb &= kb - 1;
-        const int mi = (int)(__builtin_amdgcn_readlane((int)key, i) & 0xFFFF);
-        if (mi >= 3 && mi < R - 3) {
+      // scores exist only where a valid kept point's +-3 window put them in the map (:253-263); everything else reads as the
+      // unordered_map default 0 (:271-276). An interior point's own window covers its seven scores; a point within three bins of a
+      // row end only sees what INTERIOR kept points within six bins of that end wrote: positions 3 .. 8 (and R - 9 .. R - 4). Those are
+      // marked with one bit each, the marks of the wave OR-ed by six DPP steps, spread over their +-3 windows by three shift-ors
+      // (E bit j <-> a score exists at bin j - 3, resp. R - 12 + j), and a lane shifts its seven bits out. (It was a loop over every kept
+      // lane with seven compare-ors each, in every wave that holds an edge point: with tied intensities the kept points crowd at the
+      // far end of the row - ties go to the larger range - and every row took it.)
+      if (R >= 24) {
+        const bool ik = kept && interior;
+        int marks = (ik && mpos <= 8) ? (1 << (mpos - 3)) : 0;
+        marks |= (ik && mpos >= R - 9) ? (1 << (6 + mpos - (R - 9))) : 0;
+        marks = __builtin_amdgcn_readlane(wave_inclusive_or(marks), 63);
+        uint32_t es = (uint32_t)marks & 0x3Fu, ee = ((uint32_t)marks >> 6) & 0x3Fu;
+        es |= es << 1; es |= es << 2; es |= es << 3;  // bit b set -> bits b .. b + 6
+        ee |= ee << 1; ee |= ee << 2; ee |= ee << 3;
+        const uint32_t c_lo = ((es << 3) >> (mpos < 3 ? mpos : 0)) & 0x7Fu;          // bin r = mpos - 3 + t <-> bit r + 3 of es << 3
+        const uint32_t c_hi = (ee >> (mpos >= R - 3 ? mpos - R + 9 : 0)) & 0x7Fu;    // <-> bit r - (R - 12) of ee
+        covered = interior ? 0x7Fu : (mpos < 3 ? c_lo : c_hi);
+      } else {  // a row too short for the two ends to be apart: the plain loop
+        covered = 0;
+        unsigned long long kb = __ballot(kept);
+        while (kb) {
+          const int i = __ffsll((long long)kb) - 1;
+          kb &= kb - 1;
+          const int mi = (int)(__builtin_amdgcn_readlane((int)key, i) & 0xFFFF);
+          if (mi >= 3 && mi < R - 3) {
 #pragma unroll
-          for (int t = 0; t < 7; t++) {
-            const int r = mpos - 3 + t;
-            if (r >= mi - 3 && r <= mi + 3) covered |= 1u << t;
+            for (int t = 0; t < 7; t++) {
+              const int r = mpos - 3 + t;
+              if (r >= mi - 3 && r <= mi + 3) covered |= 1u << t;
+            }
           }
         }
       }

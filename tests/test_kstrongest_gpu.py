@@ -100,3 +100,28 @@ def test_unsupported_sizes_fail_loudly(hip_lib):
         capi.Context(capi.default_params(k_strongest=65), 4, 100)
     with pytest.raises(capi.CfearError):
         capi.Context(capi.default_params(), 4, 20000)
+
+
+@pytest.mark.parametrize("R", [3360, 333, 40, 25, 24, 23, 16, 13])
+@pytest.mark.parametrize("k", [12, 3])
+def test_kept_points_at_the_row_ends(oracle, R, k):
+    """AxialNonMaxSupress at the ends of a row (radar_filters.cpp:251-276): a kept point within three bins of an end only sees the
+    scores that interior kept points within six bins of that end put into the map; everything else reads as 0. Rows whose strongest
+    returns sit in the first / last nine bins in every mix of edge and interior positions (R >= 24: the marked-bits path of the
+    kernel, shorter rows: its plain loop)."""
+    rng = np.random.default_rng(R * 31 + k)
+    A = 96
+    img = rng.integers(0, 50, size=(A, R), dtype=np.uint8)
+    for a in range(A):
+        ends = []
+        if a % 3 != 1:
+            ends.append(0)
+        if a % 3 != 0:
+            ends.append(R - 9)
+        for e0 in ends:
+            span = min(9, R - e0) if e0 else min(9, R)
+            n = int(rng.integers(1, span + 1))
+            pos = e0 + rng.choice(span, size=n, replace=False)
+            pos = pos[(pos >= 0) & (pos < R)]
+            img[a, pos] = rng.integers(120, 256, size=len(pos)) if a % 2 else 200  # distinct intensities / ties
+    run_case(oracle, img, k, 60)
