@@ -8,10 +8,12 @@
 #pragma once
 #include <type_traits>
 #include "blockops.h"
+#include "kdtree_flann_dev.h"
 #include "../../include/cfear_hip.h"
 
 namespace cfear_dev {
 
+#define CFEAR_HAVE_KD 1
 // Device-resident MapPointNormal. Lives in device memory; the arrays are one flat allocation.
 struct ScanDev {
   int n_points;   // input_ size (cloud after the min-range cut, compensated)
@@ -32,6 +34,7 @@ struct ScanDev {
   double* rsrc;       // [6][cap_cells] SoA: read with consecutive cell indices when the scan is the source
   double* rtar;       // [cap_cells][8] 64-byte records: read at random cell indices when the scan is a target
   double* rcov;       // [cap_cells][3] covariance xx, xy, yy: what the P2D cost reads of a target cell besides its rtar record (n_scan_normal.cpp:290-299)
+  KdTree kd;          // parity mode (cfear_tune NN_TIE_RULE = 2): the kd-tree FLANN would build over mean_f (kdtree_flann_dev.h); arrays null otherwise
 };
 #define CFEAR_GRID_CAP (128 * 128)  // buckets per scan (ScanDev::cap_grid)
 // Scans of up to CFEAR_GRID16_MAX cells (every scan the odometry builds) keep their bucket offsets as 16-bit values in the
@@ -44,6 +47,7 @@ __device__ __forceinline__ unsigned short* grid_off16(int* gstart) { return rein
 __device__ __forceinline__ const unsigned short* grid_off16(const int* gstart) { return reinterpret_cast<const unsigned short*>(gstart + CFEAR_GRID_CAP + 4); }
 
 struct FeatureParams {
+  int nn_tie;                // cfear_tune NN_TIE_RULE: 2 = also build the FLANN kd-tree over the cell means (parity mode)
   float range_res, min_distance;
   float radius;              // (float)par.res, pointnormal.h:118
   double downsample_factor;  // pointnormal.h:241
@@ -934,6 +938,9 @@ __device__ __forceinline__ GridView grid_view(const ScanDev* S) {
   G.gw = S->gw; G.gh = S->gh; G.n_cells = S->n_cells;
   return G;
 }
+// TIE_HIGH: exact-distance ties to the HIGHEST cell index (cfear_tune NN_TIE_RULE = 1: the other end of the admissible answers, for sensitivity
+// runs on the device like the oracle's CFO_PERT_NN_TIE_HIGH); the production rule is the lowest
+template <bool TIE_HIGH = false>
 __device__ inline int scan_closest(const GridView& S, double px, double py, double d) {
   const float qx = (float)px, qy = (float)py;
   const int gw = S.gw, gh = S.gh;
@@ -973,13 +980,24 @@ __device__ inline int scan_closest(const GridView& S, double px, double py, doub
           const float dx = qx - c[u].x, dy = qy - c[u].y;
           float d2 = dx * dx; d2 += dy * dy;
           const int i = __float_as_int(c[u].z);
-          if (q + u < rb[r] && (d2 < bd || (d2 == bd && i < best))) { bd = d2; best = i; }
+          if (q + u < rb[r] && (d2 < bd || (d2 == bd && (TIE_HIGH ? i > best : i < best)))) { bd = d2; best = i; }
         }
       }
     }
   }
   if (best >= 0 && (double)bd < d * d) return best;
   return -1;
+}
+// GetClosestIdx under a tie rule other than the production one (cfear_tune NN_TIE_RULE; parity / sensitivity modes, slow paths): 1 = highest
+// index, 2 = what FLANN's kd-tree descent returns (kdtree_flann_dev.h; the scan must have been built in that mode). stack: CFEAR_KD_STACK
+// entries of this thread's own
+__device__ inline int scan_closest_rule(const ScanDev* S, const GridView& G, double px, double py, double d, int rule, KdVisit* stack) {
+  if (rule == 2 && S->kd.nodes) {
+    float bd = 0.f;
+    const int best = kd_nearest(&S->kd, (float)px, (float)py, stack, &bd);  // kd_cells.nearestKSearch(pnt, 1, ...)
+    return (best >= 0 && (double)bd < d * d) ? best : -1;                   // pointNKNSquaredDistances[0] < d*d
+  }
+  return rule == 1 ? scan_closest<true>(G, px, py, d) : scan_closest<false>(G, px, py, d);
 }
 
 }  // namespace cfear_dev

@@ -89,6 +89,18 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   W.red_f = reinterpret_cast<float*>(lds + FeatLdsC::red_f);
   return W;
 }
+// cfear_tune NN_TIE_RULE = 2: one thread builds the scan's kd-tree (kdtree_flann_dev.h) over the float cell means; the activation stack of the
+// build lives in the partial-moment scratch (free once the cells exist). A scan without the arrays (created before the mode was switched on)
+// or a stack that does not suffice is reported through the scan's status.
+__device__ inline void kd_build_block(ScanDev* S, const BlockScratch& B) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int frames = (int)(((size_t)7 * B.cap_points * sizeof(double)) / sizeof(KdFrame));
+    const bool ok = S->kd.nodes && kd_build_serial(&S->kd, S->mean_f, S->n_cells, reinterpret_cast<KdFrame*>(B.part), frames);
+    if (!ok && S->status == 0) S->status = CFEAR_ERR_UNSUPPORTED;
+  }
+  __syncthreads();
+}
 // byte_intensities: every intensity of the cloud is an integer in 0..255 (block-uniform; always true for clouds made from
 // the filter's slots) - the compact path keeps them as bytes
 // (the batched cloud pass leaves the cloud in registers only: the general path needs it in memory and writes it first)
@@ -96,10 +108,12 @@ __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const Featu
                                                   unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities,
                                                   const PointRegs& PR, bool registers_only = false) {
   const FeatureScratch W = make_fscratch(B, lds);
-  if (byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR)) return;
-  // registers_only (a constant of the call site): the cloud pass may have left the cloud in registers only (byte intensities)
-  if (registers_only && PR.rounds > 0) point_regs_to_global(PR, S->xyi);  // block-uniform
-  features_block(S, n, P, W, next_pow2(n), pt, bounds);
+  if (!(byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR))) {
+    // registers_only (a constant of the call site): the cloud pass may have left the cloud in registers only (byte intensities)
+    if (registers_only && PR.rounds > 0) point_regs_to_global(PR, S->xyi);  // block-uniform
+    features_block(S, n, P, W, next_pow2(n), pt, bounds);
+  }
+  if (P.nn_tie == 2) kd_build_block(S, B);  // parity mode: the kd-tree FLANN builds over the cell means (ComputeSearchTreeFromCells, pointnormal.cpp:151-162)
 }
 __device__ inline RegScratch make_rscratch(const BlockScratch& B, unsigned char* lds) {
   RegScratch W;
@@ -309,8 +323,13 @@ __device__ __forceinline__ void register_step_body(unsigned char* lds /* RegLds:
 #define CFEAR_REG_MIN_WG 3  // workgroups per compute unit the registration step kernel is compiled for (tools: A/B builds)
 #endif
 // KCOST: the cost metric the kernel is compiled for (registration_dev.h evaluate_partial), -1: any (the timed instantiation)
+#ifdef CFEAR_REG_NUM_VGPR  // tools/reg_resources.sh: cap the architectural VGPRs below the occupancy budget (the rest of it: AGPRs for spills)
+#define CFEAR_REG_VGPR_ATTR __attribute__((amdgpu_num_vgpr(CFEAR_REG_NUM_VGPR)))
+#else
+#define CFEAR_REG_VGPR_ATTR
+#endif
 template <bool TIMED, int KCOST>
-__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
+__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) CFEAR_REG_VGPR_ATTR void register_step_kernel(OdoParams OP, SeqState* states, ScanDev* const* scan_slots,
                                                                 const BlockScratch* scratch, double* poses_work /*[B][MAX_SCANS*3]*/,
                                                                 double* cov_work /*[B][36]*/, cfear_reg_summary* summaries,
                                                                 double* poses_out /*[B][3]*/) {

@@ -68,11 +68,15 @@ __global__ __launch_bounds__(BLOCK_F) void scan_from_cells_kernel(ScanDev* S, in
   if (threadIdx.x == 0) { S->n_points = 0; S->n_samples = 0; S->n_cells = n; S->status = n > 0 ? 0 : CFEAR_ERR_EMPTY; }
   __syncthreads();
   cell_grid_block(S, n, P, W, false, nullptr);
+  if (P.nn_tie == 2) kd_build_block(S, B);
 }
 
-__global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx) {
+__global__ void closest_kernel(const ScanDev* S, const double* q, int nq, double d, int* idx, int rule) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) idx[i] = scan_closest(grid_view(S), q[2 * i], q[2 * i + 1], d);
+  if (i >= nq) return;
+  if (rule == 0) { idx[i] = scan_closest(grid_view(S), q[2 * i], q[2 * i + 1], d); return; }
+  KdVisit stack[CFEAR_KD_STACK];  // (per-thread scratch: this little kernel only)
+  idx[i] = scan_closest_rule(S, grid_view(S), q[2 * i], q[2 * i + 1], d, rule, stack);
 }
 
 __global__ __launch_bounds__(BLOCK_R, 3) void register_kernel(ScanDev* const* scans, int n, double* poses, double* cov6, RegParams P,
@@ -168,6 +172,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 FeatureParams feature_params(const cfear_ctx* ctx) {
   FeatureParams P;
+  P.nn_tie = ctx->tune_nn_tie;
   P.range_res = ctx->par.range_res; P.min_distance = ctx->par.min_distance;
   P.radius = (float)ctx->par.res;
   P.downsample_factor = ctx->par.downsample_factor;
@@ -179,6 +184,7 @@ RegParams reg_params(const cfear_ctx* ctx) {
   RegParams P;
   P.cost = ctx->par.cost; P.loss = ctx->par.loss; P.weight_opt = ctx->par.weight_opt;
   P.recompute_repeats = ctx->tune_repeat_shortcut ? 0 : 1;
+  P.nn_tie = ctx->tune_nn_tie;
   P.loss_limit = ctx->par.loss_limit; P.covar_scale = ctx->par.covar_scale; P.regularization = ctx->par.regularization;
   P.assoc_radius = ctx->par.assoc_radius;
   P.max_outer = ctx->par.max_itr_association; P.min_itr = ctx->par.min_itr; P.max_inner = ctx->par.max_solver_iterations;
@@ -187,11 +193,11 @@ RegParams reg_params(const cfear_ctx* ctx) {
 
 constexpr int GRID_CAP = CFEAR_GRID_CAP;
 
-struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, rcov, total; };
+struct ScanLayout { size_t xyi, cells, mean_f, gstart, gpts, rsrc, rtar, rcov, kd_nodes, kd_vind, kd_data, total; };
 // cap_cells <= cap_points: cells a scan can hold (every cell is the centroid neighbourhood of an occupied voxel, so never more than
 // points; the batched odometry may be sized for fewer: cfear_tune MAX_CELLS). with_cells: the 120-byte cfear_cell records exist (the
 // per-call scans, whose cells can be downloaded); the scans of the batched odometry objects go without
-ScanLayout scan_layout(int cap_points, int cap_cells, bool with_cells = true) {
+ScanLayout scan_layout(int cap_points, int cap_cells, bool with_cells = true, bool with_kd = false) {
   ScanLayout L;
   size_t o = align_up(sizeof(ScanDev), 256);
   L.xyi = o; o = align_up(o + sizeof(float) * 3 * (size_t)cap_points, 256);
@@ -202,12 +208,18 @@ ScanLayout scan_layout(int cap_points, int cap_cells, bool with_cells = true) {
   L.rsrc = o; o = align_up(o + sizeof(double) * 6 * (size_t)cap_cells, 256);
   L.rtar = o; o = align_up(o + sizeof(double) * 8 * (size_t)cap_cells, 256);
   L.rcov = o; o = align_up(o + sizeof(double) * 3 * (size_t)cap_cells, 256);
+  L.kd_nodes = L.kd_vind = L.kd_data = 0;
+  if (with_kd) {  // cfear_tune NN_TIE_RULE = 2 (kdtree_flann_dev.h)
+    L.kd_nodes = o; o = align_up(o + sizeof(KdNode) * (2 * (size_t)cap_cells + 2), 256);
+    L.kd_vind = o; o = align_up(o + sizeof(int) * (size_t)cap_cells, 256);
+    L.kd_data = o; o = align_up(o + sizeof(float) * 2 * (size_t)cap_cells, 256);
+  }
   L.total = o;
   return L;
 }
 // writes a ScanDev header for a flat device block at d_base
-ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells, bool with_cells = true) {
-  const ScanLayout L = scan_layout(cap_points, cap_cells, with_cells);
+ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells, bool with_cells = true, bool with_kd = false) {
+  const ScanLayout L = scan_layout(cap_points, cap_cells, with_cells, with_kd);
   ScanDev h;
   memset(&h, 0, sizeof(h));
   h.status = CFEAR_ERR_EMPTY;
@@ -215,6 +227,11 @@ ScanDev scan_header(unsigned char* d_base, int cap_points, int cap_cells, bool w
   h.xyi = reinterpret_cast<float*>(d_base + L.xyi);
   h.cells = with_cells ? reinterpret_cast<cfear_cell*>(d_base + L.cells) : nullptr;
   h.rcov = reinterpret_cast<double*>(d_base + L.rcov);
+  if (with_kd) {
+    h.kd.nodes = reinterpret_cast<KdNode*>(d_base + L.kd_nodes); h.kd.vind = reinterpret_cast<int*>(d_base + L.kd_vind);
+    h.kd.data = reinterpret_cast<float*>(d_base + L.kd_data);
+  }
+  h.kd.root = -1;
   h.mean_f = reinterpret_cast<float*>(d_base + L.mean_f);
   h.gstart = reinterpret_cast<int*>(d_base + L.gstart);
   h.gpts = reinterpret_cast<float4*>(d_base + L.gpts);
@@ -278,6 +295,7 @@ struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
   int* d_order = nullptr; unsigned* d_work = nullptr;  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): see order_kernel
   bool order_ready = false;  // d_work holds the keys of a registration launch
+  bool with_kd = false;  // the scans carry FLANN kd-tree arrays (cfear_tune NN_TIE_RULE = 2 at creation)
   int large_kernel = 0, n_cus = 256;  // cfear_tune LARGE_SUBMAP_KERNEL at creation; compute units of the device
   int* d_flags = nullptr;  // bit 0: a scan had more cells than cap_cells, bit 1: a cloud had more points than cap_points (only allocated when either can happen)
   unsigned char* d_scans = nullptr;    // B * nslots flat scan blocks
@@ -596,9 +614,9 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = cap;
-  const ScanLayout L = scan_layout(cap, cap);
+  const ScanLayout L = scan_layout(cap, cap, true, ctx->tune_nn_tie == 2);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
-  const ScanDev h = scan_header(s->d_block, cap, cap);
+  const ScanDev h = scan_header(s->d_block, cap, cap, true, ctx->tune_nn_tie == 2);
   ScanDev back;
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);  // h lives until the synchronize below
   if (e == hipSuccess) {
@@ -638,9 +656,9 @@ int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = n;
-  const ScanLayout L = scan_layout(n, n);
+  const ScanLayout L = scan_layout(n, n, true, ctx->tune_nn_tie == 2);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
-  const ScanDev h = scan_header(s->d_block, n, n);
+  const ScanDev h = scan_header(s->d_block, n, n, true, ctx->tune_nn_tie == 2);
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(s->d_block + L.cells, cells, sizeof(cfear_cell) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
@@ -699,7 +717,7 @@ int cfear_scan_closest(cfear_ctx* ctx, const cfear_scan* s, const double* qxy, i
   if (hipMalloc(&di, sizeof(int) * (size_t)nq) != hipSuccess) { (void)hipFree(dq); return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc idx"); }
   hipError_t e = hipMemcpyAsync(dq, qxy, sizeof(double) * 2 * (size_t)nq, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(closest_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const ScanDev*>(s->d_block), dq, nq, d, di);
+    hipLaunchKernelGGL(closest_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const ScanDev*>(s->d_block), dq, nq, d, di, ctx->tune_nn_tie);
     e = hipMemcpyAsync(idx, di, sizeof(int) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1029,7 +1047,8 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,
   // n_scan_normal.cpp:242,258); the association parks four results per source cell in the same scratch
   o->pair_cap = std::max(s, 4) * o->cap_cells;
-  const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false);
+  o->with_kd = ctx->tune_nn_tie == 2;
+  const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false, o->with_kd);
   const ScratchLayout WL = scratch_layout(o->cap_points, o->pair_cap);
   {  // refuse what cannot fit with a message that names the numbers (a bare NOMEM after gigabytes of partial allocations helps nobody)
     size_t free_b = 0, total_b = 0;
@@ -1076,7 +1095,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   for (int q = 0; q < B; q++) {
     for (int j = 0; j < o->nslots; j++) {
       unsigned char* blk = o->d_scans + SL.total * ((size_t)q * o->nslots + j);
-      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points, o->cap_cells, false);
+      scan_hdrs[(size_t)q * o->nslots + j] = scan_header(blk, o->cap_points, o->cap_cells, false, o->with_kd);
       ptrs[(size_t)q * o->nslots + j] = reinterpret_cast<ScanDev*>(blk);
     }
     hdrs[q] = scratch_header(o->d_scratch + WL.total * (size_t)q, o->cap_points, o->pair_cap);
@@ -1557,7 +1576,7 @@ int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfea
     CFEAR_HIP_CHECK(ctx, hipMemcpy(&st, o->d_states + sequence, sizeof(st), hipMemcpyDeviceToHost));
     if (n_keyframes) *n_keyframes = st.nkf;
     if (n_cells) {  // cells of the scan built by the last step
-      const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false);
+      const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false, o->with_kd);
       ScanDev h;
       CFEAR_HIP_CHECK(ctx, hipMemcpy(&h, o->d_scans + SL.total * ((size_t)sequence * o->nslots + st.last_slot), sizeof(h), hipMemcpyDeviceToHost));
       *n_cells = h.n_cells;

@@ -5,7 +5,9 @@
 // per compute unit. A city-block scene at k = 12 builds 650-750 blocks per registration: with 710 in LDS two out of five
 // registrations evaluated part of their matches from memory. pipeline.hip keeps an instantiation for larger submaps.
 #define CFEAR_REG_MAX_SCANS 8
+#ifndef CFEAR_MATCH_LDS_CAP  // (tools/reg_resources.sh, tools/build_variant.sh: A/B builds)
 #define CFEAR_MATCH_LDS_CAP 784
+#endif
 #include "common.h"
 #include "odometry_step_dev.h"
 

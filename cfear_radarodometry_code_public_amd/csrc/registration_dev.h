@@ -20,6 +20,8 @@ struct RegParams {
   int recompute_repeats;  // 1: an outer iteration that would repeat the previous one exactly is run again anyway (ctl_lm_done; cfear_tune REPEAT_SHORTCUT = 0)
   double loss_limit, covar_scale, regularization, assoc_radius;
   int max_outer, min_itr, max_inner;
+  int nn_tie;  // cfear_tune NN_TIE_RULE: 0 = exact-distance 1-NN ties to the lowest cell index (production), 1 = highest, 2 = FLANN's kd-tree order:
+               // the non-zero rules take the general association path (slow: sensitivity / parity modes)
 };
 
 // Per-block global scratch: compacted matches (SoA) + per-pair association result.
@@ -675,6 +677,29 @@ __device__ __noinline__ int associate_pair(const ScanDev* src, const LRegShared*
   }
   return ti;
 }
+// ... under a tie rule other than the production one (RegParams::nn_tie): the same pair through scan_closest_rule; the kd descent's stack
+// is this thread's slice of the match arrays in memory (free until the emission that follows every association of the general path)
+__device__ __noinline__ int associate_pair_rule(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nsrc, int p, double curr_radius, int rule) {
+  const double angle_outlier = 0.86602540378443864676;  // cos(M_PI/6)
+  const int i = p / nsrc, j = p - i * nsrc;
+  const auto* T = sh->Trel[i];
+  const size_t cc = (size_t)src->cap_cells;
+  const double* rs = src->rsrc + j;
+  const double mx = rs[0], my = rs[cc];
+  const double snx = rs[2 * cc], sny = rs[3 * cc];
+  const double qx = (T[0] * mx + T[1] * my) + T[4];
+  const double qy = (T[2] * mx + T[3] * my) + T[5];
+  KdVisit* stack = reinterpret_cast<KdVisit*>(sh->rw.tmx) + (size_t)threadIdx.x * CFEAR_KD_STACK;
+  int ti = scan_closest_rule(scans[i], CFEAR_GENERIC(const GridView, sh->kf[i]), qx, qy, curr_radius, rule, stack);
+  if (ti >= 0) {
+    const double2 tn = reinterpret_cast<const double2*>(sh->kf[i].rtar + 8 * (size_t)ti)[1];
+    const double nx = T[0] * snx + T[1] * sny;
+    const double ny = T[2] * snx + T[3] * sny;
+    const double sim = fmax(nx * tn.x + ny * tn.y, 0.0);
+    if (!(sim > angle_outlier)) ti = -1;  // :247
+  }
+  return ti;
+}
 __device__ __noinline__ void emit_match(ScanDev* const* scans, const ScanDev* src, const LRegShared* sh, int nsrc, int p, int ti, int o, bool use_lds) {
   const RegParams& P = CFEAR_GENERIC(const RegParams, sh->rp);
   const RegScratch& W = CFEAR_GENERIC(const RegScratch, sh->rw);
@@ -1007,7 +1032,8 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   // the grouped path parks four ints + two ints of positions per (group, source cell) in W.assoc
   const bool can_park = 6 * (long long)ngroups * nsrc <= (long long)sh->rw.acap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
   bool done = false;
-  if (nk <= 4 && nsrc <= nt) {  // one group of keyframes, one block of cells: the matches stay in registers
+  const int tie_rule = sh->rp.nn_tie;  // (block-uniform) a non-production tie rule: the general path below
+  if (tie_rule == 0 && nk <= 4 && nsrc <= nt) {  // one group of keyframes, one block of cells: the matches stay in registers
     const AssocBlock R = assoc_block(src, sh, 0, nk, nsrc, itr, 0, 0, false);
     const unsigned long long T = R.tb;  // matches per keyframe, 16-bit fields
     const unsigned long long t0 = T & 0xFFFF, t1 = (T >> 16) & 0xFFFF, t2 = (T >> 32) & 0xFFFF, t3 = (T >> 48) & 0xFFFF;
@@ -1015,7 +1041,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
     mode = M <= lcap ? 1 : 2;
     (void)emit_block<KCOST>(scans, src, sh, 0, nk, nsrc, 0, 0, false, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
     done = true;
-  } else if (can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
+  } else if (tie_rule == 0 && can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
     // several blocks of cells and / or several groups of four keyframes (a submap of 5 .. 63 keyframes: the reference's s10 and s50
     // presets; a dense scan against four): the items (group g of four keyframes, source cell j), numbered g * nsrc + j, are dealt to
     // the threads DENSELY - with 172 source cells and 13 groups a 512-thread workgroup makes 5 passes where group after group it made
@@ -1080,7 +1106,9 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
     const int p0 = tid * ipt, p1 = min(pairs, p0 + ipt);
     int cnt = 0;
     for (int p = p0; p < p1; p++) {
-      const int ti = associate_pair(src, sh, nsrc, p, curr_radius);
+      // (the kd descent's per-thread stack needs CFEAR_KD_STACK * 16 B * blockDim of the match arrays: 64 B per pair of capacity)
+      const int ti = (tie_rule != 0 && (size_t)sh->rw.cap * 64 >= (size_t)nt * CFEAR_KD_STACK * sizeof(KdVisit))
+                         ? associate_pair_rule(scans, src, sh, nsrc, p, curr_radius, tie_rule) : associate_pair(src, sh, nsrc, p, curr_radius);
       sh->rw.assoc[p] = ti;
       cnt += (ti >= 0) ? 1 : 0;
     }

@@ -115,10 +115,17 @@ int cfear_synchronize(cfear_ctx* ctx);
  * LARGE_SUBMAP_KERNEL (default 0): with submap_scan_size > 7 the batched step has two registration kernels - the production shape compiled for
  * 64 scans (256 threads, three workgroups per compute unit) and one that gives a registration a whole unit (512 threads, all of its LDS for
  * the residual blocks, every wave evaluating: 2 x faster per registration at fifty keyframes). 0 = the second when the sequences fit the
- * chip at one per unit or the submap has 24 keyframes or more, 1 = always the first, 2 = always the second. Poses agree to the summation order of the evaluation's partial sums. */
+ * chip at one per unit or the submap has 24 keyframes or more, 1 = always the first, 2 = always the second. Poses agree to the summation order of the evaluation's partial sums.
+ * NN_TIE_RULE (default 0) - the one knob here that DOES change results, on purpose: which of several exactly equidistant cells the 1-NN search
+ * of GetClosestIdx (pointnormal.cpp:238-254) returns. The reference leaves that to FLANN's kd-tree; 1-5 % of a scan's cells share their float
+ * mean with another cell, and the choice moves a registration by up to centimetres on a few percent of the sweeps of a cluttered scene
+ * (DESIGN.md section 2). 0 = the lowest cell index (production: a uniform grid search); 1 = the highest (the other end, for sensitivity runs);
+ * 2 = what a restatement of flann::KDTreeSingleIndex (leaf size 15, as pcl::KdTreeFLANN builds it) returns - scans and batched odometry objects
+ * created afterwards also build that tree (one thread, ~0.1-0.2 ms per scan) and every association walks it pair by pair: a parity mode for
+ * comparisons with a build of the reference, several times slower than production. Set it before the scans / objects are created. */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
        CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6, CFEAR_TUNE_MAX_CELLS = 7,
-       CFEAR_TUNE_REGISTRATION_ORDER = 8, CFEAR_TUNE_LARGE_SUBMAP_KERNEL = 9 };
+       CFEAR_TUNE_REGISTRATION_ORDER = 8, CFEAR_TUNE_LARGE_SUBMAP_KERNEL = 9, CFEAR_TUNE_NN_TIE_RULE = 10 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

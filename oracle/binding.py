@@ -68,7 +68,7 @@ def build(force=False):
 
 
 PERT = {"voxel_reverse": 1, "voxel_random": 2, "voxel_stdsort": 4, "sum_reverse": 8, "sum_pairwise": 16, "wsum_eigen_redux": 32,
-        "eig_jacobi": 64, "nn_tie_high": 128}
+        "eig_jacobi": 64, "nn_tie_high": 128, "nn_tie_flann": 256}
 _STDSORT = None
 
 
@@ -88,6 +88,17 @@ def set_perturbation(mask=0, seed=1):
         L.cfo_set_voxel_sorter(C.cast(_STDSORT.cfo_stdsort_perm, C.c_void_p))
     L.cfo_set_perturbation(C.c_uint(mask), C.c_uint64(seed))
     return mask
+
+
+def flann_nearest(pts, queries):
+    """cfo_flann_nearest: (indices, squared distances) of the restated FLANN 1-NN search"""
+    pts = np.ascontiguousarray(pts, dtype=np.float32); q = np.ascontiguousarray(queries, dtype=np.float32)
+    idx = np.zeros(len(q), dtype=np.int32); d = np.zeros(len(q), dtype=np.float32)
+    L = lib()
+    L.cfo_flann_nearest.restype = None
+    L.cfo_flann_nearest(pts.ctypes.data_as(C.c_void_p), C.c_int(len(pts)), q.ctypes.data_as(C.c_void_p), C.c_int(len(q)), idx.ctypes.data_as(C.c_void_p),
+                        d.ctypes.data_as(C.c_void_p))
+    return idx, d
 
 
 def lib():

@@ -327,6 +327,7 @@ struct cfo_scan {
   int gw, gh;
   int* gstart;
   int* gorder;
+  struct cfo_kdtree* kd; /* CFO_PERT_NN_TIE_FLANN: the kd-tree over mean_f, built on first use */
 };
 
 typedef struct { uint64_t key; } vkey_t;
@@ -595,9 +596,177 @@ cfo_scan* cfo_scan_create(const float* xyi, int n, const cfo_params* p, int brut
   return s;
 }
 
+/* ---- [3P-recall] flann::KDTreeSingleIndex<L2_Simple<float>> over 2-D float points, as pcl::KdTreeFLANN<pcl::PointXY> builds it
+ * (KDTreeSingleIndexParams(15): leaf_max_size 15, reorder = true) and searches it (nearestKSearch(k = 1): SearchParams(-1, eps 0),
+ * KNNSimpleResultSet). Restated from the published algorithm (flann/algorithms/kdtree_single_index.h, FLANN 1.8 / 1.9: divideTree,
+ * middleSplit_, planeSplit, computeInitialDistances, searchLevel; flann/util/result_set.h: KNNSimpleResultSet::addPoint), not from a
+ * source under /root/reference - the library is not vendored there. What it is for: exact-distance ties. A point replaces the best
+ * so far only if strictly nearer, so of several equidistant points the FIRST ONE VISITED is returned; the visiting order is the
+ * best-child-first descent over this tree. ---------------------------------------------------------------------------------------- */
+typedef struct { float low, high; } kd_interval;
+typedef struct { int left, right, divfeat, child1, child2; float divlow, divhigh; } kd_node; /* child1 < 0: leaf over vind[left, right) */
+typedef struct cfo_kdtree {
+  int n, nnodes, cap_nodes, root;
+  int* vind;      /* the permutation divideTree leaves behind */
+  float* data;    /* reordered copy: point vind[i] at row i (reorder_) */
+  const float* pts;
+  kd_node* nodes;
+  kd_interval root_bbox[2];
+} cfo_kdtree;
+static void kd_free(cfo_kdtree* t) { if (t) { free(t->vind); free(t->data); free(t->nodes); free(t); } }
+static void kd_minmax(const cfo_kdtree* t, const int* ind, int count, int dim, float* mn, float* mx) { /* computeMinMax */
+  *mn = t->pts[2 * ind[0] + dim]; *mx = *mn;
+  for (int i = 1; i < count; i++) {
+    const float v = t->pts[2 * ind[i] + dim];
+    if (v < *mn) *mn = v;
+    if (v > *mx) *mx = v;
+  }
+}
+static void kd_plane_split(const cfo_kdtree* t, int* ind, int count, int cutfeat, float cutval, int* lim1, int* lim2) { /* planeSplit */
+  int left = 0, right = count - 1;
+  for (;;) {
+    while (left <= right && t->pts[2 * ind[left] + cutfeat] < cutval) ++left;
+    while (left <= right && t->pts[2 * ind[right] + cutfeat] >= cutval) --right;
+    if (left > right) break;
+    { const int x = ind[left]; ind[left] = ind[right]; ind[right] = x; } ++left; --right;
+  }
+  *lim1 = left;
+  right = count - 1;
+  for (;;) {
+    while (left <= right && t->pts[2 * ind[left] + cutfeat] <= cutval) ++left;
+    while (left <= right && t->pts[2 * ind[right] + cutfeat] > cutval) --right;
+    if (left > right) break;
+    { const int x = ind[left]; ind[left] = ind[right]; ind[right] = x; } ++left; --right;
+  }
+  *lim2 = left;
+}
+static void kd_middle_split(const cfo_kdtree* t, int* ind, int count, int* index, int* cutfeat, float* cutval, const kd_interval* bbox) { /* middleSplit_ */
+  const float EPS = 0.00001f;
+  float max_span = bbox[0].high - bbox[0].low;
+  for (int i = 1; i < 2; i++) { const float span = bbox[i].high - bbox[i].low; if (span > max_span) max_span = span; }
+  float max_spread = -1;
+  *cutfeat = 0;
+  for (int i = 0; i < 2; i++) {
+    const float span = bbox[i].high - bbox[i].low;
+    if (span > (float)((1 - EPS) * max_span)) {
+      float mn, mx;
+      kd_minmax(t, ind, count, i, &mn, &mx);
+      const float spread = (float)(mx - mn);
+      if (spread > max_spread) { *cutfeat = i; max_spread = spread; }
+    }
+  }
+  const float split_val = (bbox[*cutfeat].low + bbox[*cutfeat].high) / 2;
+  float mn, mx;
+  kd_minmax(t, ind, count, *cutfeat, &mn, &mx);
+  if (split_val < mn) *cutval = mn;
+  else if (split_val > mx) *cutval = mx;
+  else *cutval = split_val;
+  int lim1, lim2;
+  kd_plane_split(t, ind, count, *cutfeat, *cutval, &lim1, &lim2);
+  if (lim1 > count / 2) *index = lim1;
+  else if (lim2 < count / 2) *index = lim2;
+  else *index = count / 2;
+}
+static int kd_divide(cfo_kdtree* t, int left, int right, kd_interval* bbox) { /* divideTree */
+  const int me = t->nnodes++;
+  if (right - left <= 15) {
+    t->nodes[me].child1 = t->nodes[me].child2 = -1; t->nodes[me].left = left; t->nodes[me].right = right;
+    for (int i = 0; i < 2; i++) bbox[i].low = bbox[i].high = t->pts[2 * t->vind[left] + i];
+    for (int k = left + 1; k < right; k++)
+      for (int i = 0; i < 2; i++) {
+        const float v = t->pts[2 * t->vind[k] + i];
+        if (bbox[i].low > v) bbox[i].low = v;
+        if (bbox[i].high < v) bbox[i].high = v;
+      }
+  } else {
+    int idx, cutfeat; float cutval;
+    kd_middle_split(t, t->vind + left, right - left, &idx, &cutfeat, &cutval, bbox);
+    t->nodes[me].divfeat = cutfeat;
+    kd_interval lb[2] = {bbox[0], bbox[1]}, rb[2] = {bbox[0], bbox[1]};
+    lb[cutfeat].high = cutval;
+    const int c1 = kd_divide(t, left, left + idx, lb);
+    rb[cutfeat].low = cutval;
+    const int c2 = kd_divide(t, left + idx, right, rb);
+    t->nodes[me].child1 = c1; t->nodes[me].child2 = c2;
+    t->nodes[me].divlow = lb[cutfeat].high; t->nodes[me].divhigh = rb[cutfeat].low;
+    for (int i = 0; i < 2; i++) {
+      bbox[i].low = lb[i].low < rb[i].low ? lb[i].low : rb[i].low;
+      bbox[i].high = lb[i].high > rb[i].high ? lb[i].high : rb[i].high;
+    }
+  }
+  return me;
+}
+static cfo_kdtree* kd_build(const float* pts, int n) { /* buildIndex */
+  cfo_kdtree* t = (cfo_kdtree*)calloc(1, sizeof(cfo_kdtree));
+  t->n = n; t->pts = pts;
+  t->vind = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  t->data = (float*)malloc(sizeof(float) * 2 * (size_t)(n > 0 ? n : 1));
+  t->nodes = (kd_node*)malloc(sizeof(kd_node) * (size_t)(2 * n + 2));
+  for (int i = 0; i < n; i++) t->vind[i] = i;
+  if (n == 0) { t->root = -1; return t; }
+  for (int i = 0; i < 2; i++) t->root_bbox[i].low = t->root_bbox[i].high = pts[i]; /* computeBoundingBox */
+  for (int k = 1; k < n; k++)
+    for (int i = 0; i < 2; i++) {
+      if (pts[2 * k + i] < t->root_bbox[i].low) t->root_bbox[i].low = pts[2 * k + i];
+      if (pts[2 * k + i] > t->root_bbox[i].high) t->root_bbox[i].high = pts[2 * k + i];
+    }
+  t->root = kd_divide(t, 0, n, t->root_bbox);
+  for (int i = 0; i < n; i++) { t->data[2 * i] = pts[2 * t->vind[i]]; t->data[2 * i + 1] = pts[2 * t->vind[i] + 1]; }
+  return t;
+}
+typedef struct { float worst; int index; } kd_result; /* KNNSimpleResultSet, capacity 1 */
+static void kd_search_level(const cfo_kdtree* t, kd_result* rs, const float* vec, int node, float mindistsq, float* dists) { /* searchLevel, epsError = 1 */
+  const kd_node* nd = &t->nodes[node];
+  if (nd->child1 < 0) {
+    const float worst_dist = rs->worst;
+    for (int i = nd->left; i < nd->right; ++i) {
+      float result = 0, diff; /* L2_Simple */
+      diff = vec[0] - t->data[2 * i]; result += diff * diff;
+      diff = vec[1] - t->data[2 * i + 1]; result += diff * diff;
+      if (result < worst_dist) { /* addPoint: if (dist >= worst_distance_) return; */
+        if (!(result >= rs->worst)) { rs->worst = result; rs->index = t->vind[i]; }
+      }
+    }
+    return;
+  }
+  const int idx = nd->divfeat;
+  const float val = vec[idx];
+  const float diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+  int best, other; float cut_dist;
+  if ((diff1 + diff2) < 0) { best = nd->child1; other = nd->child2; cut_dist = (val - nd->divhigh) * (val - nd->divhigh); }
+  else { best = nd->child2; other = nd->child1; cut_dist = (val - nd->divlow) * (val - nd->divlow); }
+  kd_search_level(t, rs, vec, best, mindistsq, dists);
+  const float dst = dists[idx];
+  mindistsq = mindistsq + cut_dist - dst;
+  dists[idx] = cut_dist;
+  if (mindistsq * 1.0f <= rs->worst) kd_search_level(t, rs, vec, other, mindistsq, dists);
+  dists[idx] = dst;
+}
+static int kd_nearest(const cfo_kdtree* t, float qx, float qy, float* dist_out) { /* findNeighbors */
+  if (t->n == 0) return -1;
+  const float vec[2] = {qx, qy};
+  float dists[2] = {0, 0}, distsq = 0; /* computeInitialDistances */
+  for (int i = 0; i < 2; i++) {
+    if (vec[i] < t->root_bbox[i].low) { dists[i] = (vec[i] - t->root_bbox[i].low) * (vec[i] - t->root_bbox[i].low); distsq += dists[i]; }
+    if (vec[i] > t->root_bbox[i].high) { dists[i] = (vec[i] - t->root_bbox[i].high) * (vec[i] - t->root_bbox[i].high); distsq += dists[i]; }
+  }
+  kd_result rs = {FLT_MAX, -1};
+  kd_search_level(t, &rs, vec, t->root, distsq, dists);
+  *dist_out = rs.worst;
+  return rs.index;
+}
+
+/* the restated FLANN search on its own (tests/test_oracle_sensitivity_cpu.py): 1-NN of nq query points among n 2-D float points */
+void cfo_flann_nearest(const float* pts, int n, const float* queries, int nq, int* idx_out, float* dist_out) {
+  cfo_kdtree* t = kd_build(pts, n);
+  for (int i = 0; i < nq; i++) { float d = FLT_MAX; idx_out[i] = kd_nearest(t, queries[2 * i], queries[2 * i + 1], &d); dist_out[i] = d; }
+  kd_free(t);
+}
+
 void cfo_scan_free(cfo_scan* s) {
   if (!s) return;
   free(s->pts); free(s->samples); free(s->cells); free(s->mean_f); free(s->gstart); free(s->gorder);
+  kd_free(s->kd);
   free(s);
 }
 int cfo_scan_size(const cfo_scan* s) { return s ? s->ncells : 0; }
@@ -611,7 +780,11 @@ int cfo_scan_closest(const cfo_scan* s, double px, double py, double d, int brut
   const float qx = (float)px, qy = (float)py;
   int best = -1;
   float bd = FLT_MAX;
-  if (brute || s->gw == 0) {
+  if (g_pert & CFO_PERT_NN_TIE_FLANN) { /* kd_cells.nearestKSearch(pnt, 1, ...) as FLANN does it */
+    cfo_scan* sm = (cfo_scan*)s;
+    if (!sm->kd) sm->kd = kd_build(s->mean_f, s->ncells);
+    best = kd_nearest(sm->kd, qx, qy, &bd);
+  } else if (brute || s->gw == 0) {
     for (int i = 0; i < s->ncells; i++) {
       const float dx = qx - s->mean_f[2 * i], dy = qy - s->mean_f[2 * i + 1];
       float d2 = dx * dx; d2 += dy * dy;

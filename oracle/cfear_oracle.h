@@ -69,11 +69,21 @@ void cfo_default_params(cfo_params* p);
  *   SUM_REVERSE / SUM_PAIRWISE  order in which a cell's weights, mean and covariance terms are added (pointnormal.cpp:13-33);
  *   WSUM_EIGEN_REDUX            only `w.sum()` (pointnormal.cpp:19) in the order of Eigen's vectorised redux (SSE2 packets);
  *   EIG_JACOBI                  the 2x2 eigen-decomposition by a Jacobi rotation instead of the closed form (:39-45);
- *   NN_TIE_HIGH                 exact-distance ties of the 1-NN search go to the highest cell index instead of the lowest. */
+ *   NN_TIE_HIGH                 exact-distance ties of the 1-NN search go to the highest cell index instead of the lowest;
+ *   NN_TIE_FLANN   [3P-recall]  the 1-NN search of GetClosestIdx (pointnormal.cpp:238-254) by a restatement of what it calls:
+ *       pcl::KdTreeFLANN<PointXY>::nearestKSearch -> flann::KDTreeSingleIndex (L2_Simple<float>, leaf_max_size 15, reorder, eps 0,
+ *       KNNSimpleResultSet of one): bounding-box middle split with the planeSplit partition, best-child-first descent, a point is
+ *       taken only if STRICTLY nearer than the best so far - so among exactly equidistant cells the first one the descent visits wins,
+ *       which is a property of the tree's layout, not of the cell index. Always a true nearest neighbour; equal to the brute-force
+ *       answer whenever the minimum is unique (tests/test_oracle_sensitivity_cpu.py). */
 enum { CFO_PERT_VOXEL_REVERSE = 1, CFO_PERT_VOXEL_RANDOM = 2, CFO_PERT_VOXEL_STDSORT = 4, CFO_PERT_SUM_REVERSE = 8,
-       CFO_PERT_SUM_PAIRWISE = 16, CFO_PERT_WSUM_EIGEN_REDUX = 32, CFO_PERT_EIG_JACOBI = 64, CFO_PERT_NN_TIE_HIGH = 128 };
+       CFO_PERT_SUM_PAIRWISE = 16, CFO_PERT_WSUM_EIGEN_REDUX = 32, CFO_PERT_EIG_JACOBI = 64, CFO_PERT_NN_TIE_HIGH = 128,
+       CFO_PERT_NN_TIE_FLANN = 256 };
 typedef void (*cfo_voxel_sorter)(uint32_t* voxel_idx, uint32_t* point_idx, int n);
 void cfo_set_perturbation(unsigned mask, uint64_t seed);
+/* CFO_PERT_NN_TIE_FLANN's search on its own: the 1-NN of nq queries (x, y floats) among n 2-D float points, by the restated
+ * flann::KDTreeSingleIndex (leaf 15, reorder, eps 0, KNNSimpleResultSet of one); idx_out / dist_out: nq entries */
+void cfo_flann_nearest(const float* pts, int n, const float* queries, int nq, int* idx_out, float* dist_out);
 unsigned cfo_get_perturbation(void);
 void cfo_set_voxel_sorter(cfo_voxel_sorter fn);
 

@@ -21,7 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 MODES = [["voxel_reverse"], ["voxel_random"], ["voxel_stdsort"], ["sum_reverse"], ["sum_pairwise"], ["wsum_eigen_redux"], ["eig_jacobi"], ["nn_tie_high"],
-         ["voxel_stdsort", "wsum_eigen_redux", "eig_jacobi", "nn_tie_high"]]  # the last: everything a PCL 1.9 / Eigen 3.3 build would plausibly do, together
+         ["voxel_stdsort", "wsum_eigen_redux", "eig_jacobi", "nn_tie_high"],  # everything a PCL 1.9 / Eigen 3.3 build would plausibly do, together
+         ["nn_tie_flann"],  # round 5: the tie order of a restated flann::KDTreeSingleIndex instead of lowest / highest index
+         ["voxel_stdsort", "nn_tie_flann"]]  # ... with PCL <= 1.9's intra-voxel order: the closest this oracle gets to an Ubuntu 18.04 build of the reference
+if os.environ.get("CFEAR_3P_MODES"):  # a subset, e.g. "nn_tie_flann;voxel_stdsort+nn_tie_flann"
+    MODES = [m.split("+") for m in os.environ["CFEAR_3P_MODES"].split(";")]
 CONFIGS = {  # the headline configuration (BASELINE configs[1]) and the reference's most demanding shipped one
     "cfear3_p2l_k12_s4": dict(),
     "cfear3_p2p_k40_s4": dict(k_strongest=40, cost=0),

@@ -85,3 +85,51 @@ def test_nn_tie_mode_only_matters_for_equal_float_means(oracle):
     if dup.any():
         assert np.any(hi[dup] > lo[dup])
         assert np.array_equal(m[hi], m[lo])
+
+
+def test_flann_restatement_returns_a_true_nearest_neighbour(oracle):
+    """CFO_PERT_NN_TIE_FLANN: the restated flann::KDTreeSingleIndex descent (oracle/cfear_oracle.c kd_*) against brute force on clouds of
+    cell means with exact duplicates, walls and clusters - the returned cell is always AT the minimum float distance, it IS the
+    brute-force cell whenever the minimum is unique, and among equidistant cells it is some cell of the tie (which one is the tree's
+    business: that is the point of the mode - and it is NOT always the lowest index)."""
+    rng = np.random.default_rng(5)
+    tie_not_lowest = 0
+    for trial in range(16):
+        n = int(rng.integers(1, 900)) if trial else 1
+        pts = rng.uniform(-80, 80, size=(n, 2)).astype(np.float32)
+        if trial % 3 == 0 and n > 20:  # exact duplicates (voxel centroids whose neighbourhoods hold the same weighted points)
+            pts[rng.integers(0, n, size=n // 4)] = pts[rng.integers(0, n, size=n // 4)]
+        if trial % 4 == 1:             # a wall: one coordinate constant
+            pts[: n // 2, 1] = np.float32(12.5)
+        if trial % 5 == 2:             # everything in one place
+            pts[:] = pts[0]
+        q = np.concatenate([pts[rng.integers(0, n, size=80)].astype(np.float64) + rng.normal(0, 0.7, size=(80, 2)),
+                            pts[rng.integers(0, n, size=40)].astype(np.float64),                                      # queries AT a cell mean
+                            0.5 * (pts[rng.integers(0, n, size=40)].astype(np.float64) + pts[rng.integers(0, n, size=40)]),  # midpoints
+                            rng.uniform(-200, 200, size=(20, 2))]).astype(np.float32)                                   # outside the bounding box
+        idx, dist = oracle.flann_nearest(pts, q)
+        for i in range(len(q)):
+            dx, dy = q[i, 0] - pts[:, 0], q[i, 1] - pts[:, 1]
+            d2 = dx * dx
+            d2 = d2 + dy * dy  # float32, the order of L2_Simple
+            assert 0 <= idx[i] < n and d2[idx[i]] == d2.min() and dist[i] == d2.min(), (trial, i, idx[i], int(np.argmin(d2)))
+            if np.sum(d2 == d2.min()) == 1:
+                assert idx[i] == int(np.argmin(d2))
+            else:
+                tie_not_lowest += int(idx[i] != int(np.argmin(d2)))
+    assert tie_not_lowest > 0
+
+
+def test_flann_mode_through_the_scan_search(oracle):
+    p = oracle.default_params(range_res=RR, res=3.0, weight_intensity=1)
+    s = oracle.Scan(_cloud(oracle), p)
+    cells = s.cells()
+    m = cells["mean"].astype(np.float32)
+    q = cells["mean"] + 0.3
+    lo = np.array([s.closest(x, y, 2.0) for x, y in q])
+    oracle.set_perturbation(["nn_tie_flann"])
+    fl = np.array([s.closest(x, y, 2.0) for x, y in q])
+    oracle.set_perturbation(0)
+    assert np.array_equal(lo < 0, fl < 0)
+    ok = lo >= 0
+    assert np.array_equal(m[fl[ok]], m[lo[ok]])  # the same float mean: the same cell or an exact duplicate of it
