@@ -180,7 +180,7 @@ def _addr(a):
     return a.ctypes.data
 
 
-TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER, TUNE_LARGE_SUBMAP_KERNEL, TUNE_NN_TIE_RULE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+TUNE_FILTER_OCCUPANCY, TUNE_FILTER_ROWS_PER_WAVE, TUNE_ODOMETRY_OVERLAP, TUNE_REPLAY_PERSISTENT_MAX, TUNE_FILTER_CUS, TUNE_REPEAT_SHORTCUT, TUNE_MAX_CELLS, TUNE_REGISTRATION_ORDER, TUNE_LARGE_SUBMAP_KERNEL, TUNE_NN_TIE_RULE, TUNE_VOXEL_ORDER = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 TUNE_DEFAULTS = {TUNE_ODOMETRY_OVERLAP: 0, TUNE_FILTER_CUS: 0, TUNE_MAX_CELLS: 0, TUNE_REGISTRATION_ORDER: 1, TUNE_LARGE_SUBMAP_KERNEL: 0}  # include/cfear_hip.h
 
 

@@ -130,6 +130,7 @@ int cfear_tune(cfear_ctx* ctx, int key, int value) {
     case CFEAR_TUNE_REGISTRATION_ORDER: ctx->tune_reg_order = value != 0; return CFEAR_OK;
     case CFEAR_TUNE_MAX_CELLS: ctx->tune_max_cells = value < 0 ? 0 : value; return CFEAR_OK;
     case CFEAR_TUNE_REPEAT_SHORTCUT: ctx->tune_repeat_shortcut = value != 0; return CFEAR_OK;
+    case CFEAR_TUNE_VOXEL_ORDER: ctx->tune_voxel_order = value == 1 ? 1 : 0; return CFEAR_OK;
     case CFEAR_TUNE_NN_TIE_RULE: ctx->tune_nn_tie = (value < 0 || value > 2) ? 0 : value; return CFEAR_OK;
     case CFEAR_TUNE_LARGE_SUBMAP_KERNEL: ctx->tune_large_kernel = (value < 0 || value > 2) ? 0 : value; return CFEAR_OK;
     case CFEAR_TUNE_REPLAY_PERSISTENT_MAX: ctx->tune_replay_persistent_max = value < 0 ? 0 : value; return CFEAR_OK;

@@ -42,6 +42,7 @@ struct cfear_ctx {
   int tune_reg_order = 1;  // batched odometry objects created afterwards launch their registration workgroups longest first (keys: the previous sweep's work)
   int tune_max_cells = 0;  // batched odometry: oriented surface points per scan the scan blocks / match scratch are sized for (0 = A * k: every filtered point)
   int tune_large_kernel = 0;  // batched odometry, submap_scan_size > 7: 0 = the 512-thread kernel of register_step_large.hip when the sequences fit the chip at one per compute unit, 1 = never, 2 = always
+  int tune_voxel_order = 0;  // per-call scans: 0 = a voxel's points summed in index order (production: the stable order), 1 = in the order libstdc++'s std::sort leaves them (PCL <= 1.9)
   int tune_nn_tie = 0;  // which of several exactly equidistant cells GetClosestIdx returns: 0 lowest index (production), 1 highest, 2 FLANN's kd-tree order (parity mode, slow)
   int tune_repeat_shortcut = 1;  // registration: an outer iteration that would repeat the previous one bit for bit is not recomputed (0: it is - tests)
   int tune_replay_persistent_max = 256;  // cfear_odometry_replay_host: up to this many sequences run as persistent workgroups (replay.hip)

@@ -90,6 +90,8 @@ struct FeatureScratch {
   int* rng;         // global [cap_points][8] candidate row ranges of every sample point
   double* part;     // global [7][cap_points] partial moments of the candidate chunks
   int* tmpi;        // global [2 * cap + 16] copies of vlist/vstart (only used when leaf < radius)
+  const int* vrank; const int* vperm;  // cfear_tune VOXEL_ORDER = 1 (per-call scans, general path): rank of every point in the order PCL <= 1.9's
+                    // std::sort leaves the VoxelGrid's points in, and the point at every rank; null: points of a voxel in index order
   int cap;          // capacity (entries) of order/vstart/vlist/rng/part
   int tab_voxels;   // cell_grid_block only: twice the ints the LDS region in `keys` holds
 };
@@ -666,7 +668,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
       const int ijk0 = (int)(floorf(xyi[3 * i] * inv) - (float)min_b0);
       const int ijk1 = (int)(floorf(xyi[3 * i + 1] * inv) - (float)min_b1);
       const uint64_t idx = (uint64_t)((long long)ijk0 + (long long)ijk1 * (long long)div0);
-      key = (idx << 32) | (uint64_t)(uint32_t)i;
+      key = (idx << 32) | (uint64_t)(uint32_t)(W.vrank ? W.vrank[i] : i);  // (inside a voxel: by point index, or by the given order)
     }
     g_keys[i] = key;
   }
@@ -683,7 +685,7 @@ __device__ __forceinline__ void features_block(ScanDev* __restrict__ S, int n, c
     int o = block_exclusive_scan<CFEAR_FEAT_BLOCK>(cnt, W.red_i, &nv);
     for (int i = i0; i < i1; i++) {
       const uint64_t k = g_keys[i];
-      g_order[i] = (int)(uint32_t)k;
+      g_order[i] = W.vperm ? W.vperm[(uint32_t)k] : (int)(uint32_t)k;
       if (i == 0 || (k >> 32) != (g_keys[i - 1] >> 32)) { g_vstart[o] = i; g_vlist[o] = (int)(k >> 32); o++; }
     }
     nv_out = nv;

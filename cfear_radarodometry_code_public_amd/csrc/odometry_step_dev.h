@@ -42,6 +42,7 @@ struct BlockScratch {
   double* match;    // [8][pair_cap]
   int* assoc;       // [3 * pair_cap]
   int cap_points, p2cap, pair_cap;
+  const int* vrank; const int* vperm;  // FeatureScratch::vrank / vperm (cfear_scan_create under cfear_tune VOXEL_ORDER = 1; null otherwise)
 };
 
 struct SeqState {  // OdometryKeyframeFuser members (odometrykeyframefuser.h:203-260) for one sequence
@@ -84,6 +85,7 @@ __device__ __forceinline__ FeatureScratch make_fscratch(const BlockScratch& B, u
   W.vcur = B.vcur; W.lds = false; W.tab_voxels = 0;
   W.rng = B.rng; W.part = B.part; W.tmpi = B.tmpi;
   W.cap = B.cap_points;
+  W.vrank = B.vrank; W.vperm = B.vperm;
   W.samples = B.samples;
   W.red_i = reinterpret_cast<int*>(lds + FeatLdsC::red_i);
   W.red_f = reinterpret_cast<float*>(lds + FeatLdsC::red_f);
@@ -108,7 +110,7 @@ __device__ __forceinline__ void features_dispatch(ScanDev* S, int n, const Featu
                                                   unsigned char* lds, PhaseTimer* pt, const float* bounds, bool zeroed, bool byte_intensities,
                                                   const PointRegs& PR, bool registers_only = false) {
   const FeatureScratch W = make_fscratch(B, lds);
-  if (!(byte_intensities && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR))) {
+  if (!(byte_intensities && !W.vrank && features_block_c(S, n, P, W, lds, pt, bounds, zeroed, PR))) {  // (a given voxel order: the general path)
     // registers_only (a constant of the call site): the cloud pass may have left the cloud in registers only (byte intensities)
     if (registers_only && PR.rounds > 0) point_regs_to_global(PR, S->xyi);  // block-uniform
     features_block(S, n, P, W, next_pow2(n), pt, bounds);

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <new>
 
 #include "common.h"
@@ -280,6 +281,7 @@ BlockScratch scratch_header(unsigned char* d_base, int cap_points, int pair_cap)
   B.match = reinterpret_cast<double*>(d_base + L.match);
   B.assoc = reinterpret_cast<int*>(d_base + L.assoc);
   B.cap_points = cap_points; B.p2cap = L.p2cap; B.pair_cap = pair_cap;
+  B.vrank = nullptr; B.vperm = nullptr;
   return B;
 }
 
@@ -600,6 +602,54 @@ int cfear_compensate(cfear_ctx* ctx, cfear_cloud* c, const double motion_xyt[3],
 }
 
 // ---- scans -------------------------------------------------------------------------------------
+}  // extern "C"
+// cfear_tune VOXEL_ORDER = 1: the order PCL <= 1.9 leaves the points of a VoxelGrid voxel in (pointnormal.cpp:277-280 -> pcl::VoxelGrid::applyFilter).
+// pcl/filters/impl/voxel_grid.hpp fills a vector of (voxel index, point index) in point order and calls std::sort on it with an operator<
+// that compares the voxel index ONLY - an unstable sort, so the order of a voxel's points, and with it the last bit of its float centroid,
+// is whatever libstdc++'s introsort leaves. Reproducing that needs the same call on the same sequence: the cloud comes to the host, the
+// voxel indices are formed with the kernel's (= PCL's) float arithmetic, std::sort runs here, and the device gets every point's rank
+// (features_dev.h: the sort key inside a voxel) and the point at every rank. Per-call scans only (a host round trip per scan: parity mode).
+namespace {
+struct cloud_point_index_idx {
+  unsigned int idx, cloud_point_index;
+  bool operator<(const cloud_point_index_idx& p) const { return idx < p.idx; }
+};
+int voxel_order_stdsort(cfear_ctx* ctx, const cfear_cloud* cloud, int cap_points, int** d_out /* [2][n]: rank, perm */) {
+  *d_out = nullptr;
+  int n = 0;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&n, cloud->d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  n = std::min(n, std::min(cloud->cap, cap_points));
+  if (n <= 0) return CFEAR_OK;
+  std::vector<float> xyi(3 * (size_t)n);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyi.data(), cloud->d_xyi, sizeof(float) * xyi.size(), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const float leaf = (float)((double)(float)ctx->par.res / ctx->par.downsample_factor), inv = 1.0f / leaf;  // features_block
+  float mnx = 3.4e38f, mxx = -3.4e38f, mny = 3.4e38f, mxy = -3.4e38f;
+  for (int i = 0; i < n; i++) {
+    const float x = xyi[3 * (size_t)i], y = xyi[3 * (size_t)i + 1];
+    mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+  }
+  const int min_b0 = (int)floorf(mnx * inv), max_b0 = (int)floorf(mxx * inv), min_b1 = (int)floorf(mny * inv);
+  const int div0 = max_b0 - min_b0 + 1;
+  std::vector<cloud_point_index_idx> v((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const int ijk0 = (int)(floorf(xyi[3 * (size_t)i] * inv) - (float)min_b0), ijk1 = (int)(floorf(xyi[3 * (size_t)i + 1] * inv) - (float)min_b1);
+    v[(size_t)i].idx = (unsigned int)(ijk0 + ijk1 * div0); v[(size_t)i].cloud_point_index = (unsigned int)i;
+  }
+  std::sort(v.begin(), v.end(), std::less<cloud_point_index_idx>());
+  std::vector<int> rp(2 * (size_t)n);
+  for (int r = 0; r < n; r++) { rp[(size_t)v[(size_t)r].cloud_point_index] = r; rp[(size_t)n + r] = (int)v[(size_t)r].cloud_point_index; }
+  int* d = nullptr;
+  if (hipMalloc(&d, sizeof(int) * rp.size()) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc voxel order");
+  hipError_t e = hipMemcpyAsync(d, rp.data(), sizeof(int) * rp.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (rp is a local)
+  if (e != hipSuccess) { (void)hipFree(d); return cfear_fail(ctx, CFEAR_ERR_HIP, "voxel order upload", e); }
+  *d_out = d;
+  return n;
+}
+}  // namespace
+extern "C" {
 int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** scan) {
   if (!ctx || !cloud || !scan) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_create: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -618,10 +668,16 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
   const ScanDev h = scan_header(s->d_block, cap, cap, true, ctx->tune_nn_tie == 2);
   ScanDev back;
+  int* d_vorder = nullptr;
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);  // h lives until the synchronize below
   if (e == hipSuccess) {
     const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
-    const BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
+    BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
+    if (ctx->tune_voxel_order == 1) {  // PCL <= 1.9's intra-voxel order (parity mode): ranks from a host std::sort
+      const int nv = voxel_order_stdsort(ctx, cloud, cap, &d_vorder);
+      if (nv < 0) { (void)hipFree(s->d_block); delete s; return nv; }
+      if (d_vorder) { B.vrank = d_vorder; B.vperm = d_vorder + nv; }
+    }
     const FeatureParams P = feature_params(ctx);
     hipLaunchKernelGGL(features_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, reinterpret_cast<ScanDev*>(s->d_block), cloud->d_xyi,
                        cloud->d_n, P, B);
@@ -630,6 +686,7 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
   if (e == hipSuccess) e = hipMemcpyAsync(&back, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (d_vorder) (void)hipFree(d_vorder);
   if (e != hipSuccess) {
     (void)hipFree(s->d_block);
     delete s;
@@ -1035,6 +1092,11 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   if (rc != CFEAR_OK) return rc;
   cfear_odometry* o = new (std::nothrow) cfear_odometry();
   if (!o) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "odometry alloc");
+  if (ctx->tune_voxel_order != 0) {
+    delete o;
+    return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "odometry_create: cfear_tune VOXEL_ORDER = 1 (PCL <= 1.9's std::sort order) needs a host round trip per scan: per-call scans only "
+                      "(cfear_scan_create; the mirror classes of cfear_host.hpp use it)");
+  }
   const int B = n_sequences, s = ctx->par.submap_scan_size;
   o->filter = ctx->par.filter_type;
   o->large_kernel = ctx->tune_large_kernel;

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
            "       [--min_distance 2.5] [--submap_scan_size 3] [--weight_intensity 1] [--k_strongest 12] [--z-min 65]\n"
            "       [--radar_ccw 0] [--disable_compensate 0] [--cost_type P2L] [--loss_type Huber] [--loss_limit 0.1]\n"
            "       [--covar_scale 1] [--regularization 1] [--weight_option 0] [--registered_min_keyframe_dist 1.5]\n"
-           "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR]\n"
+           "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR] [--nn-tie 0|1|2] [--voxel-order 0|1]\n"
            "       [--replay 1]   whole recording through cfear_odometry_replay_host (pieces of 256 sweeps in pinned memory, no\n"
            "                      host round trip per sweep) instead of one CallbackOffline + pointcloudCallback per sweep\n");
     return argc < 2;
@@ -72,6 +72,10 @@ int main(int argc, char** argv) {
   p.submap_scan_size = par.submap_scan_size;
   try {
     DevicePtr dev(new Device(p, A, R, atoi(arg(argc, argv, "--device", "0"))));
+    // parity modes (include/cfear_hip.h cfear_tune): --nn-tie 2 = FLANN's kd-tree order among equidistant cells, --voxel-order 1 = PCL <= 1.9's
+    // std::sort order inside a voxel - together what an Ubuntu 18.04 build of the reference does where its sources leave the choice to a library
+    dev->check(cfear_tune(dev->ctx(), CFEAR_TUNE_NN_TIE_RULE, atoi(arg(argc, argv, "--nn-tie", "0"))), "cfear_tune");
+    if (!atoi(arg(argc, argv, "--replay", "0"))) dev->check(cfear_tune(dev->ctx(), CFEAR_TUNE_VOXEL_ORDER, atoi(arg(argc, argv, "--voxel-order", "0"))), "cfear_tune");
     if (atoi(arg(argc, argv, "--replay", "0"))) {
       // maximum-rate replay: the same parameters the two classes would apply, set once; the loop of offline_odometry.cpp:103-125
       // runs on the device sweep after sweep, the poses of a piece come back together

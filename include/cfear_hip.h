@@ -122,10 +122,16 @@ int cfear_synchronize(cfear_ctx* ctx);
  * (DESIGN.md section 2). 0 = the lowest cell index (production: a uniform grid search); 1 = the highest (the other end, for sensitivity runs);
  * 2 = what a restatement of flann::KDTreeSingleIndex (leaf size 15, as pcl::KdTreeFLANN builds it) returns - scans and batched odometry objects
  * created afterwards also build that tree (one thread, ~0.1-0.2 ms per scan) and every association walks it pair by pair: a parity mode for
- * comparisons with a build of the reference, several times slower than production. Set it before the scans / objects are created. */
+ * comparisons with a build of the reference, several times slower than production. Set it before the scans / objects are created.
+ * VOXEL_ORDER (default 0) - the second such knob: the order in which the points of a VoxelGrid voxel are added up for its float centroid
+ * (pointnormal.cpp:277-280). PCL sorts (voxel index, point) pairs on the voxel index alone with an UNSTABLE sort, so the order inside a voxel -
+ * and the centroid's last bit, which now and then flips a point across the strict d^2 < r^2 of the radius search - belongs to the sort
+ * routine: std::sort up to PCL 1.9 (Ubuntu 18.04), boost integer_sort from 1.10. 0 = by point index (production: what a stable sort gives);
+ * 1 = exactly what libstdc++'s std::sort leaves, computed on the host by the same call on the same sequence - per-call scans only
+ * (cfear_scan_create; batched odometry objects refuse the mode: it costs a host round trip per scan). */
 enum { CFEAR_TUNE_FILTER_OCCUPANCY = 1, CFEAR_TUNE_FILTER_ROWS_PER_WAVE = 2, CFEAR_TUNE_ODOMETRY_OVERLAP = 3,
        CFEAR_TUNE_REPLAY_PERSISTENT_MAX = 4, CFEAR_TUNE_FILTER_CUS = 5, CFEAR_TUNE_REPEAT_SHORTCUT = 6, CFEAR_TUNE_MAX_CELLS = 7,
-       CFEAR_TUNE_REGISTRATION_ORDER = 8, CFEAR_TUNE_LARGE_SUBMAP_KERNEL = 9, CFEAR_TUNE_NN_TIE_RULE = 10 };
+       CFEAR_TUNE_REGISTRATION_ORDER = 8, CFEAR_TUNE_LARGE_SUBMAP_KERNEL = 9, CFEAR_TUNE_NN_TIE_RULE = 10, CFEAR_TUNE_VOXEL_ORDER = 11 };
 int cfear_tune(cfear_ctx* ctx, int key, int value);
 
 /* ---- Stage 1: StructuredKStrongest (radar_filters.cpp:198-298) -----------------------------

@@ -165,3 +165,41 @@ def test_cpp_mirror_classes_against_oracle(oracle, tmp_path):
     assert out["raw"]["nn5"] == int(np.argmin(d5))
     # the transformed-copy constructor: same number of cells, the moved cell 0 is its own nearest neighbour
     assert out["moved"]["cells"] == scans[2].size and out["moved"]["nn0"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,pert", [(["--voxel-order", "1"], ["voxel_stdsort"]), (["--voxel-order", "1", "--nn-tie", "2"], ["voxel_stdsort", "nn_tie_flann"])])
+def test_offline_odometry_in_the_parity_modes_follows_the_perturbed_oracle(oracle, tmp_path, flags, pert):
+    """The drop-in route (mirror classes: one cfear_scan_create per sweep) with the two third-party choices switched to what an Ubuntu 18.04
+    build of the reference does - PCL <= 1.9's std::sort order inside a VoxelGrid voxel (cfear_tune VOXEL_ORDER: the same std::sort call on
+    the host) and FLANN's kd-tree order among equidistant cells (NN_TIE_RULE 2) - against the oracle in the same modes, every sweep of a
+    street-canyon drive on which both choices change the trajectory (sweeps 94 and 25 on); the production modes must NOT follow it."""
+    exe = build_harness()
+    T, A, R = 200, 400, 3360
+    imgs = np.empty((T, A, R), dtype=np.uint8)
+    for t0, chunk in synth.drive_chunks(T, "canyon", 3, 5, A, R, RR, ccw=False):
+        imgs[t0:t0 + len(chunk)] = chunk
+    f = tmp_path / "sweeps.u8"
+    imgs.tofile(f)
+    kw = dict(range_res=RR, k_strongest=12, z_min=60.0, res=3.0, weight_intensity=1, weight_opt=4, compensate=1, radar_ccw=0, cost=1, loss=1, loss_limit=0.1,
+              submap_scan_size=4, regularization=1.0)
+    est = {}
+    for name, fl in (("mode", flags), ("plain", [])):
+        d = tmp_path / name
+        d.mkdir()
+        args = [exe, "--frames", str(f), "--range-res", "0.0595238", "--res", "3.0", "--submap_scan_size", "4", "--z-min", "60", "--weight_option", "4",
+                "--est_directory", str(d)] + fl
+        r = subprocess.run(args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        e = np.loadtxt(d / "est_00.txt")
+        est[name] = np.stack([e[:, 3], e[:, 7], np.arctan2(e[:, 4], e[:, 0])], axis=1)
+    oracle.set_perturbation(pert)
+    try:
+        fu = oracle.Fuser(oracle.default_params(**kw))
+        exp = np.array([fu.process_polar(imgs[t]) for t in range(T)])
+    finally:
+        oracle.set_perturbation(0)
+    d = np.abs(est["mode"] - exp)
+    assert np.all(d[:, :2] < 1e-4 + 5e-7) and np.all(d[:, 2] < 1e-5 + 2e-6), (int(np.argmax(d.max(1))), d.max(0))
+    # the production order does not reproduce that run: it is off by more than the output's six decimals where the mode is not
+    assert np.abs(est["plain"] - exp).max() > 1e-5 > d.max() and np.abs(est["plain"] - est["mode"]).max() > 1e-5
