@@ -55,7 +55,7 @@ CELL_DTYPE = np.dtype([
 class RegSummary(C.Structure):
     _fields_ = [
         ("success", C.c_int32), ("usable", C.c_int32), ("outer_iterations", C.c_int32),
-        ("num_residuals", C.c_int32), ("num_residual_blocks", C.c_int32), ("reserved", C.c_int32),
+        ("num_residuals", C.c_int32), ("num_residual_blocks", C.c_int32), ("assoc_path", C.c_int32),
         ("final_cost", C.c_double), ("score", C.c_double),
         ("inner_iterations", C.c_int32 * CFEAR_MAX_OUTER), ("termination", C.c_int32 * CFEAR_MAX_OUTER),
         ("outer_cost", C.c_double * CFEAR_MAX_OUTER), ("outer_pose", (C.c_double * 3) * CFEAR_MAX_OUTER),
@@ -76,7 +76,7 @@ EXPORTS = [
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_cloud_device", "cfear_odometry_step_host", "cfear_odometry_poses",
     "cfear_odometry_replay_host", "cfear_odometry_replay_device", "cfear_host_alloc", "cfear_host_free",
-    "cfear_odometry_covariances", "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
+    "cfear_odometry_covariances", "cfear_odometry_status", "cfear_odometry_summary", "cfear_odometry_profile", "cfear_odometry_profile_read", "cfear_odometry_profile_read_stages", "cfear_odometry_phase_times", "cfear_time_kstrongest",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
         "cfear_odometry_step_cloud_device": (C.c_int, [vp, vp, f32p, C.c_int, i32p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_covariances": (C.c_int, [vp, vp, f64p]),
+        "cfear_odometry_status": (C.c_int, [vp, vp]),
         "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_odometry_replay_device": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -566,6 +567,10 @@ class Odometry:
         out = np.zeros((self.B, 3))
         self._ctx._check(self._ctx._L.cfear_odometry_poses(self._ctx._h, self._h, out.ctypes.data), "cfear_odometry_poses")
         return out
+
+    def status(self):
+        """raises CfearError (rc=-6) if a scan of this object was truncated (cfear_odometry_status)"""
+        self._ctx._check(self._ctx._L.cfear_odometry_status(self._ctx._h, self._h), "cfear_odometry_status")
 
     def covariances(self):
         """cov_current of every sequence after the last sweep: [B, 6, 6]"""

@@ -1626,6 +1626,14 @@ int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* o, double* cov6) 
   return odo_capacity_check(ctx, o, "odometry_covariances");
 }
 
+int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* o) {
+  if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_status: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return odo_capacity_check(ctx, o, "odometry_status");
+}
+
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* o, int sequence, cfear_reg_summary* summary, int* n_cells,
                            int* n_keyframes) {
   if (!ctx || !o || sequence < 0 || sequence >= o->B) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_summary: bad argument");

@@ -183,7 +183,8 @@ struct RegIo {  // where the controller reads/writes the caller-visible data
 struct RegShared {
   // command published by the controller (wave 0) to all waves
   int cmd, itr, M, state;
-  int lds_match, pad_a;  // where the compacted matches live: 1 the LDS match array (M <= match_lds_cap(cost)), 2 its capacity there and the rest in memory, 0 memory
+  int lds_match, assoc_path;  // assoc_path: which association path the last build took (cfear_reg_summary::reserved: 1 one block of cells against <= 4 keyframes,
+                              // 2 (group, cell) items dealt densely, 3 pair ranges - the general path); lds_match: where the compacted matches live: 1 the LDS match array (M <= match_lds_cap(cost)), 2 its capacity there and the rest in memory, 0 memory
   double x[3];  // parameters to evaluate at (EVAL) / current pose of the last scan (BUILD)
   double c, s;  // cos/sin of x[2], computed once by the controller
   double cur_c, cur_s, prev_c, prev_s;  // cos/sin of xcur[2] and prev_par[2]: the values published with the evaluation that produced
@@ -1032,6 +1033,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
   // the grouped path parks four ints + two ints of positions per (group, source cell) in W.assoc
   const bool can_park = 6 * (long long)ngroups * nsrc <= (long long)sh->rw.acap && (reinterpret_cast<uintptr_t>(sh->rw.assoc) & 15) == 0;
   bool done = false;
+  int assoc_path = 3;
   const int tie_rule = sh->rp.nn_tie;  // (block-uniform) a non-production tie rule: the general path below
   if (tie_rule == 0 && nk <= 4 && nsrc <= nt) {  // one group of keyframes, one block of cells: the matches stay in registers
     const AssocBlock R = assoc_block(src, sh, 0, nk, nsrc, itr, 0, 0, false);
@@ -1040,7 +1042,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
     M = (int)(t0 + t1 + t2 + t3);
     mode = M <= lcap ? 1 : 2;
     (void)emit_block<KCOST>(scans, src, sh, 0, nk, nsrc, 0, 0, false, R.a, R.e, (t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48), mode);
-    done = true;
+    done = true; assoc_path = 1;
   } else if (tie_rule == 0 && can_park && (long long)nk * nsrc <= 65535 && nk <= 64) {
     // several blocks of cells and / or several groups of four keyframes (a submap of 5 .. 63 keyframes: the reference's s10 and s50
     // presets; a dense scan against four): the items (group g of four keyframes, source cell j), numbered g * nsrc + j, are dealt to
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       const int4 v = park[it];
       if (v.x >= 0 || v.y >= 0 || v.z >= 0 || v.w >= 0) emit_item<KCOST>(scans, src, sh, nsrc, 4 * g, min(4, nk - 4 * g), j, v, gt[16 + g] + ppos[it], mode);
     }
-    done = true;
+    done = true; assoc_path = 2;
   }
   if (!done) {  // anything else (thousands of cells per scan): contiguous pair ranges per thread, associations parked in global memory
     const double curr_radius = (itr == 1) ? 2 * sh->rp.assoc_radius : sh->rp.assoc_radius;  // :222
@@ -1121,7 +1123,7 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
       if (ti >= 0) { emit_match(scans, src, sh, nsrc, p, ti, o, mode == 1 || o < lcap); o++; }
     }
   }
-  if (tid == 0) sh->lds_match = mode;
+  if (tid == 0) { sh->lds_match = mode; sh->assoc_path = assoc_path; }
   __syncthreads();
   return M;
 }
@@ -1224,6 +1226,7 @@ __device__ __noinline__ void ctl_finish(LRegShared* sh, bool have_cov, const LNo
     if (io.out) {
       io.out->success = ret; io.out->usable = sh->success ? 1 : 0; io.out->outer_iterations = sh->itr;
       io.out->num_residuals = sh->nres; io.out->num_residual_blocks = sh->M; io.out->final_cost = sh->ss.final_cost;
+      io.out->assoc_path = sh->assoc_path;
       io.out->score = sh->success ? sh->ss.final_cost / sh->nres : 0.0;
     }
     sh->ret = ret;
@@ -1506,7 +1509,7 @@ __device__ inline int register_block(ScanDev* const* scans, int n, double* poses
   if (tid == 64) { sh->srs = scans[n - 1]->rsrc; sh->scc = (long long)scans[n - 1]->cap_cells; }
   if (tid == 0 && out) {
     out->success = 0; out->usable = 0; out->outer_iterations = 0; out->num_residuals = 0; out->num_residual_blocks = 0;
-    out->reserved = 0; out->final_cost = 0; out->score = 0;
+    out->assoc_path = 0; out->final_cost = 0; out->score = 0;
   }
   if (out)  // one thread per outer iteration (448 stores by a single thread were a measurable part of the start-up)
     for (int i = tid; i < CFEAR_MAX_OUTER; i += CFEAR_REG_BLOCK) { out->inner_iterations[i] = 0; out->termination[i] = 0; out->outer_cost[i] = 0; out->outer_pose[i][0] = out->outer_pose[i][1] = out->outer_pose[i][2] = 0; }

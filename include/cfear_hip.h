@@ -226,7 +226,9 @@ typedef struct cfear_reg_summary {
   int32_t outer_iterations; /* itr_ as documented at n_scan_normal.cpp:161 */
   int32_t num_residuals;    /* problem_->NumResiduals() of the last problem */
   int32_t num_residual_blocks;
-  int32_t reserved;
+  int32_t assoc_path;       /* diagnostic, no reference counterpart: which association path the last problem build took - 1 = one block of source
+                               cells against <= 4 keyframes (matches in registers), 2 = (group of four keyframes, cell) items dealt densely
+                               (large submaps, dense scans), 3 = pair ranges per thread (the general path; also every NN_TIE_RULE != 0) */
   double final_cost;        /* summary_.final_cost */
   double score;             /* getScore() */
   int32_t inner_iterations[CFEAR_MAX_OUTER]; /* summary_.iterations.size() per outer iteration */
@@ -304,6 +306,10 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt)
  * Register() (GetCovariance), the identity FormatScans starts from when the registration had no usable solution, zeros before
  * the second sweep. (The cost-sampling variant, estimate_cov_by_sampling, is the per-call cfear_cov_by_sampling.) Synchronises. */
 int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* odo, double* cov6);
+/* Has any scan of this object been truncated - more oriented surface points than CFEAR_TUNE_MAX_CELLS, or a cloud with more points than the object
+ * holds? Synchronises the context stream; returns CFEAR_OK or CFEAR_ERR_CAPACITY (with the message the reading calls give). For callers of the
+ * asynchronous cfear_odometry_replay_device, which read their records on the device and never pass through poses / summary / replay_host. */
+int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* odo);
 /* Last Register() summary / cell count / keyframe count of one sequence (debug + parity tests). */
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);

@@ -94,6 +94,7 @@ def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.059
     ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
     odo = ctx.odometry(B, max_cells=max_cells)
     cmax = rmax = 0
+    paths = set()
     gens = [synth.drive_chunks(T, kind, 10 + q, 20 + q, A, R, rr, ccw=False) for q in range(B)]
     frames = np.empty((T, B, A, R), dtype=np.uint8)
     for q, g in enumerate(gens):
@@ -116,6 +117,8 @@ def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.059
                 S, nc, nk = odo.summary(q)
                 g = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(max(int(S.outer_iterations), 0), 8)]], int(S.num_residuals), nk, nc)
                 pose = got[q]
+                if t > 0:
+                    paths.add(int(S.assoc_path))
             else:
                 r = recs[t, q]
                 g = (int(r["outer_iterations"]), [int(v) for v in r["inner_iterations"][:min(max(int(r["outer_iterations"]), 0), 8)]], int(r["num_residuals"]),
@@ -126,7 +129,7 @@ def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.059
             assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
             kmax = max(kmax, e[3]); cmax = max(cmax, e[4]); rmax = max(rmax, e[2])
     if stats is not None:
-        stats.update(cells_max=cmax, residuals_max=rmax, keyframes_max=kmax)
+        stats.update(cells_max=cmax, residuals_max=rmax, keyframes_max=kmax, assoc_paths=sorted(paths))
     odo.release()
     ctx.close()
     return kmax

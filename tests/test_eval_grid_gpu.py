@@ -102,6 +102,8 @@ def test_resolution_dense_scans_take_several_blocks_of_source_cells(oracle, res,
     drive_parity.run_batched(oracle, p, "thicket", max(int(40 * SCALE), 8), route=route, max_cells=max_cells, stats=st)
     assert st["cells_max"] > 1100, st
     assert st["residuals_max"] > 900, st
+    if route == "step":
+        assert st["assoc_paths"] == [2], st  # several blocks of source cells: the grouped path, not the pair ranges
 
 
 def test_resolution_dense_scans_replay_persistent(oracle):

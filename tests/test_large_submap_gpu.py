@@ -63,8 +63,11 @@ _batched_parity = drive_parity.run_batched
 ])
 def test_large_submap_batched_route_matches_oracle(oracle, name, kind, sweeps, params, route):
     """batched route: features_step_kernel + register_step_kernel per sweep, three sequences side by side"""
-    kmax = _batched_parity(oracle, params, kind, sweeps, route=route)
+    st = {}
+    kmax = _batched_parity(oracle, params, kind, sweeps, route=route, stats=st)
     assert kmax <= params["submap_scan_size"]  # the ring never exceeds submap_scan_size
+    if route == "step":  # which association path ran (cfear_reg_summary::assoc_path): the grouped one once there are more than four keyframes -
+        assert 3 not in st["assoc_paths"] and (2 in st["assoc_paths"]) == (kmax > 4), st  # never the pair-by-pair general path
     if sweeps >= 3 * params["submap_scan_size"]:
         assert kmax == params["submap_scan_size"]
 
@@ -137,6 +140,8 @@ def test_max_cells_capacity_is_loud_and_otherwise_invisible():
         odo.poses()
     with pytest.raises(capi.CfearError, match="rc=-6"):
         odo.summary(0)
+    with pytest.raises(capi.CfearError, match=r"rc=-6.*odometry_status"):  # the call for users of the asynchronous device-side replay
+        odo.status()
     odo.reset()  # a reset clears the condition
     odo.release()
     with pytest.raises(capi.CfearError, match=r"rc=-5.*sequences fit.*CFEAR_TUNE_MAX_CELLS"):

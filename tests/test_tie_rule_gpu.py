@@ -76,8 +76,11 @@ def test_batched_fuser_follows_the_rule_at_every_sweep(oracle, rule):
                 g = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(max(int(S.outer_iterations), 0), 8)]], int(S.num_residuals), nk, nc)
                 if t > 0:
                     assert g == e, (t, q, g, e)
+                    assert S.assoc_path == 3  # the rule runs in the general path
                 assert np.all(np.abs(got[q][:2] - exp[:2]) < 1e-4) and abs(got[q][2] - exp[2]) < 1e-5, (t, q, got[q], exp)
                 S0 = odo0.summary(q)[0]
+                if t > 0:
+                    assert S0.assoc_path in (1, 2)  # (the street canyon has more than 256 cells per scan: blocks of source cells)
                 differs_from_production += int(S0.num_residuals != S.num_residuals or np.abs(got0[q] - got[q]).max() > 1e-6)
     finally:
         oracle.set_perturbation(0)
