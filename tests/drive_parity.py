@@ -83,7 +83,7 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
     return out
 
 
-def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.0595238), persistent_max=0, route="step", max_cells=None, stats=None):
+def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.0595238), persistent_max=0, route="step", max_cells=None, stats=None, large_kernel=None):
     """B sequences (different drives) through the batched route - cfear_odometry_step_host, or cfear_odometry_replay_host with the
     persistent workgroups switched off (two launches per sweep) - against B oracle fusers, every sweep. stats: optional dict that
     receives the largest cell / residual counts seen (what a test asserts to know which code path it drove)"""
@@ -92,7 +92,7 @@ def run_batched(oracle, params, kind, T, B=3, A=400, R=3360, rr=np.float32(0.059
     fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
     ctx = capi.Context(capi.default_params(**kw), A, R)
     ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
-    odo = ctx.odometry(B, max_cells=max_cells)
+    odo = ctx.odometry(B, max_cells=max_cells, large_kernel=large_kernel)
     cmax = rmax = 0
     paths = set()
     gens = [synth.drive_chunks(T, kind, 10 + q, 20 + q, A, R, rr, ccw=False) for q in range(B)]

@@ -72,6 +72,22 @@ def test_large_submap_batched_route_matches_oracle(oracle, name, kind, sweeps, p
         assert kmax == params["submap_scan_size"]
 
 
+@pytest.mark.parametrize("name,kind,sweeps,params,large_kernel", [
+    ("s10_p2p", "canyon", 60, S10_P2P, 1),   # the 256-thread shape compiled for 64 scans (what a batch of more sequences than compute units runs)
+    ("s10_p2d", "blocks", 60, S10_P2D, 1),
+    ("s50_cfear3", "canyon", 130, S50, 1),
+    ("s8_p2l", "blocks", 60, dict(SWEEP, cost=1, submap_scan_size=8), 2),  # register_step_large.hip (forced; the default for these three sequences anyway)
+    ("s10_p2d", "canyon", 60, S10_P2D, 2),
+])
+def test_large_submap_both_kernel_shapes_match_oracle(oracle, name, kind, sweeps, params, large_kernel):
+    """cfear_tune LARGE_SUBMAP_KERNEL: with more than seven keyframes the batched step has two registration kernels (256 threads x three
+    per unit compiled for 64 scans; 512 threads with a unit to itself) and picks by the number of sequences and the submap size - both
+    against the oracle's fuser at every sweep, whatever the default would have picked for three sequences"""
+    st = {}
+    kmax = drive_parity.run_batched(oracle, params, kind, sweeps, route="step", stats=st, large_kernel=large_kernel)
+    assert kmax <= params["submap_scan_size"] and 3 not in st["assoc_paths"], st
+
+
 def test_repeat_shortcut_off_gives_identical_results():
     """An outer iteration that would repeat the previous one bit for bit is not recomputed (ctl_lm_done); with the shortcut
     switched off (cfear_tune REPEAT_SHORTCUT = 0) the iteration runs again - and every summary field, pose and covariance of a
