@@ -135,6 +135,15 @@ __global__ __launch_bounds__(BLOCK_F, 4) void features_step_kernel(const uint32_
   __shared__ __attribute__((aligned(16))) unsigned char lds[FeatLdsC::total];
   features_step_body<TIMED>(lds, OP.seq0 + (int)blockIdx.x, slots_all, trig, OP, states, scratch);
 }
+// the production registration shape (256 threads, three workgroups per unit) compiled for the 64 scans a sequence can keep: submaps of 8 .. 63
+// keyframes when there are more sequences than compute units (launch_register_step). A kernel name of its own: register_step.hip instantiates
+// register_step_kernel with 8-scan shared state under the same template arguments, and profilers key on the name.
+template <bool TIMED, int KCOST>
+__global__ __launch_bounds__(BLOCK_R, CFEAR_REG_MIN_WG) void register_step64_kernel(OdoParams OP, SeqState* states, const BlockScratch* scratch, double* cov_work,
+                                                                                   cfear_reg_summary* summaries, double* poses_out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
+  register_step_body<TIMED, KCOST>(lds, OP.order ? OP.order[blockIdx.x] : OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
+}
 // the same stage from clouds on the device (filter_type CA-CFAR / cfear_odometry_step_cloud_device)
 __global__ __launch_bounds__(BLOCK_F, 4) void features_cloud_step_kernel(const float* xyi_all, int cap, const int* counts, OdoParams OP,
                                                                          const SeqState* states, const BlockScratch* scratch) {
@@ -450,8 +459,8 @@ static void launch_register_step(const OdoParams& P_in, int count, hipStream_t s
     cfear_launch_register_step_large(&P, count, st, o->d_states, o->d_scratch_hdr, o->d_cov_work, o->d_summaries, o->d_poses_out);
     return;
   }
-#define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scan_ptrs, \
-                                                  o->d_scratch_hdr, o->d_poses_work, o->d_cov_work, o->d_summaries, o->d_poses_out)
+#define CFEAR_LAUNCH_REG(T, C) hipLaunchKernelGGL((register_step64_kernel<T, C>), dim3(count), dim3(BLOCK_R), 0, st, P, o->d_states, o->d_scratch_hdr, \
+                                                  o->d_cov_work, o->d_summaries, o->d_poses_out)
   // one instantiation per cost metric here too (the evaluation inline, no run-time dispatch): a ten- or fifty-keyframe submap
   // evaluates thousands of residual blocks 30-80 times per registration
   if (P.phase_times) CFEAR_LAUNCH_REG(true, -1);

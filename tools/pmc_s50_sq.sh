@@ -6,6 +6,6 @@ for shape in 1 2; do
     rm -rf /tmp/pmc_s50
     CFEAR_PRESET_LARGE_KERNEL=$shape CFEAR_BENCH_PRESETS=cfear3_s50 timeout 400 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_s50 -o s50 -- python $R/tools/gpu_presets.py > $R/gpurun_out/pmc_s50_sq.log 2>&1
     echo "shape $shape: $(grep -h 'cfear3_s50' $R/gpurun_out/pmc_s50_sq.log | tail -1)"
-    (cd $R; ROCPD_LAST=12 python tools/rocpd_summary.py $(find /tmp/pmc_s50 -name "*.db" | head -1) 2>/dev/null | grep -E "register_step[a-z_]*kernel<false" | grep -E "\| [A-Z]")
+    (cd $R; ROCPD_LAST=12 python tools/rocpd_summary.py $(find /tmp/pmc_s50 -name "*.db" | head -1) 2>/dev/null | grep -E "register_step[a-z_0-9]*kernel<false" | grep -E "\| [A-Z]")
   done
 done

@@ -23,3 +23,8 @@ bash $R/tools/pmc_k1_inputs.sh $O/${P}_k1_inputs.txt > /dev/null 2>&1
 [ -f $R/tools/_stop/libcfear_hip_k1stop1.so ] && bash $R/tools/pmc_k1_phases.sh $O/${P}_k1_phases.txt > /dev/null 2>&1
 cd $R; for ps in s10_p2p s10_p2d s50_cfear3; do timeout 900 python tests/run_drive_parity.py canyon ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_canyon_$ps.json $ps > /dev/null 2>&1; done
 bash $R/tools/ab_reg_order.sh $O/${P}_ab_reg_order.txt > /dev/null 2>&1
+# round 5: the large-submap registration kernel's counters after the instruction diet, the CA-CFAR detector alone, the whole GPU test suite
+(bash $R/tools/pmc_s50_sq.sh) > $O/${P}_s50_sq.txt 2>&1
+(bash $R/tools/pmc_s50.sh) > $O/${P}_odo_mem_s50_after.txt 2>&1
+cd $R; timeout 300 python tools/gpu_time_cfar.py 2>&1 | grep -v amdgpu > $O/${P}_cfar_kernel_final.txt
+(timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -12) > $O/${P}_gpu_tests.log 2>&1
