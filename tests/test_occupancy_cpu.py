@@ -31,11 +31,15 @@ def remarks(src, tmp_path):
 def test_step_kernels_keep_their_occupancy(tmp_path):
     k = remarks("pipeline.hip", tmp_path)
     feat = [v for n, v in k.items() if "features_step_kernelILb0" in n][0]
-    regs = {"large:" + n: v for n, v in k.items() if "register_step_kernelILb0" in n}  # the instantiations for large submaps (64 scans), one per cost metric
+    regs = {"wide:" + n: v for n, v in k.items() if "register_step64_kernelILb0" in n}  # the same shape compiled for large submaps (64 scans), one per cost metric
     regs.update({"small:" + n: v for n, v in remarks("register_step.hip", tmp_path).items() if "register_step_kernelILb0" in n})  # production (<= 8 scans): one per cost metric
     assert len(regs) == 6, sorted(regs)
     for n, reg in regs.items():
         assert reg["Occupancy"] >= 3 and reg["LDS"] <= 53760, (n, reg)      # three 256-thread workgroups per CU
+    big = {n: v for n, v in remarks("register_step_large.hip", tmp_path).items() if "register_step_large_kernelILb0" in n}
+    assert len(big) == 3, sorted(big)
+    for n, reg in big.items():  # one 512-thread workgroup with the unit's LDS to itself: two waves per SIMD, nothing spilled but the frame of its callees
+        assert reg["Occupancy"] >= 2 and reg["LDS"] <= 160 * 1024 and reg["ScratchSize"] <= 32, (n, reg)
     assert feat["Occupancy"] >= 4 and feat["LDS"] <= 80384 and feat["ScratchSize"] <= 16, feat  # two 512-thread workgroups per CU; at most two registers parked in scratch once per workgroup
     k = remarks("kstrongest.hip", tmp_path)
     flt = [v for n, v in k.items() if "kstrongest_kernelILi4ELi7" in n][0]
