@@ -10,7 +10,11 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (a checker script: it live
 
 S10 = dict(k_strongest=40, cost=0, loss=2, loss_limit=0.1, submap_scan_size=10, res=3.0, weight_intensity=1, weight_opt=4, regularization=0.1, covar_scale=1.0)
 PRESETS = {"s10_p2p": S10, "s10_p2d": dict(S10, cost=2), "s50_cfear3": dict(S10, submap_scan_size=50),
-           "s8_p2l": dict(k_strongest=12, cost=1, loss=1, loss_limit=0.1, res=3.0, weight_intensity=0, weight_opt=0, submap_scan_size=8)}
+           "s8_p2l": dict(k_strongest=12, cost=1, loss=1, loss_limit=0.1, res=3.0, weight_intensity=0, weight_opt=0, submap_scan_size=8),
+           # round 5: the reference's evaluation grid (tests/test_eval_grid_gpu.py) on long drives
+           "cfear1": dict(cost=1, submap_scan_size=1, res=3.5, k_strongest=12, loss=1, loss_limit=0.1, covar_scale=1.0, regularization=1.0, weight_intensity=0, weight_opt=4),
+           "nocomp_p2p_k40": dict(cost=0, submap_scan_size=4, res=3.0, k_strongest=40, loss=1, loss_limit=0.1, weight_intensity=1, weight_opt=0, compensate=0),
+           "res1_s3": dict(cost=1, submap_scan_size=3, res=1.0, k_strongest=12, loss=1, loss_limit=0.1, weight_intensity=1, weight_opt=0)}
 
 
 def main():

@@ -140,3 +140,38 @@ def test_cfar_fuser_point_capacity_is_loud(oracle):
         odo.step_host(frames[0])
     odo.release()
     ctx.close()
+
+
+def test_cloud_step_on_a_kstrongest_object_matches_the_oracle(oracle):
+    """cfear_odometry_step_cloud_device is not tied to the CA-CFAR filter: an object created for k-strongest takes clouds of up to A * k points
+    from any producer - here the oracle's own k-strongest clouds, uploaded - and follows the oracle's fuser fed with the same clouds"""
+    import torch
+    T, B, k = 40, 2, 12
+    kw = dict(PRESET, z_min=60.0, cost=1, weight_intensity=1, weight_opt=4, k_strongest=k)
+    frames = _frames(T, B, "blocks", seed0=9)
+    fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
+    ctx = capi.Context(capi.default_params(**kw), A, R)
+    odo = ctx.odometry(B)
+    dev = torch.device("cuda:0")
+    cap = A * k
+    for t in range(T):
+        clouds = [oracle.cloud(oracle.filter_polar(frames[t, q], 60, k), float(RR), 2.5) for q in range(B)]
+        h = np.zeros((B, cap, 3), dtype=np.float32)
+        for q, c in enumerate(clouds):
+            h[q, :len(c)] = c
+        d_xyi = torch.from_numpy(h).to(dev)
+        d_n = torch.tensor([len(c) for c in clouds], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        odo.step_cloud_device(d_xyi.data_ptr(), cap, d_n.data_ptr())
+        got = odo.poses()
+        for q in range(B):
+            exp = fus[q].process_cloud(clouds[q])
+            S = fus[q].last_summary()
+            Sg, nc, nk = odo.summary(q)
+            if t > 0:
+                assert (int(Sg.outer_iterations), int(Sg.num_residuals), nk, nc) == (int(S.outer_iterations), int(S.num_residuals), int(fus[q].num_keyframes), len(fus[q].last_cells())), (t, q)
+            assert np.all(np.abs(got[q][:2] - exp[:2]) < 1e-4) and abs(got[q][2] - exp[2]) < 1e-5, (t, q, got[q], exp)
+    with pytest.raises(capi.CfearError, match="capacity .* exceeds"):
+        odo.step_cloud_device(d_xyi.data_ptr(), cap + 1, d_n.data_ptr())
+    odo.release()
+    ctx.close()
