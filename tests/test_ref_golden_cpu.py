@@ -41,22 +41,33 @@ def test_world_clouds_compensation_and_cells(oracle, ref):
 
 
 def test_nearest_cell_tie_order(oracle, ref):
-    """GetClosestIdx (pointnormal.cpp:238-254) queried AT every cell mean: its own index where the float mean is unique; among the
-    cells that share a float mean the reference returns FLANN's first visit, the oracle (and the HIP path) the lowest index - the
-    `[3P]` row DESIGN.md section 2 shows is worth up to centimetres per registration. If this fails, the tie rule of
-    cfo_scan_closest / scan_closest has to follow what the file shows."""
+    """GetClosestIdx (pointnormal.cpp:238-254) queried AT every cell mean: its own index where the float mean is unique; among the cells that
+    share a float mean the reference returns whatever FLANN's descent visits first - the `[3P]` row DESIGN.md section 2 shows is worth up to a
+    centimetre per registration. Both sides have the rule as a switch since round 5: this test says which setting the real binary matches -
+    the restated kd-tree (CFO_PERT_NN_TIE_FLANN = library NN_TIE_RULE 2) must; if the production rule (lowest index) does too on this scan,
+    good, and if neither does the restatement of flann::KDTreeSingleIndex in oracle/cfear_oracle.c (kd_*) is what has to be corrected."""
     if "world3_closest_self" not in ref:
         pytest.skip("ref_golden.npz predates the tie-order dump (oracle/ref_recipe/dump_ref_golden.cpp)")
     p = oracle.default_params(range_res=RR, res=3.0, weight_intensity=1)
     s = oracle.Scan(ref["world3_cloud_comp"], p)
     means = s.cells()["mean"]
-    got = np.array([s.closest(x, y, 0.5) for x, y in means])
     want = ref["world3_closest_self"]
     m32 = means.astype(np.float32)
     _, inv, cnt = np.unique(m32, axis=0, return_inverse=True, return_counts=True)
     dup = cnt[inv.ravel()] > 1
-    assert np.array_equal(got[~dup], want[~dup]) and np.array_equal(want[~dup], np.arange(len(means))[~dup])
-    assert np.array_equal(got[dup], want[dup]), "FLANN's choice among cells with equal float means: %r, lowest index: %r" % (want[dup].tolist(), got[dup].tolist())
+    got = {}
+    for mode in ("lowest", "nn_tie_flann"):
+        oracle.set_perturbation([] if mode == "lowest" else [mode])
+        try:
+            got[mode] = np.array([s.closest(x, y, 0.5) for x, y in means])
+        finally:
+            oracle.set_perturbation(0)
+        assert np.array_equal(got[mode][~dup], want[~dup]) and np.array_equal(want[~dup], np.arange(len(means))[~dup]), mode
+    agree = {mode: bool(np.array_equal(g[dup], want[dup])) for mode, g in got.items()}
+    assert agree["nn_tie_flann"], ("the restated FLANN descent does not reproduce the binary's choices among cells with equal float means: binary %r, restatement %r, "
+                                   "lowest index %r" % (want[dup].tolist(), got["nn_tie_flann"][dup].tolist(), got["lowest"][dup].tolist()))
+    if not agree["lowest"]:
+        print("the production tie rule (lowest index) differs from the binary on this scan: compare in the parity mode (NN_TIE_RULE 2)")
 
 
 @pytest.mark.parametrize("tag,cost", [("p2l", 1), ("p2d", 2)])
