@@ -301,7 +301,19 @@ int set_kernel_attributes(cfear_ctx*) { return CFEAR_OK; }  // LDS is static (up
 struct cfear_scan {
   unsigned char* d_block = nullptr;  // ScanDev header + arrays
   int cap_points = 0;
+  bool with_kd = false;  // built under cfear_tune NN_TIE_RULE = 2: carries the kd-tree the parity mode's search walks
 };
+// cfear_tune NN_TIE_RULE = 2 needs scans that were built in that mode: anything else would answer by the production rule without saying so
+static int check_tie_rule_scans(cfear_ctx* ctx, cfear_scan* const* scans, int n, const char* what) {
+  if (ctx->tune_nn_tie != 2) return CFEAR_OK;
+  for (int i = 0; i < n; i++)
+    if (scans[i] && !scans[i]->with_kd) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "%s: scan %d was created before cfear_tune NN_TIE_RULE = 2 was set - it has no kd-tree for the parity mode's search; create the scans after the tune call", what, i);
+      return cfear_fail(ctx, CFEAR_ERR_INVALID, msg);
+    }
+  return CFEAR_OK;
+}
 struct cfear_odometry {
   int B = 0, nslots = 0, cap_points = 0, cap_cells = 0, pair_cap = 0;
   int* d_order = nullptr; unsigned* d_work = nullptr;  // registration workgroups longest first (cfear_tune REGISTRATION_ORDER): see order_kernel
@@ -486,6 +498,7 @@ static void odo_launch_sweep_cloud(cfear_odometry* o, const OdoParams& P, const 
 static int odo_cfar_points(const cfear_ctx* ctx) { return ctx->par.cfar_max_points > 0 ? ctx->par.cfar_max_points : 32768; }
 static bool odo_shape_ok(const cfear_ctx* ctx, const cfear_odometry* o) {
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->filter != ctx->par.filter_type) return false;
+  if ((ctx->tune_nn_tie == 2 && !o->with_kd) || (ctx->tune_nn_tie != 0 && o->pair_cap < 8192)) return false;  // the tie rule was switched after the object was created
   return o->cap_points == (o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest);
 }
 // the CA-CFAR stage of n_scans sweeps (radar_driver.cpp:52-56) into clouds of o->cap_points points each
@@ -672,7 +685,7 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   if (rc != CFEAR_OK) return rc;
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
-  s->cap_points = cap;
+  s->cap_points = cap; s->with_kd = ctx->tune_nn_tie == 2;
   const ScanLayout L = scan_layout(cap, cap, true, ctx->tune_nn_tie == 2);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
   const ScanDev h = scan_header(s->d_block, cap, cap, true, ctx->tune_nn_tie == 2);
@@ -721,7 +734,7 @@ int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_
   if (rc != CFEAR_OK) return rc;
   cfear_scan* s = new (std::nothrow) cfear_scan();
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
-  s->cap_points = n;
+  s->cap_points = n; s->with_kd = ctx->tune_nn_tie == 2;
   const ScanLayout L = scan_layout(n, n, true, ctx->tune_nn_tie == 2);
   if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
   const ScanDev h = scan_header(s->d_block, n, n, true, ctx->tune_nn_tie == 2);
@@ -777,6 +790,7 @@ int cfear_scan_download_cells(cfear_ctx* ctx, const cfear_scan* s, cfear_cell* c
 
 int cfear_scan_closest(cfear_ctx* ctx, const cfear_scan* s, const double* qxy, int nq, double d, int32_t* idx) {
   if (!ctx || !s || !qxy || !idx || nq <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_closest: bad argument");
+  { cfear_scan* one = const_cast<cfear_scan*>(s); const int trc = check_tie_rule_scans(ctx, &one, 1, "scan_closest"); if (trc != CFEAR_OK) return trc; }
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double* dq = nullptr; int* di = nullptr;
   if (hipMalloc(&dq, sizeof(double) * 2 * (size_t)nq) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc queries");
@@ -805,6 +819,7 @@ static int register_impl(cfear_ctx* ctx, cfear_scan* const* scans, int n, double
     if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "register: null scan");
     if (scans[i]->cap_points > capmax) capmax = scans[i]->cap_points;
   }
+  if ((rc = check_tie_rule_scans(ctx, scans, n, "register")) != CFEAR_OK) return rc;
   rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
   if (rc != CFEAR_OK) return rc;
   const ScratchLayout L = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
@@ -859,7 +874,9 @@ int cfear_get_cost(cfear_ctx* ctx, cfear_scan* const* scans, int n, const double
     if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "get_cost: null scan");
     if (scans[i]->cap_points > capmax) capmax = scans[i]->cap_points;
   }
-  int rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
+  int rc = check_tie_rule_scans(ctx, scans, n, "get_cost");
+  if (rc != CFEAR_OK) return rc;
+  rc = ensure_ctx_scratch(ctx, capmax, (MAX_SCANS - 1) * capmax);
   if (rc != CFEAR_OK) return rc;
   const ScratchLayout L = scratch_layout(capmax, (MAX_SCANS - 1) * capmax);
   unsigned char* base = static_cast<unsigned char*>(ctx->d_scratch);
@@ -965,11 +982,14 @@ int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const
   *success = 0;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < n; i++) if (!scans[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cov_by_sampling: null scan");
+  { const int trc = check_tie_rule_scans(ctx, scans, n, "cov_by_sampling"); if (trc != CFEAR_OK) return trc; }
   int nsrc = 0;
   int rc = cfear_scan_size(ctx, scans[n - 1], &nsrc);
   if (rc != CFEAR_OK) return rc;
   const int steps = samples_per_axis, m = steps * steps * steps, L = 3 * (n - 1);
-  const int cap = (n - 1) * (nsrc > 0 ? nsrc : 1);
+  // match scratch per sample: a pair of capacity per (keyframe, source cell); under a non-production tie rule the kd descent's per-thread stacks
+  // live there too (registration_dev.h associate_pair_rule: 64 B per pair of capacity for blockDim x 64 entries of 16 B)
+  const int cap = std::max((n - 1) * (nsrc > 0 ? nsrc : 1), ctx->tune_nn_tie != 0 ? 4096 : 1);
   std::vector<double> xs, ths;  // :277-290
   linspace(-xy_range * 0.5, xy_range * 0.5, steps, xs);
   linspace(-yaw_range * 0.5, yaw_range * 0.5, steps, ths);
@@ -1118,6 +1138,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
   // residual blocks of a registration <= keyframes x cells of the current scan (one match per source cell and keyframe,
   // n_scan_normal.cpp:242,258); the association parks four results per source cell in the same scratch
   o->pair_cap = std::max(s, 4) * o->cap_cells;
+  if (ctx->tune_nn_tie != 0) o->pair_cap = std::max(o->pair_cap, 8192);  // room for the kd descent's per-thread stacks (associate_pair_rule, 512-thread kernels)
   o->with_kd = ctx->tune_nn_tie == 2;
   const ScanLayout SL = scan_layout(o->cap_points, o->cap_cells, false, o->with_kd);
   const ScratchLayout WL = scratch_layout(o->cap_points, o->pair_cap);
@@ -1245,7 +1266,7 @@ static int odo_step_clouds(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi
 
 int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi, int capacity, const int* d_counts) {
   if (!ctx || !o || !d_xyi || !d_counts || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: bad argument");
-  if (!odo_shape_ok(ctx, o)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: submap_scan_size / k_strongest / filter_type changed after odometry_create");
+  if (!odo_shape_ok(ctx, o)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
   if (capacity > o->cap_points) {
     char msg[256];
     snprintf(msg, sizeof(msg), "odometry_step_cloud: capacity %d exceeds the %d points per scan this object was created for (A * k_strongest, or cfar_max_points with "
@@ -1264,7 +1285,7 @@ int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const fl
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_polar) {
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
   if (!odo_shape_ok(ctx, o))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest / filter_type changed after odometry_create");
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (o->filter == CFEAR_FILTER_CACFAR) {  // radar_driver.cpp:52-56, then the cloud route
     int rc = CFEAR_OK;
@@ -1574,7 +1595,7 @@ static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames,
 static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, int n_sweeps) {
   if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
   if (!odo_shape_ok(ctx, o))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type changed after odometry_create");
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return odo_join(ctx, o);
 }

@@ -111,3 +111,26 @@ def test_replay_route_and_large_submap_follow_the_flann_rule(oracle):
         oracle.set_perturbation(0)
     odo.release()
     ctx.close()
+
+
+def test_switching_the_rule_under_existing_scans_and_objects_is_refused(oracle):
+    """a scan / batched object built before NN_TIE_RULE = 2 has no kd-tree: the parity mode must not answer by the production rule in silence"""
+    frames = _frames(3, 1, "blocks")
+    ctx = capi.Context(capi.default_params(**KW), A, R)
+    xyi = oracle.cloud(oracle.filter_polar(frames[1, 0], 60, 12), float(RR), 2.5)
+    scan = ctx.scan_create(ctx.cloud_upload(xyi))
+    odo = ctx.odometry(1)
+    odo.step_host(frames[0])
+    ctx.tune(capi.TUNE_NN_TIE_RULE, 2)
+    with pytest.raises(capi.CfearError, match="created before cfear_tune NN_TIE_RULE"):
+        scan.closest(np.zeros((1, 2)), 2.0)
+    with pytest.raises(capi.CfearError, match="NN_TIE_RULE changed after odometry_create"):
+        odo.step_host(frames[1])
+    ctx.tune(capi.TUNE_NN_TIE_RULE, 0)
+    odo.step_host(frames[1])  # back in the mode it was created for
+    scan2 = None
+    ctx.tune(capi.TUNE_NN_TIE_RULE, 2)
+    scan2 = ctx.scan_create(ctx.cloud_upload(xyi))
+    with pytest.raises(capi.CfearError, match="scan 0 was created before"):
+        ctx.register([scan, scan2], np.zeros((2, 3)))
+    ctx.close()
