@@ -499,6 +499,7 @@ static int odo_cfar_points(const cfear_ctx* ctx) { return ctx->par.cfar_max_poin
 static bool odo_shape_ok(const cfear_ctx* ctx, const cfear_odometry* o) {
   if (o->nslots != ctx->par.submap_scan_size + 1 || o->filter != ctx->par.filter_type) return false;
   if ((ctx->tune_nn_tie == 2 && !o->with_kd) || (ctx->tune_nn_tie != 0 && o->pair_cap < 8192)) return false;  // the tie rule was switched after the object was created
+  if (ctx->tune_voxel_order != 0) return false;  // per-call scans only (cfear_odometry_create refuses it too)
   return o->cap_points == (o->filter == CFEAR_FILTER_CACFAR ? odo_cfar_points(ctx) : ctx->A * ctx->par.k_strongest);
 }
 // the CA-CFAR stage of n_scans sweeps (radar_driver.cpp:52-56) into clouds of o->cap_points points each
@@ -1266,7 +1267,7 @@ static int odo_step_clouds(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi
 
 int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const float* d_xyi, int capacity, const int* d_counts) {
   if (!ctx || !o || !d_xyi || !d_counts || capacity <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: bad argument");
-  if (!odo_shape_ok(ctx, o)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
+  if (!odo_shape_ok(ctx, o)) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step_cloud: submap_scan_size / k_strongest / filter_type changed after odometry_create, or a parity mode (cfear_tune NN_TIE_RULE / VOXEL_ORDER) was switched under the object");
   if (capacity > o->cap_points) {
     char msg[256];
     snprintf(msg, sizeof(msg), "odometry_step_cloud: capacity %d exceeds the %d points per scan this object was created for (A * k_strongest, or cfar_max_points with "
@@ -1285,7 +1286,7 @@ int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const fl
 int cfear_odometry_step_device(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* d_polar) {
   if (!ctx || !o || !d_polar) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: bad argument");
   if (!odo_shape_ok(ctx, o))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_step: submap_scan_size / k_strongest / filter_type changed after odometry_create, or a parity mode (cfear_tune NN_TIE_RULE / VOXEL_ORDER) was switched under the object");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (o->filter == CFEAR_FILTER_CACFAR) {  // radar_driver.cpp:52-56, then the cloud route
     int rc = CFEAR_OK;
@@ -1595,7 +1596,7 @@ static int replay_impl(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames,
 static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames, int n_sweeps) {
   if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
   if (!odo_shape_ok(ctx, o))
-    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type / NN_TIE_RULE changed after odometry_create");
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type changed after odometry_create, or a parity mode (cfear_tune NN_TIE_RULE / VOXEL_ORDER) was switched under the object");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return odo_join(ctx, o);
 }
