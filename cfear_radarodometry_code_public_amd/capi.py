@@ -141,7 +141,7 @@ def lib():
         "cfear_odometry_step_cloud_device": (C.c_int, [vp, vp, f32p, C.c_int, i32p]),
         "cfear_odometry_poses": (C.c_int, [vp, vp, f64p]),
         "cfear_odometry_covariances": (C.c_int, [vp, vp, f64p]),
-        "cfear_odometry_status": (C.c_int, [vp, vp]),
+        "cfear_odometry_status": (C.c_int, [vp, vp, i32p]),
         "cfear_odometry_replay_host": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_odometry_replay_device": (C.c_int, [vp, vp, u8p, C.c_int, vp]),
         "cfear_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -568,9 +568,14 @@ class Odometry:
         self._ctx._check(self._ctx._L.cfear_odometry_poses(self._ctx._h, self._h, out.ctypes.data), "cfear_odometry_poses")
         return out
 
-    def status(self):
-        """raises CfearError (rc=-6) if a scan of this object was truncated (cfear_odometry_status)"""
-        self._ctx._check(self._ctx._L.cfear_odometry_status(self._ctx._h, self._h), "cfear_odometry_status")
+    def status(self, per_sequence=False):
+        """raises CfearError (rc=-6) if a scan of this object was truncated (cfear_odometry_status); per_sequence=True: returns the per-sequence
+        flag words instead of raising (bit 0 cells lost, bit 1 points lost)"""
+        if per_sequence:
+            out = np.zeros(self.B, dtype=np.int32)
+            self._ctx._L.cfear_odometry_status(self._ctx._h, self._h, out.ctypes.data)
+            return out
+        self._ctx._check(self._ctx._L.cfear_odometry_status(self._ctx._h, self._h, None), "cfear_odometry_status")
 
     def covariances(self):
         """cov_current of every sequence after the last sweep: [B, 6, 6]"""

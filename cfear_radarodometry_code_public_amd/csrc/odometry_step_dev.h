@@ -71,7 +71,7 @@ struct OdoParams {
   // seq0 + blockIdx.x), work[q] = what sequence q's registration of THIS sweep cost (evaluations x residual blocks + associations),
   // the key the next sweep's order is sorted by (null: not recorded)
   const int* order; unsigned* work;
-  int* flags;  // one word per odometry object: bit 0 = some scan had more cells than its block holds, bit 1 = some cloud had more points
+  int* flags;  // word 0 for the odometry object, word 1 + q for sequence q: bit 0 = some scan had more cells than its block holds, bit 1 = some cloud had more points
                // than the object is sized for (both CFEAR_ERR_CAPACITY); null: cannot happen
 };
 
@@ -159,7 +159,7 @@ __device__ __forceinline__ void features_step_body(unsigned char* lds /* FeatLds
   if (TIMED) { pt.mark(); pt.mark(); }
   CFEAR_STOP_AT(1, );
   features_dispatch(cur, n, OP.fp, B, lds, TIMED ? &pt : nullptr, n > 0 ? bounds : nullptr, true, true, PR, true);  // :161
-  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) atomicOr(OP.flags, 1);  // (thread 0 wrote the status itself)
+  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) { atomicOr(OP.flags, 1); OP.flags[1 + q] |= 1; }  // (thread 0 wrote the status itself; word 1 + q: this sequence's own)
   if (!TIMED && OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 
@@ -180,7 +180,7 @@ __device__ __forceinline__ void features_cloud_step_body(unsigned char* lds /* F
   if (n > cap) { n = cap; clipped = true; }
   if (n > cur->cap_points) { n = cur->cap_points; clipped = true; }
   if (n < 0) n = 0;
-  if (clipped && OP.flags && threadIdx.x == 0) atomicOr(OP.flags, 2);  // more detections than the object is sized for (cfar_max_points)
+  if (clipped && OP.flags && threadIdx.x == 0) { atomicOr(OP.flags, 2); OP.flags[1 + q] |= 2; }  // more detections than the object is sized for (cfar_max_points)
   const float* src = xyi_all + 3 * (size_t)q * cap;
   int bytes = 1;
   for (int i = threadIdx.x; i < n; i += BLOCK_F) {
@@ -196,7 +196,7 @@ __device__ __forceinline__ void features_cloud_step_body(unsigned char* lds /* F
   PointRegs PR;
   point_regs_from_global(cur->xyi, n, PR);
   features_dispatch(cur, n, OP.fp, B, lds, nullptr, nullptr, false, byte_intensities, PR);  // :161
-  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) atomicOr(OP.flags, 1);
+  if (OP.flags && threadIdx.x == 0 && cur->status == CFEAR_ERR_CAPACITY) { atomicOr(OP.flags, 1); OP.flags[1 + q] |= 1; }
   if (OP.wg_times && threadIdx.x == 0) OP.wg_times[(size_t)q * 32 + 1] = (long long)wall_clock64();
 }
 

@@ -1108,7 +1108,7 @@ int cfear_odometry_reset(cfear_ctx* ctx, cfear_odometry* o) {
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_summaries, 0, sizeof(cfear_reg_summary) * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_poses_out, 0, sizeof(double) * 3 * (size_t)o->B, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_cov_work, 0, sizeof(double) * 36 * (size_t)o->B, ctx->stream));
-  if (o->d_flags) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int), ctx->stream));
+  if (o->d_flags) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int) * ((size_t)o->B + 1), ctx->stream));
   o->order_ready = false;
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
@@ -1176,7 +1176,7 @@ int cfear_odometry_create(cfear_ctx* ctx, int n_sequences, cfear_odometry** out)
     ok = ok && hipMalloc(&o->d_slots[1], sizeof(uint32_t) * (size_t)B * o->cap_points) == hipSuccess;
   }
   // (a sweep's CA-CFAR detections may exceed the points the object holds; cfear_odometry_step_cloud_device allocates the word when first used)
-  if (ok && (o->cap_cells < o->cap_points || o->filter == CFEAR_FILTER_CACFAR)) ok = hipMalloc(&o->d_flags, sizeof(int)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int)) == hipSuccess;
+  if (ok && (o->cap_cells < o->cap_points || o->filter == CFEAR_FILTER_CACFAR)) ok = hipMalloc(&o->d_flags, sizeof(int) * ((size_t)B + 1)) == hipSuccess && hipMemset(o->d_flags, 0, sizeof(int) * ((size_t)B + 1)) == hipSuccess;
   if (ok && ctx->tune_reg_order && B >= 2)
     ok = hipMalloc(&o->d_order, sizeof(int) * (size_t)B) == hipSuccess && hipMalloc(&o->d_work, sizeof(unsigned) * (size_t)B) == hipSuccess &&
          hipMemset(o->d_work, 0, sizeof(unsigned) * (size_t)B) == hipSuccess;
@@ -1277,8 +1277,8 @@ int cfear_odometry_step_cloud_device(cfear_ctx* ctx, cfear_odometry* o, const fl
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   if (!o->d_flags) {  // counts beyond `capacity` are reported like every other truncation
-    CFEAR_HIP_CHECK(ctx, hipMalloc(&o->d_flags, sizeof(int)));
-    CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int), ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipMalloc(&o->d_flags, sizeof(int) * ((size_t)o->B + 1)));
+    CFEAR_HIP_CHECK(ctx, hipMemsetAsync(o->d_flags, 0, sizeof(int) * ((size_t)o->B + 1), ctx->stream));
   }
   return odo_step_clouds(ctx, o, d_xyi, capacity, d_counts, false);
 }
@@ -1657,11 +1657,15 @@ int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* o, double* cov6) 
   return odo_capacity_check(ctx, o, "odometry_covariances");
 }
 
-int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* o) {
+int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* o, int32_t* per_sequence) {
   if (!ctx || !o) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_status: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   { const int jrc = odo_join(ctx, o); if (jrc != CFEAR_OK) return jrc; }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (per_sequence) {
+    if (o->d_flags) CFEAR_HIP_CHECK(ctx, hipMemcpy(per_sequence, o->d_flags + 1, sizeof(int) * (size_t)o->B, hipMemcpyDeviceToHost));
+    else memset(per_sequence, 0, sizeof(int) * (size_t)o->B);
+  }
   return odo_capacity_check(ctx, o, "odometry_status");
 }
 

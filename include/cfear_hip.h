@@ -308,8 +308,10 @@ int cfear_odometry_poses(cfear_ctx* ctx, cfear_odometry* odo, double* poses_xyt)
 int cfear_odometry_covariances(cfear_ctx* ctx, cfear_odometry* odo, double* cov6);
 /* Has any scan of this object been truncated - more oriented surface points than CFEAR_TUNE_MAX_CELLS, or a cloud with more points than the object
  * holds? Synchronises the context stream; returns CFEAR_OK or CFEAR_ERR_CAPACITY (with the message the reading calls give). For callers of the
- * asynchronous cfear_odometry_replay_device, which read their records on the device and never pass through poses / summary / replay_host. */
-int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* odo);
+ * asynchronous cfear_odometry_replay_device, which read their records on the device and never pass through poses / summary / replay_host.
+ * per_sequence (optional, n_sequences words): which sequences - bit 0 = a scan of that sequence lost cells, bit 1 = a cloud of it lost points;
+ * the others' results are untouched (the condition is sticky until cfear_odometry_reset, like the return code). */
+int cfear_odometry_status(cfear_ctx* ctx, cfear_odometry* odo, int32_t* per_sequence);
 /* Last Register() summary / cell count / keyframe count of one sequence (debug + parity tests). */
 int cfear_odometry_summary(cfear_ctx* ctx, cfear_odometry* odo, int sequence, cfear_reg_summary* summary,
                            int* n_cells, int* n_keyframes);

@@ -158,6 +158,7 @@ def test_max_cells_capacity_is_loud_and_otherwise_invisible():
         odo.summary(0)
     with pytest.raises(capi.CfearError, match=r"rc=-6.*odometry_status"):  # the call for users of the asynchronous device-side replay
         odo.status()
+    assert np.array_equal(odo.status(per_sequence=True), [1, 1])  # ... and which sequences (both drive through the canyon)
     odo.reset()  # a reset clears the condition
     odo.release()
     with pytest.raises(capi.CfearError, match=r"rc=-5.*sequences fit.*CFEAR_TUNE_MAX_CELLS"):
