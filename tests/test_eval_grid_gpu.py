@@ -51,7 +51,7 @@ def _replay(oracle, name, kind, sweeps, params, **kw):
 # ---- CFEAR-1 -------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind", ["blocks", "canyon"])
 def test_cfear1_replay_matches_oracle_at_every_sweep(oracle, kind):
-    out = _replay(oracle, "cfear-1 " + kind, kind, 600, CFEAR1)
+    out = _replay(oracle, "cfear-1 " + kind, kind, 450, CFEAR1)  # (10 000 sweeps of this preset: profiles/r05_drive10k_blocks_cfear1.json)
     assert out["keyframes_max"] == 1  # the ring of one
 
 
@@ -66,7 +66,7 @@ def test_cfear1_batched_route_matches_oracle(oracle, route):
 @pytest.mark.parametrize("cost,s,k", [(c, s, k) for c in (P2P, P2L) for s in (1, 4) for k in (12, 40)])
 def test_compensation_disabled_replay(oracle, cost, s, k):
     p = dict(CFEAR3_GRID, compensate=0, cost=cost, submap_scan_size=s, k_strongest=k)
-    out = _replay(oracle, "compensate=0 cost %d s %d k %d" % (cost, s, k), "blocks" if k == 12 else "canyon", 200, p)
+    out = _replay(oracle, "compensate=0 cost %d s %d k %d" % (cost, s, k), "blocks" if k == 12 else "canyon", 150, p)
     assert out["keyframes_max"] == s
 
 
@@ -89,7 +89,7 @@ def test_compensation_flag_changes_the_trajectory(oracle):
 @pytest.mark.parametrize("res,s,cost", [(r, s, c) for r in (1.0, 2.0, 5.0) for s in (1, 3) for c in (P2P, P2L)])
 def test_resolution_sweep_replay(oracle, res, s, cost):
     p = dict(CFEAR3_GRID, res=res, submap_scan_size=s, cost=cost)
-    _replay(oracle, "res %g s %d cost %d" % (res, s, cost), "canyon", 150, p)
+    _replay(oracle, "res %g s %d cost %d" % (res, s, cost), "canyon", 120, p)
 
 
 @pytest.mark.parametrize("res,s,cost,route,max_cells", [
@@ -116,7 +116,7 @@ def test_resolution_dense_scans_replay_persistent(oracle):
 @pytest.mark.parametrize("loss,limit", [(l, v) for l in (NONE, CAUCHY, TUKEY, SOFTLONE, HUBER) for v in (0.01, 1.0, 4.0)])
 def test_loss_function_sweep_replay(oracle, loss, limit):
     p = dict(CFEAR3_GRID, loss=loss, loss_limit=limit)
-    _replay(oracle, "loss %s limit %g" % (LOSS_NAMES[loss], limit), "blocks", 150, p)
+    _replay(oracle, "loss %s limit %g" % (LOSS_NAMES[loss], limit), "blocks", 120, p)
 
 
 @pytest.mark.parametrize("loss,limit,route", [(TUKEY, 0.01, "step"), (CAUCHY, 4.0, "replay"), (SOFTLONE, 1.0, "step"), (NONE, 0.1, "replay"), (HUBER, 0.01, "step")])
