@@ -19,6 +19,7 @@
 // expressions in double. The result is the same bit for bit (tests/test_cfar_gpu.py); LDS is sized by the row length (17 KB at 3360
 // bins: nine rows in flight per compute unit instead of one).
 #include <math.h>
+#include <stdlib.h>
 
 #include "blockops.h"
 #include "common.h"
@@ -121,6 +122,165 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_detect_kernel(const uint8_t* 
   if (tid == 0) row_count[grow] = red_i[32] + red_i[33] + red_i[34] + red_i[35];
 }
 
+// ---- the same detector with a third of the instructions (rows whose length is a multiple of four, up to 256 * TB bins: every radar here) --------
+// The kernel above is bound by vector instruction issue (PMC: 2960 vector + 1820 scalar instructions per row, SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x
+// nine waves per SIMD = 1.05). Same shape here - one 256-thread workgroup per row, nine rows in flight per unit - with the work cut down:
+//   * the row is staged as dwords and thread t owns the bins [TB t, TB t + TB): their sum of squares is TB / 4 dot products (v_dot4_u32_u8 of a dword
+//     with itself), one block scan gives the segment's offset, the per-bin prefix goes out as 16-byte LDS stores;
+//   * the prefix array is padded by guard + window entries on both sides - zeros in front, the row total behind - so that a window clipped by a row
+//     end is simply the difference of two entries: no address clamps, and the exact path of such a bin needs arithmetic only (no memory);
+//   * a wave takes four trips of 64 consecutive bins at a time: sixteen prefix reads off four address registers (constant offsets), and in the
+//     middle of the row - every bin inside the range gate, both windows complete - three comparisons per bin; the comparison's result mask IS the
+//     hit mask, counts stay on the scalar unit.
+// Same decisions as the kernel above (the float pre-test only ever hands doubtful bins to the reference's double arithmetic): tests/test_cfar_gpu.py.
+__device__ __noinline__ bool cfar_exact_vals(uint32_t ts_u, int tn_i, uint32_t fs_u, int fn_i, int iv2, double scaling) {
+  const double tn = tn_i > 0 ? (double)tn_i : 0.0, fn = fn_i > 0 ? (double)fn_i : 0.0;
+  const double ts = tn_i > 0 ? (double)ts_u : 0.0, fs = fn_i > 0 ? (double)fs_u : 0.0;
+  const double mean = (ts / tn + fs / fn) / 2.0;  // empty window: 0/0 = NaN -> no detection (cfar.cpp:56)
+  const double threshold = scaling * mean;
+  return (double)iv2 > threshold;                 // :58-60
+}
+__device__ __forceinline__ uint32_t lane_write(uint32_t acc, uint32_t sval, const int lane_const) {  // acc's lane lane_const := a scalar (one instruction)
+  asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(sval), "n"(lane_const));
+  return acc;
+}
+template <int KI, int TB>
+__device__ __forceinline__ void cfar_four_trips(const CfarParams& P, __attribute__((address_space(3))) uint32_t* prefix, const int trip0, const int ntrips,
+                                                const int lane, const float kf_lo, const float kf_hi, const float kscale, const int iv_min2, uint32_t& acc, int& cnt) {
+  typedef __attribute__((address_space(3))) uint32_t l_u32;
+  constexpr int U = 4;
+  const int R = P.R, g = P.guard, w = P.window;
+  uint32_t S[U]; int iv2[U]; uint32_t ts[U], fs[U];
+  const int ia = trip0 * 64, ib = ia + 64 * U - 1;  // the bins of these trips (scalars: trip0 is)
+  {  // twenty reads off five address registers (constant offsets): I^2 is a difference of the prefix too
+    l_u32* const pa = prefix + (ia + lane - g - w); l_u32* const pb = pa + w; l_u32* const pc = pb + 2 * g; l_u32* const pd = pc + w;
+    l_u32* const pi = prefix + (ia + lane);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      ts[u] = pb[64 * u] - pa[64 * u]; fs[u] = pd[64 * u] - pc[64 * u];
+      S[u] = ts[u] + fs[u];
+      iv2[u] = (int)(pi[64 * u + 1] - pi[64 * u]);
+    }
+  }
+  // (scalar) every bin inside the range gate, both windows complete: the middle of the row
+  if (ia - g - w >= 0 && ib + g + w <= R && ia >= P.ilo && ib <= P.ihi) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      unsigned long long m = 0;
+      const bool cand = iv2[u] >= iv_min2;  // cfar.cpp:45 (I >= I_min <=> I^2 >= I_min^2)
+      if (__builtin_amdgcn_ballot_w64(cand)) {
+        const float Sf = (float)S[u], I2 = (float)iv2[u];
+        const unsigned long long open = __builtin_amdgcn_ballot_w64(cand && I2 >= Sf * kf_lo);  // hits are one bin in a few hundred: the common trip ends here
+        if (open) {
+          const bool sure = I2 > Sf * kf_hi;
+          m = open & __builtin_amdgcn_ballot_w64(sure);
+          const bool tie = ((open >> lane) & 1) && !sure;  // near-ties of the float test: the reference's arithmetic
+          if (__builtin_amdgcn_ballot_w64(tie)) {
+            bool hit = false;
+            if (tie) hit = cfar_exact_vals(ts[u], w, fs[u], w, iv2[u], P.scaling);
+            m |= __builtin_amdgcn_ballot_w64(hit);
+          }
+        }
+      }
+      cnt += __popcll(m);
+      acc = lane_write(acc, (uint32_t)m, 8 * KI + 2 * u);
+      acc = lane_write(acc, (uint32_t)(m >> 32), 8 * KI + 2 * u + 1);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      unsigned long long m = 0;
+      const int i = ia + 64 * u + lane;
+      const bool cand = trip0 + u < ntrips && iv2[u] >= iv_min2 && i >= P.ilo && i <= P.ihi;
+      if (__builtin_amdgcn_ballot_w64(cand)) {
+        // a window clipped by a row end: the mean of two means; in float first (a relative 1e-5 covers its handful of roundings), the reference's
+        // double arithmetic for what that cannot decide. An empty window makes the reference's mean NaN: no detection.
+        const int tn = min(i - g, w), fn = min(R - i - g, w);
+        const float thr = kscale * ((float)ts[u] * __builtin_amdgcn_rcpf((float)tn) + (float)fs[u] * __builtin_amdgcn_rcpf((float)fn));
+        const float I2 = (float)iv2[u];
+        const bool both = tn > 0 && fn > 0;
+        const bool sure = both && I2 > thr * 1.00001f;
+        bool hit = cand && sure;
+        const bool doubt = cand && both && !sure && I2 >= thr * 0.99999f;
+        if (__builtin_amdgcn_ballot_w64(doubt)) {
+          if (doubt) hit = cfar_exact_vals(ts[u], tn, fs[u], fn, iv2[u], P.scaling);
+        }
+        m = __builtin_amdgcn_ballot_w64(hit);
+      }
+      cnt += __popcll(m);
+      acc = lane_write(acc, (uint32_t)m, 8 * KI + 2 * u);
+      acc = lane_write(acc, (uint32_t)(m >> 32), 8 * KI + 2 * u + 1);
+    }
+  }
+}
+template <int TB /* bins per thread of the prefix pass: 16 or 32 */>
+__global__ __launch_bounds__(CFAR_BLOCK) void cfar_detect_fast_kernel(const uint8_t* __restrict__ polar, CfarParams P, int pad, int* __restrict__ row_count,
+                                                                      uint32_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cfar_lds[];  // prefix[-pad .. 256 TB + pad] (a bin's own square is a difference of it too)
+  __shared__ int red_i[64];
+  typedef __attribute__((address_space(3))) uint32_t l_u32;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+  typedef __attribute__((address_space(3))) u32x4 l_u32x4;
+  typedef __attribute__((address_space(1))) const uint32_t g_cu32;
+  typedef __attribute__((address_space(1))) const u32x4a g_cu32x4;
+  constexpr int ND = TB / 4, NB = CFAR_BLOCK * TB;  // dwords per thread, bins the segments cover
+  const int R = P.R, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  l_u32* const prefix = (l_u32*)cfar_lds + pad;
+  const int grow = blockIdx.x, ndw = R >> 2;
+  g_cu32* src = (g_cu32*)(polar + (long long)grow * R);
+  uint32_t seg[ND];
+  if (ND * tid + ND <= ndw) {  // this thread's own bins, straight from memory: 16 bytes per load, consecutive threads consecutive
+#pragma unroll
+    for (int j = 0; j < ND; j += 4) {
+      const u32x4 v = __builtin_nontemporal_load((g_cu32x4*)(src + ND * tid + j));
+      seg[j] = v.x; seg[j + 1] = v.y; seg[j + 2] = v.z; seg[j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < ND; j++) seg[j] = ND * tid + j < ndw ? __builtin_nontemporal_load(src + ND * tid + j) : 0u;
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < ND; j++) s = __builtin_amdgcn_udot4(seg[j], seg[j], s, false);
+  for (int i = tid; i < pad; i += CFAR_BLOCK) prefix[-pad + i] = 0u;
+  int tot;
+  uint32_t o = (uint32_t)block_exclusive_scan<CFAR_BLOCK>((int)s, red_i, &tot);
+#pragma unroll
+  for (int j = 0; j < ND; j++) {
+    const uint32_t d = seg[j], b0 = d & 0xFFu, b1 = (d >> 8) & 0xFFu, b2 = (d >> 16) & 0xFFu, b3 = d >> 24;
+    u32x4 v;
+    v.x = o; o += b0 * b0; v.y = o; o += b1 * b1; v.z = o; o += b2 * b2; v.w = o; o += b3 * b3;
+    *(l_u32x4*)(prefix + TB * tid + 4 * j) = v;  // prefix[i .. i + 3], i = TB tid + 4 j (bins >= R are zeros: prefix[R ..] = the row total)
+  }
+  for (int i = NB + tid; i <= NB + pad; i += CFAR_BLOCK) prefix[i] = (uint32_t)tot;
+  __syncthreads();
+  // ---- decisions: wave wv takes the iterations wv, wv + 4, ... of four trips (256 bins) each; their masks collect in the lanes of one register ----
+  const int ntrips = (R + 63) >> 6;
+  const float kf_hi = P.kf * 1.000002f, kf_lo = P.kf * 0.999998f, kscale = P.kf * (float)P.window;  // (scaling / 2, to a rounding: the margins cover it)
+  const int iv_min2 = P.iv_min * P.iv_min;
+  constexpr int ITERS = TB / 4;  // NB / 256 iterations over four waves
+  int cnt = 0;
+  uint32_t acc = 0;
+  if (4 * wv < ntrips) cfar_four_trips<0, TB>(P, prefix, 4 * wv, ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+  if (4 * (wv + 4) < ntrips) cfar_four_trips<1, TB>(P, prefix, 4 * (wv + 4), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+  if (4 * (wv + 8) < ntrips) cfar_four_trips<2, TB>(P, prefix, 4 * (wv + 8), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+  if (4 * (wv + 12) < ntrips) cfar_four_trips<3, TB>(P, prefix, 4 * (wv + 12), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+  if constexpr (ITERS > 4) {
+    if (4 * (wv + 16) < ntrips) cfar_four_trips<4, TB>(P, prefix, 4 * (wv + 16), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+    if (4 * (wv + 20) < ntrips) cfar_four_trips<5, TB>(P, prefix, 4 * (wv + 20), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+    if (4 * (wv + 24) < ntrips) cfar_four_trips<6, TB>(P, prefix, 4 * (wv + 24), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+    if (4 * (wv + 28) < ntrips) cfar_four_trips<7, TB>(P, prefix, 4 * (wv + 28), ntrips, lane, kf_lo, kf_hi, kscale, iv_min2, acc, cnt);
+  }
+  {  // lane 8 k + 2 u + h holds half h of trip 4 (wv + 4 k) + u
+    const int trip = 4 * (wv + 4 * (lane >> 3)) + ((lane >> 1) & 3);
+    if (lane < 8 * ITERS && trip < ntrips) mask[(size_t)grow * P.mask_words + 2 * trip + (lane & 1)] = acc;
+  }
+  if (lane == 0) red_i[32 + wv] = cnt;
+  __syncthreads();
+  if (tid == 0) row_count[grow] = red_i[32] + red_i[33] + red_i[34] + red_i[35];
+}
+
 // one wave per row: the row's mask -> its points, in range-bin order, at the row's offset of its image's cloud
 __global__ __launch_bounds__(64) void cfar_emit_kernel(const uint8_t* __restrict__ polar, CfarParams P, const double* __restrict__ trig,
                                                        const int* __restrict__ row_count, const int* __restrict__ row_base,
@@ -199,7 +359,21 @@ int cfar_params(cfear_ctx* ctx, int window_size, int nb_guard_cells, float false
   return CFEAR_OK;
 }
 size_t cfar_lds_bytes(const CfarParams& P) { return sizeof(uint32_t) * (size_t)(P.R + 1) + (size_t)((P.R + 3 + 7) & ~3); }
+template <int TB>
+int cfar_launch_fast(cfear_ctx* ctx, const CfarParams& P, const uint8_t* d_polar, size_t rows, int* d_count, uint32_t* d_mask, hipStream_t stream) {
+  const int pad = (P.guard + P.window + 3) & ~3;
+  const size_t lds = sizeof(uint32_t) * ((size_t)pad + CFAR_BLOCK * TB + pad + 4);  // the padded prefix array
+  if (lds > 64 * 1024)
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_detect_fast_kernel<TB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((cfar_detect_fast_kernel<TB>), dim3((unsigned)rows), dim3(CFAR_BLOCK), lds, stream, d_polar, P, pad, d_count, d_mask);
+  return CFEAR_OK;
+}
 int cfar_launch_detect(cfear_ctx* ctx, const CfarParams& P, const uint8_t* d_polar, size_t rows, int* d_count, uint32_t* d_mask, hipStream_t stream) {
+  // the lean kernel when the rows are dword-aligned, fit 256 threads x 16 (32) bins, and the window is not enormous (its pads live in LDS)
+  if ((P.R & 3) == 0 && (reinterpret_cast<uintptr_t>(d_polar) & 3) == 0 && P.guard + P.window <= 2048 && P.iv_min <= 255 && !getenv("CFEAR_CFAR_GENERAL_KERNEL")) {
+    if (P.R <= CFAR_BLOCK * 16) return cfar_launch_fast<16>(ctx, P, d_polar, rows, d_count, d_mask, stream);
+    if (P.R <= CFAR_BLOCK * 32) return cfar_launch_fast<32>(ctx, P, d_polar, rows, d_count, d_mask, stream);
+  }
   const size_t lds = cfar_lds_bytes(P);
   if (lds > 64 * 1024)
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_detect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

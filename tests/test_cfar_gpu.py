@@ -39,6 +39,23 @@ def test_parameter_sweep_bit_exact(oracle, window, guard, pfa, mind, zmin):
     run(img, oracle, zmin, mind, window, guard, pfa)
 
 
+@pytest.mark.parametrize("R", [776, 3360, 6000])
+@pytest.mark.parametrize("window,guard,pfa,mind,zmin", [(40, 5, 0.01, 2.5, 60.0), (3, 0, 0.2, 0.0, 0.0), (60, 30, 0.001, 1.0, 10.0), (1, 1, 0.5, 2.5, 0.0),
+                                                       (500, 10, 0.0001, 2.5, 20.0), (40, 10, 0.01, 0.0, 20.0)])
+def test_parameter_sweep_rows_of_whole_dwords(oracle, R, window, guard, pfa, mind, zmin):
+    """rows whose length is a multiple of four take cfar_detect_fast_kernel (16 bins per thread up to 4096 bins, 32 up to 8192):
+    windows longer than the row's ends, a range gate that starts at bin 0, windows of one bin, and - the second image - plateaus of
+    equal bytes, where I^2 sits on the threshold to the last bit of the float pre-test (the reference's double arithmetic decides)"""
+    rng = np.random.default_rng(window * 100 + guard + R)
+    img = rng.integers(0, 256, size=(24, R), dtype=np.uint8)
+    img[:, -40:] = np.maximum(img[:, -40:], 180)  # strong returns inside the clipped windows of the far end
+    img[:, :60] = np.maximum(img[:, :60], 150)
+    run(img, oracle, zmin, mind, window, guard, pfa)
+    levels = np.array([0, 40, 40, 80, 120, 200], dtype=np.uint8)
+    img = np.repeat(levels[rng.integers(0, len(levels), size=(24, R // 8))], 8, axis=1)
+    run(np.ascontiguousarray(img), oracle, zmin, mind, window, guard, pfa)
+
+
 def test_world_sweep_host_and_device_entry_points(oracle):
     img = synth.world_scan(synth.World(7), 3, seed=2)
     n = run(img, oracle)

@@ -7,7 +7,9 @@ B = int(os.environ.get("CFAR_B", "1536")); U = 16
 w = synth.World(1234)
 uniq = torch.from_numpy(np.stack([synth.world_scan(w, u, A, R, RR, seed=1) for u in range(U)])).cuda()
 d = uniq[torch.arange(B, device="cuda") % U].contiguous()
-for zmin, win, guard, pfa in ((20.0, 40, 10, 0.01), (60.0, 10, 20, 0.01), (20.0, 500, 10, 0.0001)):
+PRESETS = ((20.0, 40, 10, 0.01), (60.0, 10, 20, 0.01), (20.0, 500, 10, 0.0001))
+if os.environ.get("CFAR_PRESET"): PRESETS = (PRESETS[int(os.environ["CFAR_PRESET"])],)  # (counters of one preset: tools/pmc_cfar.sh)
+for zmin, win, guard, pfa in PRESETS:
     ctx = capi.Context(capi.default_params(range_res=RR, z_min=zmin), A, R, stream=torch.cuda.current_stream().cuda_stream)
     cap = 16384
     xyi = torch.empty((B, cap, 3), dtype=torch.float32, device="cuda"); cnt = torch.empty((B,), dtype=torch.int32, device="cuda")
