@@ -9,7 +9,7 @@
 //                       out is a bit per range bin (the row's hit mask) and the row's count;
 //   cfar_row_scan_kernel  row counts -> row offsets of every image (the output cloud is row-major over (azimuth, range bin) like
 //                       the reference's push_back order);
-//   cfar_emit_kernel    one wave per row walks the mask and writes the points (the intensity is a gather of the hit bytes).
+//   cfar_emit_kernel    a wave per four rows walks their masks and writes the points (the intensity is a gather of the hit bytes).
 // The decision replays the reference's double arithmetic (sum / N per window, (t + f) / 2, scaling * mean, I^2 > threshold; an empty
 // window gives 0/0 = NaN and no detection) - but only where it has to: with z_min = 20 (the reference's own CA-CFAR preset,
 // params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar:27) nearly every bin passes the static test, and two double divisions per bin made
@@ -281,37 +281,81 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_detect_fast_kernel(const uint
   if (tid == 0) row_count[grow] = red_i[32] + red_i[33] + red_i[34] + red_i[35];
 }
 
-// one wave per row: the row's mask -> its points, in range-bin order, at the row's offset of its image's cloud
-__global__ __launch_bounds__(64) void cfar_emit_kernel(const uint8_t* __restrict__ polar, CfarParams P, const double* __restrict__ trig,
-                                                       const int* __restrict__ row_count, const int* __restrict__ row_base,
-                                                       const uint32_t* __restrict__ mask, float* __restrict__ xyi, int cap) {
-  const int grow = blockIdx.x, lane = threadIdx.x;
-  if (row_count[grow] == 0) return;
-  const int img = grow / P.A, az = grow - img * P.A;
-  const uint32_t* mrow = mask + (size_t)grow * P.mask_words;
+// a wave per four consecutive rows: the rows' masks -> their points, in range-bin order, at each row's offset of its image's cloud. (One
+// single-wave workgroup per row - 614 400 of them per 1536 sweeps, nine detections each - spent its time being dispatched: 430 us; the
+// counts, bases and mask words of a wave's four rows are in flight together here.)
+constexpr int CFAR_EMIT_ROWS = 4;
+__device__ __forceinline__ int cfar_emit_word(uint32_t m, int k, int o, int cap, const uint8_t* __restrict__ row, double range_res, double cos_t, double sin_t,
+                                              float* __restrict__ xyi) {
+  while (m) {
+    const int b = __ffs((int)m) - 1;
+    m &= m - 1;
+    const int i = 32 * k + b;
+    if (o < cap) {
+      const double range = range_res * (double)i;
+      xyi[3 * (size_t)o + 0] = (float)(range * cos_t);  // cfar.cpp:63-65
+      xyi[3 * (size_t)o + 1] = (float)(range * sin_t);
+      xyi[3 * (size_t)o + 2] = (float)row[i];
+    }
+    o++;
+  }
+  return o;
+}
+__global__ __launch_bounds__(CFAR_BLOCK) void cfar_emit_kernel(const uint8_t* __restrict__ polar, CfarParams P, const double* __restrict__ trig,
+                                                               const int* __restrict__ row_count, const int* __restrict__ row_base,
+                                                               const uint32_t* __restrict__ mask, float* __restrict__ xyi, int cap, long long rows) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long g0 = ((long long)blockIdx.x * (CFAR_BLOCK / 64) + wv) * CFAR_EMIT_ROWS;
+  if (g0 >= rows) return;
+  int cnt[CFAR_EMIT_ROWS], base[CFAR_EMIT_ROWS], any = 0;
+#pragma unroll
+  for (int r = 0; r < CFAR_EMIT_ROWS; r++) {
+    const bool valid = g0 + r < rows;
+    cnt[r] = valid ? row_count[g0 + r] : 0;
+    base[r] = valid ? row_base[g0 + r] : 0;
+    any |= cnt[r];
+  }
+  if (!any) return;
   const int wpl = (P.mask_words + 63) >> 6;  // consecutive mask words per lane
   const int w0 = min(P.mask_words, lane * wpl), w1 = min(P.mask_words, w0 + wpl);
-  int c = 0;
-  for (int k = w0; k < w1; k++) c += __popc(mrow[k]);
-  int o = wave_inclusive_scan(c) - c + row_base[grow];
-  if (c == 0) return;
-  const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];  // theta = (az + 1) / A * 2 pi, host libm (cfar.cpp:40)
-  const uint8_t* row = polar + (long long)grow * P.R;
-  xyi += 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
-  for (int k = w0; k < w1; k++) {
-    uint32_t m = mrow[k];
-    while (m) {
-      const int b = __ffs((int)m) - 1;
-      m &= m - 1;
-      const int i = 32 * k + b;
-      if (o < cap) {
-        const double range = P.range_res * (double)i;
-        xyi[3 * (size_t)o + 0] = (float)(range * cos_t);  // :63-65
-        xyi[3 * (size_t)o + 1] = (float)(range * sin_t);
-        xyi[3 * (size_t)o + 2] = (float)row[i];
-      }
-      o++;
+  if (wpl <= 2) {  // (rows up to 4096 bins)
+    uint32_t m[CFAR_EMIT_ROWS][2];
+#pragma unroll
+    for (int r = 0; r < CFAR_EMIT_ROWS; r++) {
+      const uint32_t* mrow = mask + (size_t)(g0 + r) * P.mask_words;
+      m[r][0] = (cnt[r] && w0 < w1) ? mrow[w0] : 0u;
+      m[r][1] = (cnt[r] && w0 + 1 < w1) ? mrow[w0 + 1] : 0u;
     }
+#pragma unroll
+    for (int r = 0; r < CFAR_EMIT_ROWS; r++) {
+      if (!cnt[r]) continue;  // (wave-uniform)
+      const long long grow = g0 + r;
+      const int img = (int)(grow / P.A), az = (int)(grow - (long long)img * P.A);
+      const int c = __popc(m[r][0]) + __popc(m[r][1]);
+      int o = wave_inclusive_scan(c) - c + base[r];
+      if (c) {
+        const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];  // theta = (az + 1) / A * 2 pi, host libm (cfar.cpp:40)
+        const uint8_t* row = polar + grow * P.R;
+        float* out = xyi + 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
+        o = cfar_emit_word(m[r][0], w0, o, cap, row, P.range_res, cos_t, sin_t, out);
+        cfar_emit_word(m[r][1], w0 + 1, o, cap, row, P.range_res, cos_t, sin_t, out);
+      }
+    }
+    return;
+  }
+  for (int r = 0; r < CFAR_EMIT_ROWS; r++) {
+    if (!cnt[r]) continue;
+    const long long grow = g0 + r;
+    const int img = (int)(grow / P.A), az = (int)(grow - (long long)img * P.A);
+    const uint32_t* mrow = mask + (size_t)grow * P.mask_words;
+    int c = 0;
+    for (int k = w0; k < w1; k++) c += __popc(mrow[k]);
+    int o = wave_inclusive_scan(c) - c + base[r];
+    if (c == 0) continue;
+    const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];
+    const uint8_t* row = polar + grow * P.R;
+    float* out = xyi + 3 * (size_t)img * cap;
+    for (int k = w0; k < w1; k++) o = cfar_emit_word(mrow[k], k, o, cap, row, P.range_res, cos_t, sin_t, out);
   }
 }
 
@@ -404,7 +448,8 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_gua
   rc = cfear_cloud_alloc(ctx, total, &c);
   if (rc != CFEAR_OK) { (void)hipFree(d_tmp); return rc; }
   if (total > 0)
-    hipLaunchKernelGGL(cfar_emit_kernel, dim3(P.A), dim3(64), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask, c->d_xyi, c->cap);
+    hipLaunchKernelGGL(cfar_emit_kernel, dim3((P.A + 4 * CFAR_EMIT_ROWS - 1) / (4 * CFAR_EMIT_ROWS)), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask,
+                       c->d_xyi, c->cap, (long long)P.A);
   e = hipMemcpyAsync(c->d_n, d_total, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_tmp);
@@ -435,7 +480,8 @@ __attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx
   rc = cfar_launch_detect(ctx, P, d_polar, rows, d_count, d_mask, stream);
   if (rc != CFEAR_OK) return rc;
   hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, d_count, P.A, d_base, d_counts);
-  hipLaunchKernelGGL(cfar_emit_kernel, dim3((unsigned)rows), dim3(64), 0, stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask, d_xyi, capacity);
+  hipLaunchKernelGGL(cfar_emit_kernel, dim3((unsigned)((rows + 4 * CFAR_EMIT_ROWS - 1) / (4 * CFAR_EMIT_ROWS))), dim3(CFAR_BLOCK), 0, stream, d_polar, P, ctx->d_trig, d_count, d_base,
+                     d_mask, d_xyi, capacity, (long long)rows);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
