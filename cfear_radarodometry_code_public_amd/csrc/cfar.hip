@@ -167,17 +167,18 @@ __device__ __forceinline__ void cfar_four_trips(const CfarParams& P, __attribute
 #pragma unroll
     for (int u = 0; u < U; u++) {
       unsigned long long m = 0;
-      const bool cand = iv2[u] >= iv_min2;  // cfar.cpp:45 (I >= I_min <=> I^2 >= I_min^2)
-      if (__builtin_amdgcn_ballot_w64(cand)) {
+      // (every predicate a comparison of its own, combined on the scalar unit: a ballot of `a && b` comes back through a VGPR)
+      const unsigned long long candm = __builtin_amdgcn_ballot_w64(iv2[u] >= iv_min2);  // cfar.cpp:45 (I >= I_min <=> I^2 >= I_min^2)
+      if (candm) {
         const float Sf = (float)S[u], I2 = (float)iv2[u];
-        const unsigned long long open = __builtin_amdgcn_ballot_w64(cand && I2 >= Sf * kf_lo);  // hits are one bin in a few hundred: the common trip ends here
+        const unsigned long long open = candm & __builtin_amdgcn_ballot_w64(I2 >= Sf * kf_lo);  // hits are one bin in a few hundred: the common trip ends here
         if (open) {
-          const bool sure = I2 > Sf * kf_hi;
-          m = open & __builtin_amdgcn_ballot_w64(sure);
-          const bool tie = ((open >> lane) & 1) && !sure;  // near-ties of the float test: the reference's arithmetic
-          if (__builtin_amdgcn_ballot_w64(tie)) {
+          const unsigned long long surem = __builtin_amdgcn_ballot_w64(I2 > Sf * kf_hi);
+          m = open & surem;
+          const unsigned long long tiem = open & ~surem;  // near-ties of the float test: the reference's arithmetic
+          if (tiem) {
             bool hit = false;
-            if (tie) hit = cfar_exact_vals(ts[u], w, fs[u], w, iv2[u], P.scaling);
+            if ((tiem >> lane) & 1) hit = cfar_exact_vals(ts[u], w, fs[u], w, iv2[u], P.scaling);
             m |= __builtin_amdgcn_ballot_w64(hit);
           }
         }
