@@ -13,7 +13,12 @@ the pose (1e-4 m, 1e-5 rad) - by both routes: cfear_odometry_replay_host with on
     (registration_dev.h build_problem_block) and a sized-down object has to hold (cfear_tune MAX_CELLS);
   * params/loss_function/loss_function_cfear-3:13-22 - loss_limit 0.01 ... 4 x {None, Cauchy, Tukey, SoftLOne, Huber}, P2P,
     four keyframes;
-  * params/weight_residual/oxford_cfear-3:25 - weight_option 0 ... 5, P2P, k = 40.
+  * params/weight_residual/oxford_cfear-3:25 - weight_option 0 ... 5, P2P, k = 40;
+  * params/submap_keyframes/submap_keyframe_cfear-3:13-15 - submap_scan_size 1 ... 10 x {P2P, P2L, P2D}, unweighted, the Mulran twin
+    (mulran_keyframe_cfear-3:11,20) with radar_ccw = true and range_res 0.0595238 (tests/test_large_submap_gpu.py has 5, 7, 8, 10
+    and 50 keyframes by the batched routes; here the sizes between, by the persistent replay route);
+  * params/grid_search/oxford_cfear-3-p2l:13-20 - the corners of the P2L grid search: k 30 / 50, z_min 50 / 70, res 2.5 / 2.75,
+    5 / 6 keyframes, loss_limit 0.2 / 0.3.
 """
 import os
 
@@ -130,3 +135,30 @@ def test_loss_function_sweep_batched_route(oracle, loss, limit, route):
 def test_weight_option_sweep_replay(oracle, weight_opt):
     p = dict(CFEAR3_GRID, k_strongest=40, weight_opt=weight_opt)
     _replay(oracle, "weight_option %d" % weight_opt, "blocks", 120, p)
+
+
+# ---- keyframes per submap ---------------------------------------------------------------------------------------------------------
+SUBMAP_GRID = dict(CFEAR3_GRID, weight_intensity=0, weight_opt=0, min_keyframe_dist=1.5)
+
+
+@pytest.mark.parametrize("s,cost", [(s, c) for s in (2, 3, 6, 9) for c in (P2P, P2L, P2D)])
+def test_submap_keyframes_sweep_replay(oracle, s, cost):
+    p = dict(SUBMAP_GRID, submap_scan_size=s, cost=cost)
+    out = _replay(oracle, "submap %d cost %d" % (s, cost), "blocks", 60 + 25 * s, p)
+    assert out["keyframes_max"] == s
+
+
+@pytest.mark.parametrize("s,cost", [(4, P2D), (6, P2L)])
+def test_submap_keyframes_mulran_twin(oracle, s, cost):
+    """the Mulran presets turn the sensor the other way round (radar_ccw: the sign of the sweep's bearing in Compensate, utils.cpp:96-113)"""
+    p = dict(SUBMAP_GRID, submap_scan_size=s, cost=cost, radar_ccw=1)
+    _replay(oracle, "mulran submap %d cost %d" % (s, cost), "canyon", 60 + 25 * s, p)
+
+
+# ---- the P2L grid search ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,zmin,res,s,limit,route", [(50, 70.0, 2.5, 6, 0.3, "replay"), (30, 50.0, 2.75, 5, 0.2, "step"), (50, 50.0, 3.0, 4, 0.1, "step")])
+def test_grid_search_corners(oracle, k, zmin, res, s, limit, route):
+    p = dict(CFEAR3_GRID, cost=P2L, k_strongest=k, z_min=zmin, res=res, submap_scan_size=s, loss_limit=limit)
+    st = {}
+    drive_parity.run_batched(oracle, p, "canyon", max(int((40 + 12 * s) * SCALE), 8), route=route, stats=st)
+    assert st["keyframes_max"] == s, st
