@@ -22,10 +22,15 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
     """-> dict(mismatches=[(sweep, what, device, oracle)], poses_dev, poses_cpu, gt, cells, seconds...)"""
     kw = dict(BASE)
     kw.update(params or {})
+    cfar = kw.pop("cfar", None)  # dict(window_size, nb_guard_cells, false_alarm_rate): CA-CFAR in front of the fuser instead of k-strongest
     world = synth.DriveWorld(kind, world_seed)
     poses_w, motions, gt = synth.drive_plan(T, world, seed)
     fu = oracle.Fuser(oracle.default_params(**kw))
-    ctx = capi.Context(capi.default_params(**kw), A, R, device=device)
+    hip_kw = dict(kw)
+    if cfar:
+        hip_kw.update(filter_type=capi.FILTER_CACFAR, cfar_window_size=cfar["window_size"], cfar_nb_guard_cells=cfar["nb_guard_cells"],
+                      cfar_false_alarm_rate=cfar["false_alarm_rate"])
+    ctx = capi.Context(capi.default_params(**hip_kw), A, R, device=device)
     if persistent_max is not None:
         ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, persistent_max)
     odo = ctx.odometry(1)
@@ -44,7 +49,10 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
         t_dev += time.time() - t0
         t0 = time.time()
         for i in range(fill):
-            e = fu.process_polar(buf[i, 0])
+            if cfar:  # the oracle's detector (cfar.cpp:27-87; min_distance 2.5 as radar_driver.cpp:52-56 passes it), then the fuser on its cloud
+                e = fu.process_cloud(oracle.cfar(buf[i, 0], float(np.float32(kw["range_res"])), float(kw["z_min"]), 2.5, **cfar))
+            else:
+                e = fu.process_polar(buf[i, 0])
             S = fu.last_summary()
             no = max(int(S.outer_iterations), 0)
             exp = (int(S.outer_iterations), [int(v) for v in S.inner_iterations[:min(no, 8)]], int(S.num_residuals), int(fu.num_keyframes),

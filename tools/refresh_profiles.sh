@@ -30,3 +30,4 @@ cd $R; timeout 300 python tools/gpu_time_cfar.py 2>&1 | grep -v amdgpu > $O/${P}
 (timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -12) > $O/${P}_gpu_tests.log 2>&1
 for ps in cfear1 nocomp_p2p_k40 res1_s3; do timeout 900 python tests/run_drive_parity.py canyon ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_canyon_$ps.json $ps > /dev/null 2>&1; done
 timeout 900 python tests/run_drive_parity.py blocks 10000 $O/${P}_drive10k_blocks_cfear1.json cfear1 > /dev/null 2>&1
+for k in canyon blocks; do timeout 900 python tests/run_drive_parity.py $k ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_${k}_ca_cfar.json ca_cfar > /dev/null 2>&1; done  # (the oracle's literal detector: ~75 ms per sweep)
