@@ -9,10 +9,13 @@
 // them densely: 5 passes instead of 13), ALL EIGHT waves evaluate, and the unit's whole LDS holds the matches (2250 residual blocks
 // with all eight arrays; P2L 2571, P2P 3600). Same device code, same results as the 256-thread kernels up to the summation order of
 // the evaluation's partial sums (eight waves instead of four).
-#define CFEAR_REG_BLOCK 512
-#define CFEAR_EVAL_WAVES 8
+#ifndef CFEAR_LARGE_BLOCK
+#define CFEAR_LARGE_BLOCK 512    // tools: A/B builds (256 with two workgroups per unit: the 512-register budget per thread, two controllers that take turns)
+#endif
+#define CFEAR_REG_BLOCK CFEAR_LARGE_BLOCK
+#define CFEAR_EVAL_WAVES (CFEAR_LARGE_BLOCK / 64)
 #ifndef CFEAR_LARGE_WG_PER_CU
-#define CFEAR_LARGE_WG_PER_CU 1  // tools: A/B builds (2: half the unit's LDS and registers each)
+#define CFEAR_LARGE_WG_PER_CU 1  // tools: A/B builds (2: half the unit's LDS each)
 #endif
 #if CFEAR_LARGE_WG_PER_CU == 1
 #define CFEAR_MATCH_LDS_CAP 2250
@@ -26,7 +29,7 @@
 
 namespace {
 template <bool TIMED, int KCOST>
-__global__ __launch_bounds__(BLOCK_R, 2 * CFEAR_LARGE_WG_PER_CU /* waves per SIMD */) void register_step_large_kernel(OdoParams OP, SeqState* states, const BlockScratch* scratch, double* cov_work,
+__global__ __launch_bounds__(BLOCK_R, (CFEAR_LARGE_BLOCK / 256) * CFEAR_LARGE_WG_PER_CU /* waves per SIMD */) void register_step_large_kernel(OdoParams OP, SeqState* states, const BlockScratch* scratch, double* cov_work,
                                                                       cfear_reg_summary* summaries, double* poses_out) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[RegLds::total];
   register_step_body<TIMED, KCOST>(lds, OP.order ? OP.order[blockIdx.x] : OP.seq0 + (int)blockIdx.x, OP, states, scratch, cov_work, summaries, poses_out);
