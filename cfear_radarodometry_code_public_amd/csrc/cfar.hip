@@ -415,7 +415,8 @@ int cfar_launch_fast(cfear_ctx* ctx, const CfarParams& P, const uint8_t* d_polar
 }
 int cfar_launch_detect(cfear_ctx* ctx, const CfarParams& P, const uint8_t* d_polar, size_t rows, int* d_count, uint32_t* d_mask, hipStream_t stream) {
   // the lean kernel when the rows are dword-aligned, fit 256 threads x 16 (32) bins, and the window is not enormous (its pads live in LDS)
-  if ((P.R & 3) == 0 && (reinterpret_cast<uintptr_t>(d_polar) & 3) == 0 && P.guard + P.window <= 2048 && P.iv_min <= 255 && !getenv("CFEAR_CFAR_GENERAL_KERNEL")) {
+  static const bool general_only = getenv("CFEAR_CFAR_GENERAL_KERNEL") != nullptr;  // tools/gpu_time_cfar.py: A/B timing of the two detectors
+  if ((P.R & 3) == 0 && (reinterpret_cast<uintptr_t>(d_polar) & 3) == 0 && P.guard + P.window <= 2048 && P.iv_min <= 255 && !general_only) {
     if (P.R <= CFAR_BLOCK * 16) return cfar_launch_fast<16>(ctx, P, d_polar, rows, d_count, d_mask, stream);
     if (P.R <= CFAR_BLOCK * 32) return cfar_launch_fast<32>(ctx, P, d_polar, rows, d_count, d_mask, stream);
   }
