@@ -104,6 +104,10 @@ void cfear_destroy(cfear_ctx* ctx) {
   if (ctx->d_slots) (void)hipFree(ctx->d_slots);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_cfar_rows) (void)hipFree(ctx->d_cfar_rows);
+  for (auto& b : ctx->pool) (void)hipFree(b.second);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->h_img) (void)hipHostFree(ctx->h_img);
+  if (ctx->ev_img) (void)hipEventDestroy(ctx->ev_img);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -150,6 +154,79 @@ int cfear_kstrongest_device(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   if (!ctx) return CFEAR_ERR_INVALID;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return cfear_launch_kstrongest(ctx, d_polar, n_scans, d_slots, ctx->stream);
+}
+
+// ---- block pool of the per-call handles (clouds, scans) and the pinned staging of their downloads (common.h) ----
+int cfear_pool_alloc(cfear_ctx* ctx, size_t bytes, void** out, size_t* got) {
+  const size_t need = (bytes + 4095) & ~(size_t)4095;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); i++)  // smallest parked block that fits without wasting more than half of it
+    if (ctx->pool[i].first >= need && ctx->pool[i].first <= 2 * need + 65536 && (best < 0 || ctx->pool[i].first < ctx->pool[best].first)) best = i;
+  if (best >= 0) {
+    *out = ctx->pool[best].second; *got = ctx->pool[best].first;
+    ctx->pool_bytes -= ctx->pool[best].first;
+    ctx->pool[best] = ctx->pool.back(); ctx->pool.pop_back();
+    return CFEAR_OK;
+  }
+  if (hipMalloc(out, need) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc (handle block)");
+  *got = need;
+  return CFEAR_OK;
+}
+void cfear_pool_free(cfear_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  constexpr size_t POOL_MAX_BYTES = (size_t)512 << 20;
+  constexpr size_t POOL_MAX_BLOCKS = 256;
+  if (!ctx) { (void)hipFree(p); return; }
+  // work on other streams of this context may still read the block: the old behaviour (wait for everything, give the memory back)
+  if (!ctx->aux_streams.empty() || ctx->pool_bytes + bytes > POOL_MAX_BYTES || ctx->pool.size() >= POOL_MAX_BLOCKS) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(p);
+    return;
+  }
+  ctx->pool.emplace_back(bytes, p);
+  ctx->pool_bytes += bytes;
+}
+int cfear_ensure_hstage(cfear_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->h_stage_bytes) return CFEAR_OK;
+  if (ctx->h_stage) { CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_stage); }
+  ctx->h_stage = nullptr; ctx->h_stage_bytes = 0;
+  const size_t want = (bytes + 65535) & ~(size_t)65535;
+  if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), want, hipHostMallocDefault) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipHostMalloc staging");
+  ctx->h_stage_bytes = want;
+  return CFEAR_OK;
+}
+
+// One polar image (or a few) from host memory to the device on the context stream. Pinned memory (cfear_host_alloc) goes by DMA directly.
+// Pageable memory - what a caller of radarDriver::CallbackOffline has (a cv::Mat, a std::vector) - is copied through a pinned staging
+// buffer of the context in 256 KB pieces, each piece's DMA running while the next is copied: measured on MI355X, hipMemcpyAsync from a
+// freshly allocated pageable 1.3 MB buffer took 600-700 us per sweep (2 GB/s; round 6, profiles/r06_dropin_phases.txt), the staged copy
+// is bound by the host's memcpy. Larger transfers than the staging (many images at once) take the runtime's own path.
+int cfear_upload_image(cfear_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+  constexpr size_t STAGE_MAX = (size_t)64 << 20, PIECE = (size_t)256 << 10;
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, h_src) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();  // (an ordinary host pointer is reported as an error by some runtimes)
+  if (pinned || bytes > STAGE_MAX) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CFEAR_OK;
+  }
+  if (ctx->ev_img_pending) { CFEAR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_img)); ctx->ev_img_pending = false; }  // the previous image has left the staging
+  if (bytes > ctx->h_img_bytes) {
+    if (ctx->h_img) (void)hipHostFree(ctx->h_img);
+    ctx->h_img = nullptr; ctx->h_img_bytes = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_img), bytes, hipHostMallocDefault) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipHostMalloc image staging");
+    ctx->h_img_bytes = bytes;
+  }
+  if (!ctx->ev_img) CFEAR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_img, hipEventDisableTiming));
+  for (size_t off = 0; off < bytes; off += PIECE) {
+    const size_t nb = bytes - off < PIECE ? bytes - off : PIECE;
+    memcpy(ctx->h_img + off, static_cast<const unsigned char*>(h_src) + off, nb);
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<unsigned char*>(d_dst) + off, ctx->h_img + off, nb, hipMemcpyHostToDevice, ctx->stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(ctx->ev_img, ctx->stream));
+  ctx->ev_img_pending = true;
+  return CFEAR_OK;
 }
 
 int cfear_ensure_staging(cfear_ctx* ctx, int n_scans) {

@@ -435,26 +435,27 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_gua
   int rc = cfar_params(ctx, window_size, nb_guard_cells, false_alarm_rate, max_distance, &P);
   if (rc != CFEAR_OK) return rc;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int* d_tmp = nullptr;  // row counts, row bases, total, masks
-  if (hipMalloc(&d_tmp, sizeof(int) * ((2 + (size_t)P.mask_words) * P.A + 1)) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cfar rows");
+  int* d_tmp = nullptr;  // row counts, row bases, total, masks (a block of the context's pool)
+  size_t tmp_bytes = 0;
+  { void* blk = nullptr; rc = cfear_pool_alloc(ctx, sizeof(int) * ((2 + (size_t)P.mask_words) * P.A + 1), &blk, &tmp_bytes); if (rc != CFEAR_OK) return rc; d_tmp = static_cast<int*>(blk); }
   int* d_count = d_tmp; int* d_base = d_tmp + P.A; int* d_total = d_tmp + 2 * P.A;
   uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_total + 1);
   rc = cfar_launch_detect(ctx, P, d_polar, (size_t)P.A, d_count, d_mask, ctx->stream);
-  if (rc != CFEAR_OK) { (void)hipFree(d_tmp); return rc; }
+  if (rc != CFEAR_OK) { cfear_pool_free(ctx, d_tmp, tmp_bytes); return rc; }
   hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_total);
   int total = 0;
   hipError_t e = hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { (void)hipFree(d_tmp); return cfear_fail(ctx, CFEAR_ERR_HIP, "filter_cfar detect pass", e); }
+  if (e != hipSuccess) { cfear_pool_free(ctx, d_tmp, tmp_bytes); return cfear_fail(ctx, CFEAR_ERR_HIP, "filter_cfar detect pass", e); }
   cfear_cloud* c = nullptr;
   rc = cfear_cloud_alloc(ctx, total, &c);
-  if (rc != CFEAR_OK) { (void)hipFree(d_tmp); return rc; }
+  if (rc != CFEAR_OK) { cfear_pool_free(ctx, d_tmp, tmp_bytes); return rc; }
   if (total > 0)
     hipLaunchKernelGGL(cfar_emit_kernel, dim3((P.A + 4 * CFAR_EMIT_ROWS - 1) / (4 * CFAR_EMIT_ROWS)), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask,
                        c->d_xyi, c->cap, (long long)P.A);
   e = hipMemcpyAsync(c->d_n, d_total, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_tmp);
+  cfear_pool_free(ctx, d_tmp, tmp_bytes);
   if (e != hipSuccess) { cfear_cloud_release(ctx, c); return cfear_fail(ctx, CFEAR_ERR_HIP, "filter_cfar emit pass", e); }
   *out = c;
   return CFEAR_OK;
@@ -519,7 +520,8 @@ int cfear_filter_cfar(cfear_ctx* ctx, const uint8_t* h_polar, int window_size, i
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int rc = cfear_ensure_staging(ctx, 1);
   if (rc != CFEAR_OK) return rc;
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R, hipMemcpyHostToDevice, ctx->stream));
+  rc = cfear_upload_image(ctx, ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R);
+  if (rc != CFEAR_OK) return rc;
   return cfar_run(ctx, ctx->d_polar, window_size, nb_guard_cells, false_alarm_rate, max_distance, cloud);
 }
 

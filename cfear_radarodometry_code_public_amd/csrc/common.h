@@ -46,6 +46,21 @@ struct cfear_ctx {
   int tune_nn_tie = 0;  // which of several exactly equidistant cells GetClosestIdx returns: 0 lowest index (production), 1 highest, 2 FLANN's kd-tree order (parity mode, slow)
   int tune_repeat_shortcut = 1;  // registration: an outer iteration that would repeat the previous one bit for bit is not recomputed (0: it is - tests)
   int tune_replay_persistent_max = 256;  // cfear_odometry_replay_host: up to this many sequences run as persistent workgroups (replay.hip)
+  // Device blocks handed back by cfear_cloud_release / cfear_scan_release, reused by the next allocation of a similar size (round 6): the
+  // per-call route (radarDriver -> Compensate -> MapPointNormal -> Register, include/cfear_hip/cfear_host.hpp) creates and drops two clouds
+  // and a scan per sweep, and hipMalloc / hipFree (the latter a device-wide synchronisation) cost more than its kernels. Reuse is
+  // stream-ordered: every per-call entry point works on ctx->stream (a context with odometry objects on streams of their own keeps the
+  // synchronising release).
+  std::vector<std::pair<size_t, void*>> pool;
+  size_t pool_bytes = 0;
+  // pinned host staging of the per-call entry points: downloads that complete with ONE synchronisation, registration arguments in one copy
+  unsigned char* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+  // pinned staging of one polar image for callers that hand over pageable memory (cfear_upload_image), and the event after its last copy
+  unsigned char* h_img = nullptr;
+  size_t h_img_bytes = 0;
+  hipEvent_t ev_img = nullptr;
+  bool ev_img_pending = false;
 };
 
 static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -66,14 +81,20 @@ static inline int cfear_fail(cfear_ctx* c, int code, const char* what, hipError_
     if (_e != hipSuccess) return cfear_fail((ctx), CFEAR_ERR_HIP, #call, _e); \
   } while (0)
 
-struct cfear_cloud {  // pcl::PointCloud<pcl::PointXYZI> on the device
+struct cfear_cloud {  // pcl::PointCloud<pcl::PointXYZI> on the device: one block, the count in its first 16 bytes
   int cap = 0;
-  float* d_xyi = nullptr;  // [cap][3] x, y, intensity
-  int* d_n = nullptr;      // point count
+  float* d_xyi = nullptr;  // [cap][3] x, y, intensity (= block + 16)
+  int* d_n = nullptr;      // point count (= block)
+  void* block = nullptr;
+  size_t bytes = 0;
 };
 
 // cabi.hip
 extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_staging(cfear_ctx* ctx, int n_scans);
+extern "C" __attribute__((visibility("hidden"))) int cfear_pool_alloc(cfear_ctx* ctx, size_t bytes, void** out, size_t* got);
+extern "C" __attribute__((visibility("hidden"))) void cfear_pool_free(cfear_ctx* ctx, void* p, size_t bytes);
+extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_hstage(cfear_ctx* ctx, size_t bytes);
+extern "C" __attribute__((visibility("hidden"))) int cfear_upload_image(cfear_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 // pipeline.hip
 extern "C" __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);
 // kstrongest.hip

@@ -299,7 +299,9 @@ int set_kernel_attributes(cfear_ctx*) { return CFEAR_OK; }  // LDS is static (up
 }  // namespace
 
 struct cfear_scan {
-  unsigned char* d_block = nullptr;  // ScanDev header + arrays
+  unsigned char* d_block = nullptr;  // ScanDev header + arrays (a block of the context's pool)
+  size_t bytes = 0;
+  int n_cells = -1;                  // known on the host since creation (cfear_scan_size without a device round trip)
   int cap_points = 0;
   bool with_kd = false;  // built under cfear_tune NN_TIE_RULE = 2: carries the kd-tree the parity mode's search walks
 };
@@ -530,20 +532,17 @@ __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int 
   cfear_cloud* c = new (std::nothrow) cfear_cloud();
   if (!c) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "cloud alloc");
   c->cap = cap > 0 ? cap : 1;
-  if (hipMalloc(&c->d_xyi, sizeof(float) * 3 * (size_t)c->cap) != hipSuccess || hipMalloc(&c->d_n, sizeof(int)) != hipSuccess) {
-    if (c->d_xyi) (void)hipFree(c->d_xyi);
-    delete c;
-    return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cloud");
-  }
+  const int rc = cfear_pool_alloc(ctx, 16 + sizeof(float) * 3 * (size_t)c->cap, &c->block, &c->bytes);  // one block from the context's pool
+  if (rc != CFEAR_OK) { delete c; return rc; }
+  c->d_n = static_cast<int*>(c->block);
+  c->d_xyi = reinterpret_cast<float*>(static_cast<unsigned char*>(c->block) + 16);
   *out = c;
   return CFEAR_OK;
 }
 
 void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* c) {
   if (!c) return;
-  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-  if (c->d_xyi) (void)hipFree(c->d_xyi);
-  if (c->d_n) (void)hipFree(c->d_n);
+  cfear_pool_free(ctx, c->block, c->bytes);  // (stream-ordered reuse; no synchronisation, no hipFree on the per-sweep path)
   delete c;
 }
 
@@ -574,7 +573,8 @@ int cfear_filter_polar(cfear_ctx* ctx, const uint8_t* h_polar, cfear_cloud** clo
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int rc = cfear_ensure_staging(ctx, 1);
   if (rc != CFEAR_OK) return rc;
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R, hipMemcpyHostToDevice, ctx->stream));
+  rc = cfear_upload_image(ctx, ctx->d_polar, h_polar, (size_t)ctx->A * ctx->R);
+  if (rc != CFEAR_OK) return rc;
   return cfear_filter_polar_device(ctx, ctx->d_polar, cloud, cloud_peaks);
 }
 
@@ -601,17 +601,37 @@ int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* c, int* n) {
   return CFEAR_OK;
 }
 
-int cfear_cloud_download(cfear_ctx* ctx, const cfear_cloud* c, float* xyi, int capacity, int* n) {
-  int m = 0;
-  int rc = cfear_cloud_size(ctx, c, &m);
+// m clouds to the host with ONE synchronisation: count and points of every cloud travel together into pinned staging, the first
+// min(n, capacity) points are handed on (the per-sweep route downloads cloud and cloud_peaks, radar_driver.cpp:59-60 / utils.cpp:96-113)
+int cfear_clouds_download(cfear_ctx* ctx, const cfear_cloud* const* clouds, int m, float* const* xyi, const int* capacity, int* n) {
+  if (!ctx || !clouds || m <= 0 || m > 16) return cfear_fail(ctx, CFEAR_ERR_INVALID, "clouds_download: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t off[17]; off[0] = 0;
+  for (int i = 0; i < m; i++) {
+    if (!clouds[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "clouds_download: null cloud");
+    const int want = (xyi && xyi[i] && capacity) ? (capacity[i] < clouds[i]->cap ? capacity[i] : clouds[i]->cap) : 0;
+    off[i + 1] = off[i] + ((16 + sizeof(float) * 3 * (size_t)(want > 0 ? want : 0) + 63) & ~(size_t)63);
+  }
+  int rc = cfear_ensure_hstage(ctx, off[m]);
   if (rc != CFEAR_OK) return rc;
-  if (n) *n = m;
-  const int cnt = m < capacity ? m : capacity;
-  if (cnt > 0 && xyi) {
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyi, c->d_xyi, sizeof(float) * 3 * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
-    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < m; i++) {
+    const int want = (xyi && xyi[i] && capacity) ? (capacity[i] < clouds[i]->cap ? capacity[i] : clouds[i]->cap) : 0;
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_stage + off[i], clouds[i]->block, 16 + sizeof(float) * 3 * (size_t)(want > 0 ? want : 0), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < m; i++) {
+    const int cnt = *reinterpret_cast<const int*>(ctx->h_stage + off[i]);
+    if (n) n[i] = cnt;
+    const int want = (xyi && xyi[i] && capacity) ? (capacity[i] < clouds[i]->cap ? capacity[i] : clouds[i]->cap) : 0;
+    const int take = cnt < want ? cnt : want;
+    if (take > 0) memcpy(xyi[i], ctx->h_stage + off[i] + 16, sizeof(float) * 3 * (size_t)take);
   }
   return CFEAR_OK;
+}
+
+int cfear_cloud_download(cfear_ctx* ctx, const cfear_cloud* c, float* xyi, int capacity, int* n) {
+  if (!ctx || !c) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cloud_download: bad argument");
+  return cfear_clouds_download(ctx, &c, 1, &xyi, &capacity, n);
 }
 
 int cfear_compensate(cfear_ctx* ctx, cfear_cloud* c, const double motion_xyt[3], int ccw) {
@@ -688,7 +708,7 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = cap; s->with_kd = ctx->tune_nn_tie == 2;
   const ScanLayout L = scan_layout(cap, cap, true, ctx->tune_nn_tie == 2);
-  if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
+  { void* blk = nullptr; rc = cfear_pool_alloc(ctx, L.total, &blk, &s->bytes); if (rc != CFEAR_OK) { delete s; return rc; } s->d_block = static_cast<unsigned char*>(blk); }
   const ScanDev h = scan_header(s->d_block, cap, cap, true, ctx->tune_nn_tie == 2);
   ScanDev back;
   int* d_vorder = nullptr;
@@ -698,7 +718,7 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
     BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
     if (ctx->tune_voxel_order == 1) {  // PCL <= 1.9's intra-voxel order (parity mode): ranks from a host std::sort
       const int nv = voxel_order_stdsort(ctx, cloud, cap, &d_vorder);
-      if (nv < 0) { (void)hipFree(s->d_block); delete s; return nv; }
+      if (nv < 0) { cfear_pool_free(ctx, s->d_block, s->bytes); delete s; return nv; }
       if (d_vorder) { B.vrank = d_vorder; B.vperm = d_vorder + nv; }
     }
     const FeatureParams P = feature_params(ctx);
@@ -711,15 +731,16 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (d_vorder) (void)hipFree(d_vorder);
   if (e != hipSuccess) {
-    (void)hipFree(s->d_block);
+    cfear_pool_free(ctx, s->d_block, s->bytes);
     delete s;
     return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_create", e);
   }
   if (back.status != 0) {
-    (void)hipFree(s->d_block);
+    cfear_pool_free(ctx, s->d_block, s->bytes);
     delete s;
     return cfear_fail(ctx, CFEAR_ERR_EMPTY, "scan_create: empty cloud (reference: 'error, cloud empty' + exit)");
   }
+  s->n_cells = back.n_cells;
   *scan = s;
   return CFEAR_OK;
 }
@@ -737,7 +758,7 @@ int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_
   if (!s) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "scan alloc");
   s->cap_points = n; s->with_kd = ctx->tune_nn_tie == 2;
   const ScanLayout L = scan_layout(n, n, true, ctx->tune_nn_tie == 2);
-  if (hipMalloc(&s->d_block, L.total) != hipSuccess) { delete s; return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc scan"); }
+  { void* blk = nullptr; rc = cfear_pool_alloc(ctx, L.total, &blk, &s->bytes); if (rc != CFEAR_OK) { delete s; return rc; } s->d_block = static_cast<unsigned char*>(blk); }
   const ScanDev h = scan_header(s->d_block, n, n, true, ctx->tune_nn_tie == 2);
   hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(s->d_block + L.cells, cells, sizeof(cfear_cell) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
@@ -747,15 +768,15 @@ int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int n, cfear_
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h and the caller's cells are read until here
-  if (e != hipSuccess) { (void)hipFree(s->d_block); delete s; return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_from_cells", e); }
+  if (e != hipSuccess) { cfear_pool_free(ctx, s->d_block, s->bytes); delete s; return cfear_fail(ctx, CFEAR_ERR_HIP, "scan_from_cells", e); }
+  s->n_cells = n;
   *scan = s;
   return CFEAR_OK;
 }
 
 void cfear_scan_release(cfear_ctx* ctx, cfear_scan* s) {
   if (!s) return;
-  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
-  if (s->d_block) (void)hipFree(s->d_block);
+  cfear_pool_free(ctx, s->d_block, s->bytes);  // back to the context's pool (stream-ordered reuse, no synchronisation)
   delete s;
 }
 
@@ -768,6 +789,7 @@ static int scan_header_download(cfear_ctx* ctx, const cfear_scan* s, ScanDev* h)
 
 int cfear_scan_size(cfear_ctx* ctx, const cfear_scan* s, int* n_cells) {
   if (!ctx || !s || !n_cells) return cfear_fail(ctx, CFEAR_ERR_INVALID, "scan_size: bad argument");
+  if (s->n_cells >= 0) { *n_cells = s->n_cells; return CFEAR_OK; }  // cfear_scan_create read the header back already
   ScanDev h;
   int rc = scan_header_download(ctx, s, &h);
   if (rc != CFEAR_OK) return rc;
@@ -831,25 +853,37 @@ static int register_impl(cfear_ctx* ctx, cfear_scan* const* scans, int n, double
   double* d_cov = d_poses + 3 * MAX_SCANS;
   ScanDev** d_ptrs = reinterpret_cast<ScanDev**>(d_cov + 36);
   cfear_reg_summary* d_sum = reinterpret_cast<cfear_reg_summary*>(reinterpret_cast<unsigned char*>(d_ptrs) + sizeof(void*) * MAX_SCANS);
-  ScanDev* h_ptrs[MAX_SCANS];
+  // arguments and results travel through pinned staging: one copy each way and one synchronisation per registration (round 6; it was
+  // three small pageable copies in, three out). Device layout of the tail: poses | cov | scan pointers | summary | prior.
+  const size_t in_bytes = sizeof(double) * (3 * MAX_SCANS + 36) + sizeof(void*) * MAX_SCANS;
+  const size_t sum_bytes = ((sizeof(cfear_reg_summary) + 15) / 16) * 16;
+  rc = cfear_ensure_hstage(ctx, in_bytes + sum_bytes + sizeof(double) * 36);
+  if (rc != CFEAR_OK) return rc;
+  double* h_poses = reinterpret_cast<double*>(ctx->h_stage);
+  double* h_cov = h_poses + 3 * MAX_SCANS;
+  ScanDev** h_ptrs = reinterpret_cast<ScanDev**>(h_cov + 36);
+  memset(ctx->h_stage, 0, in_bytes);
   for (int i = 0; i < n; i++) h_ptrs[i] = reinterpret_cast<ScanDev*>(scans[i]->d_block);
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_ptrs, h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, poses_xyt, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(h_poses, poses_xyt, sizeof(double) * 3 * n);
   // a registration that fails does not touch the caller's covariance (reg_cov of n_scan_normal_reg::Register, n_scan_normal.cpp:82-187):
   // the device copy starts as the caller's matrix, so that what comes back is the caller's matrix (not the previous call's result)
-  if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_cov, cov6_last, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
+  if (cov6_last) memcpy(h_cov, cov6_last, sizeof(double) * 36);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_poses, ctx->h_stage, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   const RegParams P = reg_params(ctx);
   double* d_prior = nullptr;
   if (prior_cov6) {  // staged behind the summary, in the tail of the context scratch
-    d_prior = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(d_sum) + ((sizeof(cfear_reg_summary) + 15) / 16) * 16);
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_prior, prior_cov6, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
+    d_prior = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(d_sum) + sum_bytes);
+    double* h_prior = reinterpret_cast<double*>(ctx->h_stage + in_bytes + sum_bytes);
+    memcpy(h_prior, prior_cov6, sizeof(double) * 36);
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_prior, h_prior, sizeof(double) * 36, hipMemcpyHostToDevice, ctx->stream));
   }
   hipLaunchKernelGGL(register_kernel, dim3(1), dim3(BLOCK_R), 0, ctx->stream, d_ptrs, n, d_poses, d_cov, P, B, d_sum, d_prior);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(poses_xyt, d_poses, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream));
-  if (cov6_last) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(cov6_last, d_cov, sizeof(double) * 36, hipMemcpyDeviceToHost, ctx->stream));
-  if (summary) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(summary, d_sum, sizeof(cfear_reg_summary), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_stage, d_poses, in_bytes + sizeof(cfear_reg_summary), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(poses_xyt, h_poses, sizeof(double) * 3 * n);
+  if (cov6_last) memcpy(cov6_last, h_cov, sizeof(double) * 36);
+  if (summary) memcpy(summary, ctx->h_stage + in_bytes, sizeof(cfear_reg_summary));
   return CFEAR_OK;
 }
 

@@ -71,13 +71,17 @@ int cfear_rotate_polar(cfear_ctx* ctx, const uint8_t* h_in, int in_rows, int in_
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)in_rows * in_cols;
   uint8_t* d = nullptr;
-  if (hipMalloc(&d, 2 * bytes) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc rotate buffers");
-  hipError_t e = hipMemcpyAsync(d, h_in, bytes, hipMemcpyHostToDevice, ctx->stream);
-  int rc = CFEAR_OK;
-  if (e == hipSuccess) rc = cfear_rotate_polar_device(ctx, d, 1, in_rows, in_cols, d + bytes);
-  if (e == hipSuccess && rc == CFEAR_OK) e = hipMemcpyAsync(h_out, d + bytes, bytes, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d);
+  size_t got = 0;
+  { void* blk = nullptr; const int arc = cfear_pool_alloc(ctx, 2 * bytes, &blk, &got); if (arc != CFEAR_OK) return arc; d = static_cast<uint8_t*>(blk); }
+  // in through the pinned image staging (pageable sources: cabi.hip cfear_upload_image), out through the same staging: one DMA each way
+  int rc = cfear_upload_image(ctx, d, h_in, bytes);
+  if (rc == CFEAR_OK) rc = cfear_rotate_polar_device(ctx, d, 1, in_rows, in_cols, d + bytes);
+  hipError_t e = hipSuccess;
+  const bool staged = rc == CFEAR_OK && ctx->h_img && ctx->h_img_bytes >= bytes && ctx->ev_img_pending;
+  if (rc == CFEAR_OK) e = hipMemcpyAsync(staged ? static_cast<void*>(ctx->h_img) : static_cast<void*>(h_out), d + bytes, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  if (rc == CFEAR_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (rc == CFEAR_OK && e == hipSuccess && staged) { memcpy(h_out, ctx->h_img, bytes); ctx->ev_img_pending = false; }
+  cfear_pool_free(ctx, d, got);
   if (rc != CFEAR_OK) return rc;
   if (e != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_HIP, "rotate_polar", e);
   return CFEAR_OK;

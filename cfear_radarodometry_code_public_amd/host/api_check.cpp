@@ -2,6 +2,7 @@
 // filter types, MapPointNormal and its accessors, n_scan_normal_reg::Register with and without soft constraints, GetCost,
 // GetCovarianceScaler) on three sweeps read from a raw uint8 file and prints the numbers as one JSON object;
 // tests/test_host_cpp.py compares them with the oracle.   usage: api_check <sweeps.u8> [A R range_res]
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -70,6 +71,51 @@ int main(int argc, char** argv) {
     const std::string report = reg.summary_.FullReport();
     MapPointNormal::PublishMap("/current_normals", m, T1[2], "sensor_est", -1, 0.5);
     if (report.find("outer iterations") == std::string::npos) throw std::runtime_error("FullReport is empty");
+    // Device twins (cfear_host.hpp): a cloud the driver made is compensated / turned into a map on the device without an upload - unless
+    // the caller changed it in between, which must be noticed. Every case is compared with the same operation on a copy of the cloud at
+    // another address (no twin: the upload route); the results have to be identical bit for bit.
+    auto maxdiff = [](const PointCloudXYZI& a, const PointCloudXYZI& b) {
+      if (a.points.size() != b.points.size()) return 1e30;
+      double m = 0;
+      for (size_t i = 0; i < a.points.size(); i++) {
+        m = std::fmax(m, std::fabs((double)a.points[i].x - b.points[i].x)); m = std::fmax(m, std::fabs((double)a.points[i].y - b.points[i].y));
+        m = std::fmax(m, std::fabs((double)a.points[i].intensity - b.points[i].intensity));
+      }
+      return m;
+    };
+    PolarImage pi2; pi2.rows = A; pi2.cols = R; pi2.data = imgs[2].data(); pi2.stamp = 2;
+    const Affine3d Tm = cfear_from_xyt(0.8, -0.1, 0.03), Tm2 = cfear_from_xyt(-0.3, 0.2, -0.01);
+    CloudPtr ca, pa; driver.CallbackOffline(pi2, ca, pa);
+    CloudPtr cb(new PointCloudXYZI(*ca)), pb(new PointCloudXYZI(*pa));
+    Compensate(*ca, Tm, false); Compensate(*pa, Tm, false);  // twin route, the sibling compensated ahead
+    Compensate(*cb, Tm, false); Compensate(*pb, Tm, false);  // upload route
+    const double tw_same = std::fmax(maxdiff(*ca, *cb), maxdiff(*pa, *pb));
+    CloudPtr cm, pm; driver.CallbackOffline(pi2, cm, pm);
+    cm->points[5].x += 1.0f; cm->points.pop_back();          // the caller edits the cloud between CallbackOffline and Compensate
+    CloudPtr cmref(new PointCloudXYZI(*cm));
+    Compensate(*cm, Tm, false); Compensate(*cmref, Tm, false);
+    const double tw_mutated = maxdiff(*cm, *cmref);
+    const bool tw_mutated_differs = cm->points.size() + 1 == ca->points.size() && std::fabs(cm->points[5].x - ca->points[5].x) > 0.5;
+    CloudPtr c3, p3; driver.CallbackOffline(pi2, c3, p3);
+    Compensate(*c3, Tm, false);                               // compensates p3's twin ahead ...
+    p3->points[0].y -= 2.0f;                                  // ... but the caller changes p3 before its own call
+    CloudPtr p3ref(new PointCloudXYZI(*p3));
+    Compensate(*p3, Tm, false); Compensate(*p3ref, Tm, false);
+    const double tw_sibling_mutated = maxdiff(*p3, *p3ref);
+    CloudPtr c4, p4; driver.CallbackOffline(pi2, c4, p4);
+    CloudPtr p4ref(new PointCloudXYZI(*p4));
+    Compensate(*c4, Tm, false); Compensate(*p4, Tm2, true);   // the sibling gets another motion than the one run ahead
+    Compensate(*p4ref, Tm2, true);
+    const double tw_sibling_other_motion = maxdiff(*p4, *p4ref);
+    CloudPtr c5, p5; driver.CallbackOffline(pi2, c5, p5);
+    for (size_t i = 0; i < c5->points.size(); i += 2) c5->points[i].x += 0.75f;  // a map of an edited cloud = the map of its copy
+    CloudPtr c5ref(new PointCloudXYZI(*c5));
+    MapPointNormal m5(c5, 3.0f, Vector2d(0, 0), true, false), m5ref(c5ref, 3.0f, Vector2d(0, 0), true, false);
+    MapPointNormal m2twin(ca, 3.0f, Vector2d(0, 0), true, false), m2up(cb, 3.0f, Vector2d(0, 0), true, false);  // compensated: twin vs upload
+    double tw_map = std::fabs((double)m5.GetSize() - (double)m5ref.GetSize()) + std::fabs((double)m2twin.GetSize() - (double)m2up.GetSize());
+    for (size_t i = 0; i < m5.GetSize() && i < m5ref.GetSize(); i++) tw_map = std::fmax(tw_map, std::fabs(m5.GetCell(i).u_(0) - m5ref.GetCell(i).u_(0)));
+    for (size_t i = 0; i < m2twin.GetSize() && i < m2up.GetSize(); i++) tw_map = std::fmax(tw_map, std::fabs(m2twin.GetCell(i).u_(1) - m2up.GetCell(i).u_(1)));
+    const bool tw_map_differs = m5.GetSize() != scans[2]->GetSize() || std::fabs(m5.GetCell(0).u_(0) - scans[2]->GetCell(0).u_(0)) > 1e-6;
     std::printf("{\"points\": [%zu, %zu, %zu], \"cfar_points\": %zu, \"cfar_peaks\": %zu, \"cells\": [%zu, %zu, %zu], "
                 "\"cell0\": [%.12g, %.12g, %.12g, %.12g], \"closest_self\": %d, \"rel_time0\": %.12g, "
                 "\"tcell0\": [%.12g, %.12g, %.12g, %.12g, %.12g], "
@@ -77,7 +123,9 @@ int main(int argc, char** argv) {
                 "\"get_cost\": {\"ok\": %d, \"score\": %.12g, \"n\": %zu, \"r0\": %.12g, \"getScore\": %.12g}, "
                 "\"register_soft\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"residuals\": %d}, "
                 "\"other\": {\"ok\": %d, \"pose\": [%.12g, %.12g, %.12g], \"residuals\": %d}, \"coarse_cells\": %zu, "
-                "\"raw\": {\"cells\": %zu, \"points\": %zu, \"nn5\": %d, \"scale\": %.12g, \"cov00\": %.12g}, \"moved\": {\"cells\": %zu, \"nn0\": %d}}\n",
+                "\"raw\": {\"cells\": %zu, \"points\": %zu, \"nn5\": %d, \"scale\": %.12g, \"cov00\": %.12g}, \"moved\": {\"cells\": %zu, \"nn0\": %d}, "
+                "\"twins\": {\"same\": %.9g, \"mutated\": %.9g, \"mutated_differs\": %d, \"sibling_mutated\": %.9g, \"sibling_other_motion\": %.9g, \"map\": %.9g, \"map_differs\": %d, "
+                "\"comp0\": [%.9g, %.9g]}}\n",
                 npts[0], npts[1], npts[2], ccloud->size(), cpeaks->size(), scans[0]->GetSize(), scans[1]->GetSize(), scans[2]->GetSize(),
                 c0.u_(0), c0.u_(1), c0.snormal_(0), c0.snormal_(1), nn.empty() ? -1 : nn[0], m->GetCellRelTimeStamp(0, false),
                 tc[0].u_(0), tc[0].u_(1), tc[0].snormal_(0), tc[0].cov_(0, 0), tc[0].cov_(0, 1),
@@ -85,7 +133,9 @@ int main(int argc, char** argv) {
                 cost_ok ? 1 : 0, score, residuals.size(), residuals.empty() ? 0.0 : residuals[0], score_after_get_cost,
                 ok_soft ? 1 : 0, cfear_tx(T2[2]), cfear_ty(T2[2]), cfear_yaw(T2[2]), reg.summary_.num_residuals,
                 ok_other ? 1 : 0, cfear_tx(To[2]), cfear_ty(To[2]), cfear_yaw(To[2]), other.summary_.num_residuals, coarse->GetSize(),
-                raw->GetSize(), npts[2], raw_nn.empty() ? -1 : raw_nn[0], raw_cells[5].scale_, raw_cells[5].cov_(0, 0), moved->GetSize(), moved_nn.empty() ? -1 : moved_nn[0]);
+                raw->GetSize(), npts[2], raw_nn.empty() ? -1 : raw_nn[0], raw_cells[5].scale_, raw_cells[5].cov_(0, 0), moved->GetSize(), moved_nn.empty() ? -1 : moved_nn[0],
+                tw_same, tw_mutated, tw_mutated_differs ? 1 : 0, tw_sibling_mutated, tw_sibling_other_motion, tw_map, tw_map_differs ? 1 : 0,
+                (double)ca->points[0].x, (double)ca->points[0].y);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 3;

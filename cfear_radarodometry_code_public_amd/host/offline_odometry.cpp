@@ -31,6 +31,10 @@ int main(int argc, char** argv) {
            "       [--radar_ccw 0] [--disable_compensate 0] [--cost_type P2L] [--loss_type Huber] [--loss_limit 0.1]\n"
            "       [--covar_scale 1] [--regularization 1] [--weight_option 0] [--registered_min_keyframe_dist 1.5]\n"
            "       [--est_directory .] [--device 0] [--filter-type kstrong|CA-CFAR] [--nn-tie 0|1|2] [--voxel-order 0|1]\n"
+           "       [--dataset oxford|mulran|...]   anything but oxford: the sweeps in the file are range-major (rows = range bins, bins x azimuths,\n"
+           "                      radar_driver.cpp:74-90) and go through the driver's cv::rotate first; --radar_ccw usually goes with it\n"
+           "       [--soft_constraint 0] [--covar_sampling 0] [--covar_XY_sample_range 0.4] [--covar_yaw_sample_range 0.0043625]\n"
+           "       [--covar_samples_per_axis 3] [--covar_sampling_scale 4]   (offline_odometry.cpp:166-178; --cov_file <path> writes the 36 values per sweep)\n"
            "       [--replay 1]   whole recording through cfear_odometry_replay_host (pieces of 256 sweeps in pinned memory, no\n"
            "                      host round trip per sweep) instead of one CallbackOffline + pointcloudCallback per sweep\n");
     return argc < 2;
@@ -44,6 +48,7 @@ int main(int argc, char** argv) {
   rad_par.k_strongest = atoi(arg(argc, argv, "--k_strongest", "12"));
   rad_par.z_min = (float)atof(arg(argc, argv, "--z-min", "65"));
   rad_par.azimuths = A;
+  rad_par.dataset = arg(argc, argv, "--dataset", "oxford");  // offline_odometry.cpp:186, :251
   rad_par.filter_type_ = Str2filter(arg(argc, argv, "--filter-type", "kstrong"));  // offline_odometry.cpp:269
   // the reference's option reuse for the CA-CFAR sweeps (offline_odometry.cpp:260-265): nb_guard_cells <- k_strongest,
   // false_alarm_rate <- regularization, window_size <- covar_scale
@@ -64,6 +69,13 @@ int main(int argc, char** argv) {
   par.weight_opt = static_cast<weightoption>(atoi(arg(argc, argv, "--weight_option", "0")));
   par.min_keyframe_dist_ = atof(arg(argc, argv, "--registered_min_keyframe_dist", "1.5"));
   par.use_guess = true;  // forced at offline_odometry.cpp:273
+  par.soft_constraint = atoi(arg(argc, argv, "--soft_constraint", "0")) != 0;                  // :166, :274
+  par.estimate_cov_by_sampling = atoi(arg(argc, argv, "--covar_sampling", "0")) != 0;          // :173, :216-217
+  par.cov_sampling_xy_range = atof(arg(argc, argv, "--covar_XY_sample_range", "0.4"));         // :176
+  par.cov_sampling_yaw_range = atof(arg(argc, argv, "--covar_yaw_sample_range", "0.0043625")); // :177
+  par.cov_sampling_samples_per_axis = (unsigned)atoi(arg(argc, argv, "--covar_samples_per_axis", "3"));  // :178
+  par.cov_sampling_covariance_scaler = atof(arg(argc, argv, "--covar_sampling_scale", "4"));   // :179
+  const std::string cov_file = arg(argc, argv, "--cov_file", "");
   const std::string est_dir = arg(argc, argv, "--est_directory", ".");
 
   std::ifstream in(frames, std::ios::binary);
@@ -72,11 +84,14 @@ int main(int argc, char** argv) {
   p.submap_scan_size = par.submap_scan_size;
   try {
     DevicePtr dev(new Device(p, A, R, atoi(arg(argc, argv, "--device", "0"))));
+    Device::SetDefault(dev);  // the reference-signature constructors and Compensate(cloud, ...) find this context
     // parity modes (include/cfear_hip.h cfear_tune): --nn-tie 2 = FLANN's kd-tree order among equidistant cells, --voxel-order 1 = PCL <= 1.9's
     // std::sort order inside a voxel - together what an Ubuntu 18.04 build of the reference does where its sources leave the choice to a library
     dev->check(cfear_tune(dev->ctx(), CFEAR_TUNE_NN_TIE_RULE, atoi(arg(argc, argv, "--nn-tie", "0"))), "cfear_tune");
     if (!atoi(arg(argc, argv, "--replay", "0"))) dev->check(cfear_tune(dev->ctx(), CFEAR_TUNE_VOXEL_ORDER, atoi(arg(argc, argv, "--voxel-order", "0"))), "cfear_tune");
     if (atoi(arg(argc, argv, "--replay", "0"))) {
+      if (rad_par.dataset != "oxford" || par.soft_constraint || par.estimate_cov_by_sampling)
+        throw std::runtime_error("--replay 1 runs the Oxford route without soft constraints / sampled covariances; use the per-sweep route for those");
       // maximum-rate replay: the same parameters the two classes would apply, set once; the loop of offline_odometry.cpp:103-125
       // runs on the device sweep after sweep, the poses of a piece come back together
       cfear_params q = p;
@@ -131,18 +146,25 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> img((size_t)A * R);
     std::ofstream est(est_dir + "/est_00.txt");
     est << std::fixed; est.precision(6);
+    std::ofstream covs;
+    if (!cov_file.empty()) { covs.open(cov_file); covs.precision(17); }
     int n = 0;
+    const bool range_major = rad_par.dataset != "oxford";
+    double tot = 0;  // the reference's `tot`: callback time only, the bag read is outside (offline_odometry.cpp:99, :119-125)
     const auto t_start = std::chrono::steady_clock::now();
     while (in.read(reinterpret_cast<char*>(img.data()), (std::streamsize)img.size())) {
       const auto t0 = std::chrono::steady_clock::now();
-      PolarImage pi; pi.rows = A; pi.cols = R; pi.data = img.data(); pi.stamp = (uint64_t)n;
+      // Oxford: rows = azimuth (radar_driver.cpp:92-98). The other datasets deliver rows = range bins, and the driver rotates (:84)
+      PolarImage pi; pi.rows = range_major ? R : A; pi.cols = range_major ? A : R; pi.data = img.data(); pi.stamp = (uint64_t)n;
       CloudPtr cloud, cloud_peaks;
       driver.CallbackOffline(pi, cloud, cloud_peaks);                     // offline_odometry.cpp:103
       const auto t1 = std::chrono::steady_clock::now();
       CFEAR_TIMING.Document("Filtering", std::chrono::duration<double, std::milli>(t1 - t0).count());  // radar_driver.cpp:111
       CFEAR_TIMING.Document("Filtered points", (double)cloud->size());    // :104
       Affine3d Tcurrent = cfear_from_xyt(0, 0, 0);
-      fuser.pointcloudCallback(cloud, cloud_peaks, Tcurrent, pi.stamp);   // :108
+      Matrix6d cov_current = cfear_mat6_identity();
+      fuser.pointcloudCallback(cloud, cloud_peaks, Tcurrent, pi.stamp, cov_current);   // :108
+      if (covs.is_open()) { for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) covs << cov_current(a, b) << (a == 5 && b == 5 ? "\n" : " "); }
       const auto t2 = std::chrono::steady_clock::now();
       CFEAR_TIMING.Document("Registration", std::chrono::duration<double, std::milli>(t2 - t1).count());  // odometrykeyframefuser.cpp:404
       double Rm[2][2]; cfear_linear2(Tcurrent, Rm);
@@ -150,10 +172,11 @@ int main(int argc, char** argv) {
           << Rm[1][0] << " " << Rm[1][1] << " 0.000000 " << cfear_ty(Tcurrent) << " "
           << "0.000000 0.000000 1.000000 0.000000\n";
       n++;
-      const double tot = std::chrono::duration<double>(t2 - t_start).count();
+      tot += std::chrono::duration<double>(t2 - t0).count();
       if (n % 10 == 0) std::cout << "Frame: " << n << ", dur: " << std::chrono::duration<double>(t2 - t0).count() << ", avg: " << n / tot << " Hz" << std::endl;  // :125
     }
-    std::cout << "frames " << n << "\n" << CFEAR_TIMING.GetStatistics();
+    std::cout << "frames " << n << ", with the file read: " << n / std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " Hz\n"
+              << CFEAR_TIMING.GetStatistics();
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << std::endl;
     return 3;

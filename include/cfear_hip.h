@@ -184,6 +184,12 @@ int cfear_filter_cfar_batch_device(cfear_ctx* ctx, const uint8_t* d_polar, int n
 int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cloud);
 int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* cloud, int* n);
 int cfear_cloud_download(cfear_ctx* ctx, const cfear_cloud* cloud, float* xyi, int capacity, int* n);
+/* m <= 16 clouds to the host with ONE synchronisation (counts and points travel together through pinned staging): what
+ * radarDriver::CallbackOffline hands its caller is two clouds (radar_driver.cpp:59-60, 163-176), and Compensate (utils.cpp:96-113)
+ * runs on both. xyi[i] receives min(n[i], capacity[i]) points; n[i] is the true count. xyi / capacity may be null (counts only). */
+int cfear_clouds_download(cfear_ctx* ctx, const cfear_cloud* const* clouds, int m, float* const* xyi, const int* capacity, int* n);
+/* Releasing a cloud or a scan parks its device block in the context for the next handle of a similar size (no hipFree, no
+ * synchronisation on the per-sweep path; cfear_destroy gives everything back). Handles must not outlive their context. */
 void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* cloud);
 /* Compensate(cloud, Tmotion, ccw) (utils.h:49, utils.cpp:96-113); motion = (tx, ty, theta). In place. */
 int cfear_compensate(cfear_ctx* ctx, cfear_cloud* cloud, const double motion_xyt[3], int ccw);

@@ -14,9 +14,11 @@
 // Error behaviour: where the reference prints and calls exit(0) this layer throws std::runtime_error
 // carrying cfear_last_error(); bool returns are kept.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -122,6 +124,76 @@ inline DeviceCloudPtr UploadCloud(const DevicePtr& dev, const PointCloudXYZI& c)
   return d;
 }
 
+// ---- device twins of host clouds (round 6) ------------------------------------------------------------
+// The reference's interfaces hand clouds over as host objects (radar_driver.h:90, utils.h:49, pointnormal.h:118), but on this
+// path they are made on the device (radarDriver), changed on the device (Compensate) and consumed on the device (MapPointNormal).
+// Every host cloud this layer fills is therefore remembered together with the device cloud it is a copy of: address, size and a
+// checksum of its (x, y, intensity) values. A later call that receives the same object with the same content works on the device
+// twin - no upload; one whose content was changed by the caller in between (or another object at a recycled address) does not
+// match and takes the upload route. The host copy is always brought up to date before a call returns (unmodified caller code reads
+// it: cloud->size() at offline_odometry.cpp:104, FormatScanMsg at odometrykeyframefuser.cpp:207).
+inline uint64_t XyiChecksum(const float* xyi, size_t n) {
+  // four independent multiply-xor lanes over 8-byte words (a single dependent chain over 10 k floats cost 10-16 us per cloud, seven times
+  // per sweep: more than the kernels it guards)
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(xyi);
+  const size_t bytes = 12 * n, words = bytes / 8;
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ (uint64_t)n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  size_t w = 0;
+  for (; w + 4 <= words; w += 4) {
+    uint64_t v[4]; std::memcpy(v, p + 8 * w, 32);
+    for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ v[k]) * 0x100000001B3ull; h[k] ^= h[k] >> 29; }
+  }
+  for (; w < words; w++) { uint64_t v; std::memcpy(&v, p + 8 * w, 8); h[w & 3] = (h[w & 3] ^ v) * 0x100000001B3ull; h[w & 3] ^= h[w & 3] >> 29; }
+  if (bytes & 7) { uint64_t v = 0; std::memcpy(&v, p + 8 * words, bytes & 7); h[0] = (h[0] ^ v) * 0x100000001B3ull; }
+  uint64_t r = h[0];
+  for (int k = 1; k < 4; k++) { r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull; r ^= r >> 33; }
+  return r;
+}
+struct CloudTwin {
+  const void* host = nullptr; size_t n = 0; uint64_t sum = 0;  // the host cloud object and what it held when the twin was last in step
+  DeviceCloudPtr dev;
+  const void* sibling = nullptr;  // the other cloud of the pair radarDriver::Process made (cloud <-> cloud_peaks)
+  // Compensate(cloud) also ran on this sibling with the same motion (the fuser compensates both, odometrykeyframefuser.cpp:148-149);
+  // the result waits here for the sibling's own call. Until then the device cloud is ahead of the host copy.
+  bool ahead = false; double ahead_mot[3] = {0, 0, 0}; bool ahead_ccw = false; std::vector<float> ahead_xyi; size_t ahead_n = 0;
+};
+class CloudTwins {
+ public:
+  static CloudTwins& instance() { thread_local CloudTwins t; return t; }
+  CloudTwin& put(const void* host, size_t n, uint64_t sum, const DeviceCloudPtr& dev, const void* sibling = nullptr) {
+    drop(host);
+    if (e_.size() >= 8) e_.erase(e_.begin());  // oldest first: a sweep touches two
+    CloudTwin t; t.host = host; t.n = n; t.sum = sum; t.dev = dev; t.sibling = sibling;
+    e_.push_back(std::move(t));
+    return e_.back();
+  }
+  CloudTwin* by_address(const void* host) { for (auto& t : e_) if (t.host == host) return &t; return nullptr; }
+  // the twin of a host cloud whose content is still what the twin was made from (scratch receives the cloud as xyi triples)
+  CloudTwin* find(const PointCloudXYZI& c, std::vector<float>& scratch) {
+    CloudTwin* t = by_address(&c);
+    if (!t) return nullptr;
+    cfear_cloud_to_xyi(c, scratch);
+    if (t->n != cfear_cloud_size(c) || t->sum != XyiChecksum(scratch.data(), t->n)) { drop(&c); return nullptr; }
+    return t;
+  }
+  void drop(const void* host) { for (size_t i = 0; i < e_.size(); i++) if (e_[i].host == host) { e_.erase(e_.begin() + (long)i); return; } }
+  void clear() { e_.clear(); }
+ private:
+  std::vector<CloudTwin> e_;
+};
+// several device clouds into host clouds with one synchronisation; returns each cloud's checksum
+inline void DownloadInto(const DevicePtr& dev, const std::vector<cfear_cloud*>& h, const std::vector<std::vector<float>*>& xyi, std::vector<int>& n) {
+  const size_t m = h.size();
+  std::vector<const cfear_cloud*> hc(h.begin(), h.end()); std::vector<float*> out(m); std::vector<int> cap(m);
+  n.assign(m, 0);
+  // sized by the previous answer for this slot, or a first guess: a cloud larger than the buffer is fetched again at its true size
+  for (size_t i = 0; i < m; i++) { if (xyi[i]->size() < 3 * 8192) xyi[i]->resize(3 * 8192); out[i] = xyi[i]->data(); cap[i] = (int)(xyi[i]->size() / 3); }
+  dev->check(cfear_clouds_download(dev->ctx(), hc.data(), (int)m, out.data(), cap.data(), n.data()), "cfear_clouds_download");
+  bool again = false;
+  for (size_t i = 0; i < m; i++) if (n[i] > cap[i]) { xyi[i]->resize(3 * (size_t)n[i]); out[i] = xyi[i]->data(); cap[i] = n[i]; again = true; }
+  if (again) dev->check(cfear_clouds_download(dev->ctx(), hc.data(), (int)m, out.data(), cap.data(), n.data()), "cfear_clouds_download");
+}
+
 // ---- radarDriver (radar_driver.h:32-120) ----------------------------------------------------------
 typedef enum filter_type { kstrong, CACFAR } filtertype;  // radar_driver.h:24
 inline filtertype Str2filter(const std::string& str) { return str == "CA-CFAR" ? filtertype::CACFAR : filtertype::kstrong; }  // radar_driver.cpp:6-12
@@ -144,7 +216,11 @@ class AzimuthCACFAR {
     ScopedParams sp(dev, p);
     DeviceCloudPtr d(new DeviceCloud()); d->dev = dev;
     dev->check(cfear_filter_cfar(dev->ctx(), cfear_cv_data(img), window_size_, nb_guard_cells_, (float)false_alarm_rate_, max_distance_, &d->h), "cfear_filter_cfar");
-    output_pointcloud = DownloadCloud(dev, d->h);
+    std::vector<float> xyi; std::vector<int> n;
+    DownloadInto(dev, {d->h}, {&xyi}, n);
+    output_pointcloud = cfear_make_cloud();
+    cfear_cloud_from_xyi(*output_pointcloud, xyi.data(), (size_t)n[0]);
+    CloudTwins::instance().put(output_pointcloud.get(), (size_t)n[0], XyiChecksum(xyi.data(), (size_t)n[0]), d);
     return d;
   }
  private:
@@ -167,7 +243,20 @@ class radarDriver {
   // range-major and go through cv::rotate first (CallbackOffline dispatches on par.dataset like the reference, :165-170).
   void CallbackOffline(const ImageConstPtr& radar_image_polar, CloudPtr& cloud, CloudPtr& cloud_peaks) {
     if (cfear_image_null(radar_image_polar)) throw std::runtime_error("Radar image NULL");  // radar_driver.cpp:75-78
+    int rows = 0, cols = 0;
+    const uint8_t* raw = (par.dataset == "oxford" && par.filter_type_ == filtertype::kstrong) ? cfear_image_raw(radar_image_polar, &rows, &cols) : nullptr;
+    if (raw) {
+      // the message's own bytes go to the device first; cv_bridge's copy (radar_driver.cpp:104) is made while the filter runs
+      LaunchKstrong(raw, rows, cols);
+      const auto t0 = std::chrono::steady_clock::now();
+      cv_polar_image = cfear_image_to_cv(radar_image_polar);
+      CFEAR_TIMING.Document("driver: toCvCopy", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      FinishKstrong(cloud, cloud_peaks);
+      return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     cv_polar_image = cfear_image_to_cv(radar_image_polar);
+    CFEAR_TIMING.Document("driver: toCvCopy", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (par.dataset != "oxford") Rotate();
     Process(cloud, cloud_peaks);
   }
@@ -179,7 +268,8 @@ class radarDriver {
     Rotate();
     Process(cloud, cloud_peaks);
   }
-  DeviceCloudPtr device_cloud() const { return last_cloud_; }  // avoids a round trip when the fuser runs on the same device
+  // the device twin of the last `cloud` (it follows the host cloud: a Compensate of that cloud works on this object)
+  DeviceCloudPtr device_cloud() const { return last_cloud_; }
   CvImagePtr cv_polar_image;  // latest radar image (radar_driver.h:92)
  private:
   DevicePtr device(int A, int R) {
@@ -202,16 +292,38 @@ class radarDriver {
       last_peaks_.reset(new DeviceCloud()); last_peaks_->dev = dev;
       cloud_peaks = cfear_make_cloud();
     } else {
-      cfear_params p = dev->params(); p.z_min = par.z_min; p.range_res = par.range_res; p.min_distance = par.min_distance; p.k_strongest = par.k_strongest;
-      ScopedParams sp(dev, p);
-      last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
-      last_cloud_->dev = dev; last_peaks_->dev = dev;
-      dev->check(cfear_filter_polar(dev->ctx(), cfear_cv_data(cv_polar_image), &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
-      cloud = DownloadCloud(dev, last_cloud_->h); cloud_peaks = DownloadCloud(dev, last_peaks_->h);
+      LaunchKstrong(cfear_cv_data(cv_polar_image), cfear_cv_rows(cv_polar_image), cfear_cv_cols(cv_polar_image));
+      FinishKstrong(cloud, cloud_peaks);
+      return;
     }
     cfear_cloud_stamp_from_cv(*cloud, cv_polar_image); cfear_cloud_stamp_from_cv(*cloud_peaks, cv_polar_image);  // :66-67
   }
-  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_;
+  // k-strongest + the two clouds (radar_driver.cpp:58-60): upload and launches ...
+  void LaunchKstrong(const uint8_t* data, int rows, int cols) {
+    const DevicePtr dev = device(rows, cols);
+    cfear_params p = dev->params(); p.z_min = par.z_min; p.range_res = par.range_res; p.min_distance = par.min_distance; p.k_strongest = par.k_strongest;
+    ScopedParams sp(dev, p);
+    last_cloud_.reset(new DeviceCloud()); last_peaks_.reset(new DeviceCloud());
+    last_cloud_->dev = dev; last_peaks_->dev = dev;
+    const auto t0 = std::chrono::steady_clock::now();
+    dev->check(cfear_filter_polar(dev->ctx(), data, &last_cloud_->h, &last_peaks_->h), "cfear_filter_polar");
+    CFEAR_TIMING.Document("driver: image upload + launches", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  // ... and both clouds back with one synchronisation, remembered as the host copies of their device twins
+  void FinishKstrong(CloudPtr& cloud, CloudPtr& cloud_peaks) {
+    const DevicePtr dev = last_cloud_->dev;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<int> n;
+    DownloadInto(dev, {last_cloud_->h, last_peaks_->h}, {&xyi_[0], &xyi_[1]}, n);
+    cloud = cfear_make_cloud(); cloud_peaks = cfear_make_cloud();
+    cfear_cloud_from_xyi(*cloud, xyi_[0].data(), (size_t)n[0]); cfear_cloud_from_xyi(*cloud_peaks, xyi_[1].data(), (size_t)n[1]);
+    CloudTwins& tw = CloudTwins::instance();
+    tw.put(cloud.get(), (size_t)n[0], XyiChecksum(xyi_[0].data(), (size_t)n[0]), last_cloud_, cloud_peaks.get());
+    tw.put(cloud_peaks.get(), (size_t)n[1], XyiChecksum(xyi_[1].data(), (size_t)n[1]), last_peaks_, cloud.get());
+    CFEAR_TIMING.Document("driver: wait + two clouds to the host", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    cfear_cloud_stamp_from_cv(*cloud, cv_polar_image); cfear_cloud_stamp_from_cv(*cloud_peaks, cv_polar_image);  // :66-67
+  }
+  DevicePtr dev_; Parameters par; DeviceCloudPtr last_cloud_, last_peaks_; std::vector<float> xyi_[2];
 };
 
 // ---- Compensate (utils.h:47-49, utils.cpp:96-113) -----------------------------------------------------
@@ -219,16 +331,49 @@ inline void Compensate(const DevicePtr& dev, DeviceCloud& cloud, const Affine3d&
   const double mot[3] = {cfear_tx(Tmotion), cfear_ty(Tmotion), cfear_yaw(Tmotion)};
   dev->check(cfear_compensate(dev->ctx(), cloud.h, mot, ccw ? 1 : 0), "cfear_compensate");
 }
-// void Compensate(pcl::PointCloud<pcl::PointXYZI>& cloud, const Eigen::Affine3d& Tmotion, bool ccw) (utils.h:49): in place
-inline void Compensate(PointCloudXYZI& cloud, const Affine3d& Tmotion, bool ccw) {
+// void Compensate(pcl::PointCloud<pcl::PointXYZI>& cloud, const Eigen::Affine3d& Tmotion, bool ccw) (utils.h:49): in place.
+// A cloud this layer made (radarDriver, an earlier Compensate) and nobody changed since is compensated on its device twin; when it
+// has a sibling from the same sweep (cloud <-> cloud_peaks) the sibling is compensated by the same motion in the same launch
+// sequence and its result parked, so that the fuser's two calls (odometrykeyframefuser.cpp:148-149) cost one synchronisation.
+// Anything else is uploaded first. `fallback` = the device for clouds without a twin (null: the process-wide default).
+inline void CompensateOn(const DevicePtr& fallback, PointCloudXYZI& cloud, const Affine3d& Tmotion, bool ccw) {
   if (cfear_cloud_size(cloud) == 0) return;
-  const DevicePtr dev = Device::Default();
-  DeviceCloudPtr d = UploadCloud(dev, cloud);
-  Compensate(dev, *d, Tmotion, ccw);
-  CloudPtr back = DownloadCloud(dev, d->h);
-  std::vector<float> xyi; cfear_cloud_to_xyi(*back, xyi);
-  cfear_cloud_from_xyi(cloud, xyi.data(), cfear_cloud_size(*back));
+  CloudTwins& tw = CloudTwins::instance();
+  static thread_local std::vector<float> xyi, sib_xyi;
+  const double mot[3] = {cfear_tx(Tmotion), cfear_ty(Tmotion), cfear_yaw(Tmotion)};
+  CloudTwin* t = tw.find(cloud, xyi);
+  if (t && t->ahead) {  // the sibling's call compensated this cloud already
+    if (t->ahead_mot[0] == mot[0] && t->ahead_mot[1] == mot[1] && t->ahead_mot[2] == mot[2] && t->ahead_ccw == ccw) {
+      cfear_cloud_from_xyi(cloud, t->ahead_xyi.data(), t->ahead_n);
+      t->n = t->ahead_n; t->sum = XyiChecksum(t->ahead_xyi.data(), t->ahead_n); t->ahead = false;
+      return;
+    }
+    tw.drop(&cloud); t = nullptr;  // another motion: the device twin is of no use any more
+  }
+  if (!t) {  // (xyi holds the cloud when find() looked at it; a cloud without any entry is converted here)
+    const DevicePtr dev = fallback ? fallback : Device::Default();
+    cfear_cloud_to_xyi(cloud, xyi);
+    DeviceCloudPtr d(new DeviceCloud()); d->dev = dev;
+    dev->check(cfear_cloud_upload(dev->ctx(), xyi.data(), (int)cfear_cloud_size(cloud), &d->h), "cfear_cloud_upload");
+    t = &tw.put(&cloud, cfear_cloud_size(cloud), 0, d);
+  }
+  const DevicePtr dev = t->dev->dev;
+  Compensate(dev, *t->dev, Tmotion, ccw);
+  CloudTwin* sib = t->sibling ? tw.by_address(t->sibling) : nullptr;
+  if (sib && (sib->ahead || sib->dev->dev != dev || sib->n == 0)) sib = nullptr;
+  std::vector<int> n;
+  if (sib) {
+    Compensate(dev, *sib->dev, Tmotion, ccw);
+    DownloadInto(dev, {t->dev->h, sib->dev->h}, {&xyi, &sib->ahead_xyi}, n);
+    sib->ahead = true; sib->ahead_n = (size_t)n[1]; sib->ahead_ccw = ccw;
+    for (int i = 0; i < 3; i++) sib->ahead_mot[i] = mot[i];
+  } else {
+    DownloadInto(dev, {t->dev->h}, {&xyi}, n);
+  }
+  cfear_cloud_from_xyi(cloud, xyi.data(), (size_t)n[0]);
+  t->n = (size_t)n[0]; t->sum = XyiChecksum(xyi.data(), t->n);
 }
+inline void Compensate(PointCloudXYZI& cloud, const Affine3d& Tmotion, bool ccw) { CompensateOn(DevicePtr(), cloud, Tmotion, ccw); }
 inline void Compensate(PointCloudXYZI& cloud, const std::vector<double>& mot, bool ccw) { Compensate(cloud, vectorToAffine3d(mot), ccw); }  // utils.h:47
 
 // ---- cell / MapPointNormal (pointnormal.h:45-243) -----------------------------------------------------
@@ -271,13 +416,12 @@ typedef CFEAR_SHARED_PTR<MapPointNormal> MapNormalPtr;
 class MapPointNormal {
  public:
   // MapPointNormal(cld, radius, origin = (0,0), weight_intensity = false, raw = false) (pointnormal.h:118, pointnormal.cpp:65-90)
+  // A cloud that still equals its device twin (radarDriver / Compensate made it, nobody changed it) is not uploaded again.
   MapPointNormal(const CloudPtr& cld, float radius, const Vector2d& origin = Vector2d(0, 0), const bool weight_intensity = false, const bool raw = false)
-      : dev_(Device::Default()), input_(cld) {
-    if (!cld || cfear_cloud_size(*cld) == 0) throw std::runtime_error("error, cloud empty");  // pointnormal.cpp:72-75 (exit(0) there)
-    if (raw) { BuildRaw(*cld); return; }
-    DeviceCloudPtr d = UploadCloud(dev_, *cld);
-    Build(*d, radius, origin, weight_intensity);
-  }
+      : input_(cld) { Init(DevicePtr(), radius, origin, weight_intensity, raw); }
+  // ... with the device to use when the cloud has no twin (the reference-signature constructor takes the process-wide default)
+  MapPointNormal(const DevicePtr& dev, const CloudPtr& cld, float radius, const Vector2d& origin = Vector2d(0, 0), const bool weight_intensity = false, const bool raw = false)
+      : input_(cld) { Init(dev, radius, origin, weight_intensity, raw); }
   // MapPointNormal(cld, radius, cell_orig, T) (pointnormal.h:120, pointnormal.cpp:91-110): transformed copy of existing cells
   MapPointNormal(const CloudPtr& cld, float radius, std::vector<cell>& cell_orig, const Affine3d& T) : dev_(Device::Default()), input_(cld) {
     (void)radius;
@@ -353,6 +497,18 @@ class MapPointNormal {
   BOOST_SERIALIZATION_SPLIT_MEMBER()
 #endif
  private:
+  void Init(const DevicePtr& fallback, float radius, const Vector2d& origin, bool weight_intensity, bool raw) {
+    const CloudPtr& cld = input_;
+    if (!cld || cfear_cloud_size(*cld) == 0) throw std::runtime_error("error, cloud empty");  // pointnormal.cpp:72-75 (exit(0) there)
+    static thread_local std::vector<float> xyi;
+    CloudTwin* t = raw ? nullptr : CloudTwins::instance().find(*cld, xyi);
+    if (t && t->ahead) t = nullptr;  // (its device cloud was compensated ahead of the host copy: not this content)
+    dev_ = t ? t->dev->dev : (fallback ? fallback : Device::Default());
+    if (raw) { BuildRaw(*cld); return; }
+    if (t) { Build(*t->dev, radius, origin, weight_intensity); return; }
+    DeviceCloudPtr d = UploadCloud(dev_, *cld);
+    Build(*d, radius, origin, weight_intensity);
+  }
   void Build(const DeviceCloud& cld, float radius, const Vector2d& origin, bool weight_intensity) {
     radius_ = radius; weight_intensity_ = weight_intensity;
     if (origin(0) != 0 || origin(1) != 0) throw std::runtime_error("MapPointNormal: origin must be (0,0) as in odometrykeyframefuser.cpp:161");
@@ -551,14 +707,21 @@ class OdometryKeyframeFuser {
     return !(std::sqrt(ax * ax + ay * ay) > acc_limit) && !(vel > vel_limit);
   }
   void processFrame(CloudPtr& cloud, CloudPtr& cloud_peaks, uint64_t) {  // :143-259
+    // The same calls on the same host objects as the reference makes (Compensate(*cloud, ...) twice, then MapPointNormal(cloud, ...)):
+    // clouds that came from radarDriver::CallbackOffline on this thread are found as device twins and never uploaded; dev_ is
+    // only the device for clouds from elsewhere.
     const Affine3d TprevMot(Tmot);
-    DeviceCloudPtr dcloud = UploadCloud(dev_, *cloud), dpeaks = UploadCloud(dev_, *cloud_peaks);
+    const auto t0 = std::chrono::steady_clock::now();
     if (par.compensate) {  // :147-150
-      Compensate(dev_, *dcloud, TprevMot, par.radar_ccw); Compensate(dev_, *dpeaks, TprevMot, par.radar_ccw);
-      cloud = DownloadCloud(dev_, dcloud->h); cloud_peaks = DownloadCloud(dev_, dpeaks->h);
+      CompensateOn(dev_, *cloud, TprevMot, par.radar_ccw);
+      CompensateOn(dev_, *cloud_peaks, TprevMot, par.radar_ccw);
     }
-    MapNormalPtr Pcurrent(new MapPointNormal(dev_, *dcloud, (float)par.res, Vector2d(0, 0), par.weight_intensity_, par.use_raw_pointcloud));  // :161
+    const auto t1 = std::chrono::steady_clock::now();
+    MapNormalPtr Pcurrent(new MapPointNormal(dev_, cloud, (float)par.res, Vector2d(0, 0), par.weight_intensity_, par.use_raw_pointcloud));  // :161
     CFEAR_TIMING.Document("Surface points", (double)Pcurrent->GetSize());  // pointnormal.cpp:87
+    const auto t2 = std::chrono::steady_clock::now();
+    CFEAR_TIMING.Document("compensate", std::chrono::duration<double, std::milli>(t1 - t0).count());     // odometrykeyframefuser.cpp:253
+    CFEAR_TIMING.Document("build_normals", std::chrono::duration<double, std::milli>(t2 - t1).count());  // :254
     const Affine3d Tguess = par.use_guess ? T_prev * TprevMot : T_prev;  // :164-168
     if (keyframes_.empty()) {  // :171-177
       keyframes_.push_back({Pcurrent, cfear_from_xyt(0, 0, 0)}); updated = true; return;
@@ -567,6 +730,7 @@ class OdometryKeyframeFuser {
     for (auto& k : keyframes_) { cov_vek.push_back(cfear_mat6_identity()); scans_vek.push_back(k.cloud_normal_); T_vek.push_back(k.pose); }
     cov_vek.push_back(cfear_mat6_identity()); scans_vek.push_back(Pcurrent); T_vek.push_back(Tguess);
     if (!par.disable_registration) (void)radar_reg->Register(scans_vek, T_vek, cov_vek, par.soft_constraint);  // :184-186: the result lands in a shadowed variable
+    CFEAR_TIMING.Document("register", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());  // :255
     Tcurrent = T_vek.back(); cov_current = cov_vek.back();  // :195-196
     const Affine3d Tmot_current = T_prev.inverse() * Tcurrent;
     if (!AccelerationVelocitySanityCheck(Tmot, Tmot_current)) Tcurrent = Tguess;  // :198-199

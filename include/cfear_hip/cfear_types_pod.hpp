@@ -55,6 +55,8 @@ inline void cfear_cloud_from_xyi(PointCloudXYZI& c, const float* xyi, size_t n) 
   for (size_t i = 0; i < n; i++) { c.points[i].x = xyi[3 * i]; c.points[i].y = xyi[3 * i + 1]; c.points[i].z = 0; c.points[i].intensity = xyi[3 * i + 2]; }
 }
 inline bool cfear_image_null(const ImageConstPtr& m) { return m.data == nullptr; }
+// the message's own bytes when they already are what toCvCopy(mono8) would produce (8-bit, one channel, rows back to back); else null
+inline const uint8_t* cfear_image_raw(const ImageConstPtr& m, int* rows, int* cols) { *rows = m.rows; *cols = m.cols; return m.data; }
 inline CvImagePtr cfear_image_to_cv(const ImageConstPtr& m) {  // cv_bridge::toCvCopy(msg, "mono8")
   CvImagePtr c(new CvImage()); c->rows = m.rows; c->cols = m.cols; c->stamp = m.stamp;
   c->image.assign(m.data, m.data + (size_t)m.rows * m.cols);

@@ -54,6 +54,12 @@ inline void cfear_cloud_from_xyi(PointCloudXYZI& c, const float* xyi, size_t n) 
   for (size_t i = 0; i < n; i++) { pcl::PointXYZI p; p.x = xyi[3 * i]; p.y = xyi[3 * i + 1]; p.z = 0; p.intensity = xyi[3 * i + 2]; c.points[i] = p; }  // radar_filters.cpp:326-334
 }
 inline bool cfear_image_null(const ImageConstPtr& m) { return m == NULL; }
+// the message's own bytes when they already are what toCvCopy(TYPE_8UC1) would produce (8-bit, one channel, rows back to back); else null
+inline const uint8_t* cfear_image_raw(const ImageConstPtr& m, int* rows, int* cols) {
+  *rows = (int)m->height; *cols = (int)m->width;
+  const bool mono = m->encoding == sensor_msgs::image_encodings::MONO8 || m->encoding == sensor_msgs::image_encodings::TYPE_8UC1;
+  return (mono && m->step == m->width && m->data.size() >= (size_t)m->height * m->width) ? m->data.data() : nullptr;
+}
 // radar_driver.cpp:81-82 / :104-105: toCvCopy(..., MONO8 / TYPE_8UC1); a stamp below 1 ms becomes ros::Time::now()
 inline CvImagePtr cfear_image_to_cv(const ImageConstPtr& m) {
   CvImagePtr c = cv_bridge::toCvCopy(m, sensor_msgs::image_encodings::TYPE_8UC1);

@@ -165,6 +165,13 @@ def test_cpp_mirror_classes_against_oracle(oracle, tmp_path):
     assert out["raw"]["nn5"] == int(np.argmin(d5))
     # the transformed-copy constructor: same number of cells, the moved cell 0 is its own nearest neighbour
     assert out["moved"]["cells"] == scans[2].size and out["moved"]["nn0"] == 0
+    # device twins of host clouds: the no-upload route gives exactly what the upload route gives, and a cloud the caller changed between
+    # CallbackOffline and Compensate / MapPointNormal (or a sibling changed / compensated by another motion after it was run ahead) is noticed
+    tw = out["twins"]
+    assert tw["same"] == 0 and tw["mutated"] == 0 and tw["sibling_mutated"] == 0 and tw["sibling_other_motion"] == 0 and tw["map"] == 0, tw
+    assert tw["mutated_differs"] == 1 and tw["map_differs"] == 1, tw
+    comp = oracle.compensate(clouds[2], np.array([0.8, -0.1, 0.03]), 0)
+    assert np.all(np.abs(np.array(tw["comp0"]) - comp[0, :2]) <= 2 * np.spacing(np.abs(comp[0, :2]).astype(np.float32)))
 
 
 @pytest.mark.gpu
