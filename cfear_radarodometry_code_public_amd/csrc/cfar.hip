@@ -39,6 +39,9 @@ struct CfarParams {
   int ipt;          // consecutive bins per thread of the prefix pass (odd: conflict-free LDS strides)
   float kf;         // scaling / (2 w) in float
   double range_res, scaling;
+  // owner-layout detector (cfar_detect_owner_kernel): prefix sums are kept as P << sh, a bin is worth a closer look when (S << sh) - I^2 * kopen <= 0
+  int sh, kopen;
+  int stop;         // profiling (CFEAR_CFAR_STOP = n): a row's trip ends after phase n (1 prefix, 2 integer test); 0 = the product
 };
 
 // the reference's decision as written (cfar.cpp:47-60), windows clipped by the row's ends
@@ -282,6 +285,355 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_detect_fast_kernel(const uint
   if (tid == 0) row_count[grow] = red_i[32] + red_i[33] + red_i[34] + red_i[35];
 }
 
+
+// ---- round 6: the detector with a thread owning TB consecutive bins from the load to the decision -----------------------------------------
+// cfar_detect_fast_kernel issues 1477 vector + 810 scalar + 200 LDS instructions per row (0.88 of the vector issue slots, 0.13 of the HBM rate): a
+// bin's decision is made by another lane than the one that squared it, I^2 comes back out of LDS, every comparison is a scalar mask of its own, and
+// the hit mask goes to memory for a second kernel that fetches the image again. Here
+//   * thread t keeps its TB bins' squares q[e] in registers; the prefix sum goes to LDS already scaled, P' = P << sh, in a transposed layout
+//     [e][t] (row e = the e-th bin of every thread: consecutive lanes, consecutive banks), every row twice - row TB + e holds row e one thread
+//     further - so that bin TB t + e + off is (row e + off mod TB, column t + off div TB) for EVERY e: the four window bounds of a bin are four
+//     ds_read_b32 off four address registers with compile-time offsets, no address arithmetic, no bank conflicts;
+//   * the test is in integers: I^2 > kf S  <=  (S << sh) - I^2 * kopen <= 0 with kopen = ceil((1 + 4e-6) 2^sh / kf) (v_mad_i32_i24 on the square
+//     the thread still holds; the sign bits collect in one register with v_alignbit). That is a superset of the hits by construction; the few bins
+//     it leaves (nine per row are hits, a fraction of that near-misses) go through the float pre-test and the reference's double arithmetic
+//     exactly as in the kernels above - same decisions, bit for bit (tests/test_cfar_gpu.py);
+//   * bins whose windows are clipped by a row end (g + w bins at either end, where the range gate lets them through) are decided by a short
+//     loop over just those bins with the general expressions and OR-ed into their owners' masks through LDS;
+//   * what leaves the kernel is the hits themselves - (bin, intensity) records in bin order per (row, wave) segment, and the segment's count
+//     - not a bit per bin: the second kernel (cfar_emit_recs_kernel) never touches the image or a mask. A segment with more hits than its slot
+//     holds (CFAR_SEG_CAP) writes its threads' hit masks instead and the emit kernel walks those (rare: a row of clutter).
+// The workgroups are persistent (a row per trip, the next row's loads in flight during the current row's decisions).
+constexpr int CFAR_SEG_CAP = 64;  // records per (row, wave) segment
+constexpr int CFAR_SEG_MASKS = 1 << 30;  // flag on a segment's count: its hits are in the threads' masks, not in records
+
+// thread's ND dwords of a row. CLAMPED: the caller hands a pointer inside the row for every thread (threads past the row's end one that they
+// then zero: cfar_zero_segment) - no branch around the loads, so the outstanding requests stay countable (a wait for the oldest of several rows in
+// flight instead of a wait for all of them).
+template <int ND>
+__device__ __forceinline__ void cfar_load_segment_full(__attribute__((address_space(1))) const uint32_t* p, uint32_t (&seg)[ND]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+  typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
+  typedef __attribute__((address_space(1))) const u32x4a g_cu32x4;
+  typedef __attribute__((address_space(1))) const u32x2a g_cu32x2;
+  constexpr int N4 = ND / 4 * 4, N2 = ND / 2 * 2;
+#pragma unroll
+  for (int j = 0; j < N4; j += 4) {
+    const u32x4 v = __builtin_nontemporal_load((g_cu32x4*)(p + j));
+    seg[j] = v.x; seg[j + 1] = v.y; seg[j + 2] = v.z; seg[j + 3] = v.w;
+  }
+  if constexpr (N2 > N4) {
+    const u32x2 v = __builtin_nontemporal_load((g_cu32x2*)(p + N4));
+    seg[N4] = v.x; seg[N4 + 1] = v.y;
+  }
+  if constexpr (ND > N2) seg[N2] = __builtin_nontemporal_load(p + N2);
+}
+template <int ND>
+__device__ __forceinline__ void cfar_load_segment(__attribute__((address_space(1))) const uint32_t* p, int navail, uint32_t (&seg)[ND]) {
+  if (navail >= ND) {
+    cfar_load_segment_full<ND>(p, seg);
+  } else {
+#pragma unroll
+    for (int j = 0; j < ND; j++) seg[j] = j < navail ? __builtin_nontemporal_load(p + j) : 0u;
+  }
+}
+
+template <int TB, int NW, int RS /* columns of the transposed prefix array: a multiple of 64, so that the reads of two rows pair up as ds_read2st64_b32 off one base */,
+          bool FULL /* the row is a whole number of threads' segments: branch-free loads, several rows in flight */>
+__global__ __launch_bounds__(64 * NW) void cfar_detect_owner_kernel(const uint8_t* __restrict__ polar, CfarParams P, int rows, int padl, int* __restrict__ seg_count,
+                                                                    uint32_t* __restrict__ recs, uint32_t* __restrict__ hmask) {
+  constexpr int NT = 64 * NW, ND = TB / 4;
+  static_assert(TB % 4 == 0 && TB <= 32 && RS % 64 == 0, "bins per thread / row stride");
+  extern __shared__ __attribute__((aligned(16))) uint32_t cfar_lds[];
+  typedef __attribute__((address_space(3))) uint32_t l_u32;
+  typedef __attribute__((address_space(1))) const uint32_t g_cu32;
+  l_u32* const lp = (l_u32*)cfar_lds;                 // [2 TB][RS] scaled prefix sums; thread t's column is padl + t
+  l_u32* const lcand = lp + 2 * TB * RS;              // [NW][64] a wave's candidate bins (what the integer test left)
+  l_u32* const lstage = lcand + NW * 64;              // [NW][CFAR_SEG_CAP] a wave's records of the row, until the next trip writes them out
+  int* const red_i = (int*)(cfar_lds + 2 * TB * RS + NW * 64 + NW * CFAR_SEG_CAP);  // [16] scan scratch
+  const int R = P.R, g = P.guard, w = P.window, sh = P.sh, ndw = R >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the four window bounds of bin TB t + e: rows e + r, column t + q of the transposed array (off = TB q + r, 0 <= r < TB)
+  l_u32 *pA, *pB, *pC, *pD;
+  {
+    const int off[4] = {-g - w, -g, g, g + w};
+    l_u32* pp[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int r = ((off[c] % TB) + TB) % TB, q = (off[c] - r) / TB;
+      pp[c] = lp + (r * RS + padl + tid + q);
+    }
+    pA = pp[0]; pB = pp[1]; pC = pp[2]; pD = pp[3];
+  }
+  l_u32* const pown = lp + (padl + tid);  // P'[TB t + e] = pown[e RS]
+  // Columns: thread t's at padl + t. Left of thread 0 the array reads 0 (bins < 0: written once, here), right of the thread that holds bin R it
+  // reads the row total (bins >= R): a window a row end clips is then simply the difference of two entries, like everywhere else. The threads past
+  // the row's end write those columns as a matter of course (their bytes are zeros); where the workgroup has no such thread a loop fills them in.
+  const int tR = R / TB, padr = (g + w + TB - 1) / TB + 1;
+  const int last_col_thread = min(tR + padr, RS - 1 - padl);
+  const bool writes = tid <= last_col_thread;
+  for (int k = tid; k < 2 * TB * padl; k += NT) lp[(k / padl) * RS + k % padl] = 0u;
+  // this thread's bins inside the range gate (cfar.cpp:45)
+  uint32_t vmask;
+  {
+    int lo_e = P.ilo - TB * tid, hi_e = P.ihi + 1 - TB * tid;
+    lo_e = lo_e < 0 ? 0 : (lo_e > TB ? TB : lo_e);
+    hi_e = hi_e < 0 ? 0 : (hi_e > TB ? TB : hi_e);
+    vmask = hi_e > lo_e ? ((hi_e >= 32 ? 0xFFFFFFFFu : ((1u << hi_e) - 1u)) & ~((1u << lo_e) - 1u)) : 0u;
+  }
+  const int navail = ndw - ND * tid;  // dwords of the row from this thread's first on
+  const int nK = -P.kopen;
+  const float kscale = P.kf * (float)w;  // scaling / 2, to a rounding (the margins of the pre-test cover it)
+  const int iv_min2 = P.iv_min * P.iv_min;
+  const uint32_t scale = 1u << sh;
+  // The decision for one bin the integer test could not rule out (any bin of the gate): the window sums off the prefix array, a float pre-test, the
+  // reference's own arithmetic for what that cannot decide (cfar.cpp:47-60). The integer test is a superset test for the clipped bins too: their
+  // windows are shorter than w, so their means - sums over fewer bins - are at least the sums over w.
+  auto decide = [&](int bin, int* iv2_out) -> bool {
+    const int t = bin / TB, e = bin - t * TB, dt = t - tid;
+    const uint32_t ts = (pB[e * RS + dt] - pA[e * RS + dt]) >> sh, fs = (pD[e * RS + dt] - pC[e * RS + dt]) >> sh;
+    const int iv2 = (int)((pown[(e + 1) * RS + dt] - pown[e * RS + dt]) >> sh);
+    *iv2_out = iv2;
+    const int t1 = bin - g, f0 = bin + g;
+    const int tn = t1 > 0 ? min(t1, w) : 0, fn = f0 < R ? min(R - f0, w) : 0;  // cfar.cpp:48-53
+    if (!(iv2 >= iv_min2 && tn > 0 && fn > 0)) return false;  // :45; an empty window makes the reference's mean NaN: no detection (:56)
+    const float thr = kscale * ((float)ts * __builtin_amdgcn_rcpf((float)tn) + (float)fs * __builtin_amdgcn_rcpf((float)fn));
+    const float I2 = (float)iv2;
+    if (I2 > thr * 1.00001f) return true;
+    if (!(I2 >= thr * 0.99999f)) return false;
+    return cfar_exact_vals(ts, tn, fs, fn, iv2, P.scaling);
+  };
+
+  // Rows in flight: the memory system needs ~2 us of requests outstanding to stream at its rate, and a compute unit holds five of these workgroups,
+  // so every workgroup keeps the next PF rows' bytes on their way (registers: ND each) while it works on the current one. (Rows past the end of the
+  // batch re-read the last row: nothing looks at them.)
+  constexpr int NBUF = 3;  // rows in flight per workgroup, the current one included
+  uint32_t buf0[ND], buf1[ND], buf2[ND];
+  int grow = blockIdx.x;
+  const bool has_bytes = navail >= ND;           // FULL: every thread holds a whole segment or none
+  const int toff = has_bytes ? ND * tid : 0;     // (threads without bytes read thread 0's and zero them)
+  auto request = [&](long long gk, uint32_t (&dst)[ND]) __attribute__((always_inline)) {
+    if constexpr (FULL) {
+      if (gk > rows - 1) gk = rows - 1;
+      cfar_load_segment_full<ND>((g_cu32*)(polar + gk * R) + toff, dst);
+    } else {
+      if (gk < rows) cfar_load_segment<ND>((g_cu32*)(polar + gk * R) + ND * tid, navail, dst);
+    }
+  };
+  request(grow, buf0);
+  request((long long)grow + gridDim.x, buf1);
+  request((long long)grow + 2LL * gridDim.x, buf2);
+  int prev_total = -1;  // records of the previous trip's row waiting in lstage (-1: nothing to write)
+  int prev_row = 0;
+  // one row; `seg` holds its bytes and is asked for the row NBUF trips ahead as soon as its squares are taken. (The three register sets take turns -
+  // the loop below is unrolled by three - because moving a set on would mean waiting for it.)
+  auto trip = [&](uint32_t (&seg)[ND]) __attribute__((always_inline)) {
+    // ---- squares, the segment's sum, its offset in the row ----
+    int nq[TB];       // -(I^2 kopen) - 1 per bin: what the integer test adds the window sums to
+    uint32_t qs[TB];  // I^2 << sh
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < ND; j++) {
+      const uint32_t d = (FULL && !has_bytes) ? 0u : seg[j], b[4] = {d & 0xFFu, (d >> 8) & 0xFFu, (d >> 16) & 0xFFu, d >> 24};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t q = __umul24(b[k], b[k]);
+        nq[4 * j + k] = __mul24((int)q, nK) - 1;
+        qs[4 * j + k] = __umul24(q, scale);
+      }
+      s = __builtin_amdgcn_udot4(d, d, s, false);
+    }
+#pragma unroll
+    for (int e = 0; e < TB; e++) asm volatile("" : "+v"(nq[e]), "+v"(qs[e]));  // (the squares are taken before the registers they come from are loaded again)
+    __builtin_amdgcn_sched_barrier(0);
+    // The previous row's records leave now - after the wait for this row's bytes, not before it: one counter serves loads and stores, and a store
+    // counts until the L2 has it - and the bytes of the row NBUF trips ahead are asked for right after.
+    if (prev_total >= 0) {
+      const size_t sidx = (size_t)prev_row * NW + wv;
+      if (lane < prev_total && !(prev_total & CFAR_SEG_MASKS)) recs[sidx * CFAR_SEG_CAP + lane] = lstage[wv * CFAR_SEG_CAP + lane];
+      if (lane == 0) seg_count[sidx] = prev_total;
+    }
+    request((long long)grow + (long long)NBUF * gridDim.x, seg);
+    if (P.stop == 11) { prev_total = (nq[0] ^ nq[TB - 1] ^ (int)qs[3] ^ (int)s) == 0x12345 ? 0 : -1; return; }
+    int tot;
+    uint32_t o = (uint32_t)block_exclusive_scan_1b<NT>((int)s, red_i, 0, &tot) << sh;
+    if (P.stop == 12) { prev_total = (nq[0] ^ nq[TB - 1] ^ (int)qs[3] ^ (int)o) == 0x12345 ? 0 : -1; __syncthreads(); return; }
+    // (the barrier of the scan also ends the previous row's reads of everything written below)
+    if (writes) {
+#pragma unroll
+      for (int e = 0; e < TB; e++) {
+        pown[e * RS] = o;
+        pown[(e + TB) * RS - 1] = o;  // ... one column to the left in the second copy
+        o += qs[e];
+      }
+    }
+    if (last_col_thread >= NT - 1) {  // (uniform; a row that nearly fills the workgroup) columns right of the last thread's: the row total
+      const int c0 = padl + NT - 1, ncol = RS - c0;  // the second copy of the last thread's column, then whole columns
+      const uint32_t tot_s = (uint32_t)tot << sh;
+      for (int k = tid; k < TB + 2 * TB * (ncol - 1); k += NT) {
+        if (k < TB) lp[(TB + k) * RS + c0] = tot_s;
+        else lp[((k - TB) % (2 * TB)) * RS + c0 + 1 + (k - TB) / (2 * TB)] = tot_s;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < TB; e++) asm volatile("" : "+v"(nq[e]));  // (kept in registers across the barrier: recomputing them from the bytes costs two instructions a bin)
+    __syncthreads();
+    if (P.stop == 1) { prev_total = -1; return; }
+    // ---- the integer test on every bin of the thread (bit e of h <-> bin TB t + e) ----
+    // (groups of GB bins, the next group's sixteen-odd reads in flight while this group's arithmetic runs: left to itself the compiler waits for
+    // every four reads - fourteen LDS round trips a row with nothing else to do at two waves per SIMD)
+    uint32_t h = 0;
+    {
+      constexpr int GB = TB % 7 == 0 ? 7 : (TB % 5 == 0 ? 5 : 4), NG = TB / GB;
+      uint32_t va[2][GB], vb[2][GB], vc[2][GB], vd[2][GB];
+#pragma unroll
+      for (int k = 0; k < GB; k++) {
+        const int e = TB - 1 - k;
+        va[0][k] = pA[e * RS]; vb[0][k] = pB[e * RS]; vc[0][k] = pC[e * RS]; vd[0][k] = pD[e * RS];
+      }
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) {
+        const int cur = gi & 1, nxt = cur ^ 1;
+        if (gi + 1 < NG) {
+#pragma unroll
+          for (int k = 0; k < GB; k++) {
+            const int e = TB - 1 - ((gi + 1) * GB + k);
+            va[nxt][k] = pA[e * RS]; vb[nxt][k] = pB[e * RS]; vc[nxt][k] = pC[e * RS]; vd[nxt][k] = pD[e * RS];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < GB; k++) {
+          const int e = TB - 1 - (gi * GB + k);
+          uint32_t r;  // bit 31 <=> (S << sh) <= I^2 kopen
+          asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(nq[e]), "v"(vb[cur][k]), "v"(vd[cur][k]));
+          r = r - va[cur][k] - vc[cur][k];
+          h = __builtin_amdgcn_alignbit(h, r, 31);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    h &= vmask;
+    if (P.stop == 2) { prev_total = h == 0xFFFFFFFFu ? 0 : -1; return; }
+    // ---- what it leaves, in bin order: one lane per candidate decides, the hits close ranks ----
+    const int c = __popc(h);
+    int total = 0;
+    if (__builtin_amdgcn_ballot_w64(c != 0)) {
+      const int inc = wave_inclusive_scan(c);
+      const int ncand = __builtin_amdgcn_readlane(inc, 63);
+      if (ncand <= 64) {
+        {
+          l_u32* out = lcand + wv * 64 + (inc - c);
+          uint32_t hh = h;
+          while (hh) {
+            const int e = __ffs((int)hh) - 1;
+            hh &= hh - 1u;
+            *out++ = (uint32_t)(TB * tid + e);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool hit = false;
+        int bin = 0, iv2 = 0;
+        if (lane < ncand) { bin = (int)lcand[wv * 64 + lane]; hit = decide(bin, &iv2); }
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        total = __popcll(hm);
+        if (hit) {
+          const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+          // (the intensity back out of its square: the square is exact, the root of a perfect square <= 255^2 within an ulp of the integer)
+          lstage[wv * CFAR_SEG_CAP + pos] = (uint32_t)bin | ((uint32_t)(__builtin_sqrtf((float)iv2) + 0.5f) << 16);
+        }
+      } else {  // a row of clutter: every thread walks its own candidates; the hit masks go out as they are and the emit kernel walks them
+        uint32_t hh = h;
+        while (hh) {
+          const int e = __ffs((int)hh) - 1;
+          hh &= hh - 1u;
+          int iv2;
+          if (!decide(TB * tid + e, &iv2)) h &= ~(1u << e);
+        }
+        hmask[(size_t)grow * NT + tid] = h;
+        total = CFAR_SEG_MASKS | __builtin_amdgcn_readlane(wave_inclusive_scan(__popc(h)), 63);  // the flag: the masks hold the segment
+      }
+    }
+    prev_total = total; prev_row = grow;
+  };
+  while (true) {
+    if (grow >= rows) break;
+    trip(buf0); grow += gridDim.x;
+    if (grow >= rows) break;
+    trip(buf1); grow += gridDim.x;
+    if (grow >= rows) break;
+    trip(buf2); grow += gridDim.x;
+  }
+  if (prev_total >= 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const size_t sidx = (size_t)prev_row * NW + wv;
+    if (lane < prev_total && !(prev_total & CFAR_SEG_MASKS)) recs[sidx * CFAR_SEG_CAP + lane] = lstage[wv * CFAR_SEG_CAP + lane];
+    if (lane == 0) seg_count[sidx] = prev_total;
+  }
+}
+
+// segments -> points: lane <-> segment (64 consecutive segments per wave); a lane walks its segment's records. Segments that overflowed their
+// slot are taken by the whole wave afterwards, from the threads' hit masks and the image.
+__global__ __launch_bounds__(CFAR_BLOCK) void cfar_emit_recs_kernel(const uint8_t* __restrict__ polar, CfarParams P, const double* __restrict__ trig,
+                                                                    const int* __restrict__ seg_count, const int* __restrict__ seg_base,
+                                                                    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ hmask,
+                                                                    float* __restrict__ xyi, int cap, long long n_segs, int NW, int TB) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long g0 = ((long long)blockIdx.x * (CFAR_BLOCK / 64) + wv) * 64;
+  if (g0 >= n_segs) return;
+  const long long gs = g0 + lane;
+  const bool valid = gs < n_segs;
+  const int craw = valid ? seg_count[gs] : 0, base = valid ? seg_base[gs] : 0;
+  const int c = craw & (CFAR_SEG_MASKS - 1);
+  if (c > 0 && !(craw & CFAR_SEG_MASKS)) {
+    const long long row = gs / NW;
+    const int img = (int)(row / P.A), az = (int)(row - (long long)img * P.A);
+    const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];  // theta = (az + 1) / A * 2 pi, host libm (cfar.cpp:40)
+    float* out = xyi + 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
+    const uint32_t* rr = recs + (size_t)gs * CFAR_SEG_CAP;
+    for (int k = 0; k < c; k++) {
+      const uint32_t rec = rr[k];
+      const int o = base + k;
+      if (o < cap) {
+        const double range = P.range_res * (double)(rec & 0xFFFFu);
+        out[3 * (size_t)o + 0] = (float)(range * cos_t);  // cfar.cpp:63-65
+        out[3 * (size_t)o + 1] = (float)(range * sin_t);
+        out[3 * (size_t)o + 2] = (float)(rec >> 16);
+      }
+    }
+  }
+  unsigned long long ov = __builtin_amdgcn_ballot_w64((craw & CFAR_SEG_MASKS) != 0);
+  while (ov) {
+    const int l = __ffsll((long long)ov) - 1;
+    ov &= ov - 1ull;
+    const long long sg = g0 + l;
+    const long long row = sg / NW;
+    const int swv = (int)(sg - row * NW), sbase = __builtin_amdgcn_readlane(base, l);
+    const int img = (int)(row / P.A), az = (int)(row - (long long)img * P.A);
+    const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];
+    float* out = xyi + 3 * (size_t)img * cap;
+    const uint8_t* rowp = polar + row * P.R;
+    uint32_t h = hmask[(size_t)row * (64 * NW) + 64 * swv + lane];
+    const int hc = __popc(h);
+    int o = wave_inclusive_scan(hc) - hc + sbase;
+    while (h) {
+      const int e = __ffs((int)h) - 1;
+      h &= h - 1u;
+      const int i = TB * (64 * swv + lane) + e;
+      if (o < cap) {
+        const double range = P.range_res * (double)i;
+        out[3 * (size_t)o + 0] = (float)(range * cos_t);
+        out[3 * (size_t)o + 1] = (float)(range * sin_t);
+        out[3 * (size_t)o + 2] = (float)rowp[i];
+      }
+      o++;
+    }
+  }
+}
+
 // a wave per four consecutive rows: the rows' masks -> their points, in range-bin order, at each row's offset of its image's cloud. (One
 // single-wave workgroup per row - 614 400 of them per 1536 sweeps, nine detections each - spent its time being dispatched: 430 us; the
 // counts, bases and mask words of a wave's four rows are in flight together here.)
@@ -368,10 +720,10 @@ __global__ __launch_bounds__(1024) void cfar_row_scan_kernel(const int* __restri
   const int ipt = (A + blockDim.x - 1) / blockDim.x;
   const int i0 = threadIdx.x * ipt, i1 = min(A, i0 + ipt);
   int s = 0;
-  for (int i = i0; i < i1; i++) s += row_count[i];
+  for (int i = i0; i < i1; i++) s += row_count[i] & 0x3FFFFFFF;  // (bit 30: CFAR_SEG_MASKS of the owner-layout detector's segments)
   int tot;
   int o = block_exclusive_scan(s, red_i, &tot);
-  for (int i = i0; i < i1; i++) { row_base[i] = o; o += row_count[i]; }
+  for (int i = i0; i < i1; i++) { row_base[i] = o; o += row_count[i] & 0x3FFFFFFF; }
   if (threadIdx.x == 0) *d_total = tot;
 }
 
@@ -400,7 +752,117 @@ int cfar_params(cfear_ctx* ctx, int window_size, int nb_guard_cells, float false
   P.mask_words = 2 * ((P.R + 63) / 64);
   P.ipt = (P.R + CFAR_BLOCK - 1) / CFAR_BLOCK;
   P.ipt |= 1;
+  // owner-layout detector: the scale of the integer test (sh < 0: not usable - the old kernels run)
+  P.sh = -1; P.kopen = 0;
+  { static const int stop = getenv("CFEAR_CFAR_STOP") ? atoi(getenv("CFEAR_CFAR_STOP")) : 0; P.stop = stop; }
+  {
+    const double smax = 2.0 * (double)window_size * 65025.0, kf = P.scaling * 0.5 / (double)window_size;
+    for (int sh = 12; sh >= 0 && P.sh < 0; sh--) {
+      if (smax * (double)(1 << sh) >= 2147483648.0) continue;
+      const double k = ceil((1.0 + 4e-6) * (double)(1 << sh) / kf);
+      if (k >= 64.0 && k <= 33025.0) { P.sh = sh; P.kopen = (int)k; }  // I^2 kopen < 2^31; at least six bits of the threshold
+    }
+  }
   *out = P;
+  return CFEAR_OK;
+}
+
+// ---- which instantiation of the owner-layout detector a row length takes (threads x bins per thread just above R) ----
+struct CfarOwnerShape { int TB, NW; };
+
+const CfarOwnerShape* cfar_owner_shape(int R, int reach /* guard + window, or 0: the shape with the largest scratch for this row length */) {
+  static const CfarOwnerShape shapes[4] = {{28, 2}, {20, 3}, {16, 4}, {32, 4}};
+  static const int forced = getenv("CFEAR_CFAR_SHAPE") ? atoi(getenv("CFEAR_CFAR_SHAPE")) : 0;  // bins per thread (tools/gpu_time_cfar.py: A/B of the shapes)
+  // Measured at 3360 bins (profiles/r06_cfar_shapes.txt): two waves x 28 bins per thread is the fastest shape while the windows are short; with long
+  // windows (the reference's sweep goes to 500 bins) the bins a row end clips are hundreds, the integer test is loose for them, and a wave of 1792
+  // bins collects more than the 64 candidates one pass decides - four waves x 16 bins then.
+  const CfarOwnerShape* best = nullptr;
+  for (const CfarOwnerShape& s : shapes) {
+    if (R >= 64 * s.NW * s.TB) continue;
+    if (forced ? s.TB == forced : false) return &s;
+    if (reach > 128 && s.NW < 4) continue;
+    if (reach == 0 ? (!best || s.NW > best->NW) : (!best || s.NW * s.TB < best->NW * best->TB)) best = &s;
+  }
+  return best;
+}
+size_t cfar_owner_ints_per_row(const CfarOwnerShape& s) { return (size_t)s.NW * (2 + CFAR_SEG_CAP) + 64 * (size_t)s.NW; }
+int cfar_device_cus(int device) {
+  static int cus[64] = {0};
+  if (device < 0 || device >= 64) return 256;
+  if (!cus[device]) { int n = 0; cus[device] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ? n : 256; }
+  return cus[device];
+}
+constexpr size_t cfar_owner_lds_bytes(int TB, int NW, int RS) { return sizeof(uint32_t) * (2 * (size_t)TB * RS + 64 * NW + (size_t)NW * CFAR_SEG_CAP + 16); }
+template <int TB, int NW, int RS, bool FULL>
+int cfar_launch_owner_tf(cfear_ctx* ctx, const CfarParams& P, int padl, const uint8_t* d_polar, size_t rows, int* seg_count, uint32_t* recs, uint32_t* hmask, hipStream_t stream) {
+  constexpr int NT = 64 * NW;
+  constexpr size_t lds = cfar_owner_lds_bytes(TB, NW, RS);
+  if (lds > 64 * 1024)
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_detect_owner_kernel<TB, NW, RS, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((160 * 1024) / (lds + 512));  // persistent workgroups: what a compute unit's LDS holds, up to 32 waves
+  if (per_cu * NW > 32) per_cu = 32 / NW;
+  if (per_cu < 1) per_cu = 1;
+  { static const int force = getenv("CFEAR_CFAR_PER_CU") ? atoi(getenv("CFEAR_CFAR_PER_CU")) : 0; if (force > 0 && force < per_cu) per_cu = force; }  // (profiling: fewer resident workgroups)
+  size_t grid = (size_t)cfar_device_cus(ctx->device) * per_cu;
+  if (grid > rows) grid = rows;
+  hipLaunchKernelGGL((cfar_detect_owner_kernel<TB, NW, RS, FULL>), dim3((unsigned)grid), dim3(NT), lds, stream, d_polar, P, (int)rows, padl, seg_count, recs, hmask);
+  return CFEAR_OK;
+}
+template <int TB, int NW, int RS>
+int cfar_launch_owner_t(cfear_ctx* ctx, const CfarParams& P, int padl, const uint8_t* d_polar, size_t rows, int* seg_count, uint32_t* recs, uint32_t* hmask, hipStream_t stream) {
+  return P.R % TB == 0 ? cfar_launch_owner_tf<TB, NW, RS, true>(ctx, P, padl, d_polar, rows, seg_count, recs, hmask, stream)
+                       : cfar_launch_owner_tf<TB, NW, RS, false>(ctx, P, padl, d_polar, rows, seg_count, recs, hmask, stream);
+}
+// columns of the transposed prefix array this configuration needs: one per thread that holds bins (and the one that holds bin R), and on either
+// side the window's reach in threads + 1; rounded up to a multiple of 64
+int cfar_owner_columns(const CfarParams& P, const CfarOwnerShape& s, int* padl) {
+  const int pad = (P.guard + P.window + s.TB - 1) / s.TB + 1, data = P.R / s.TB + 1;
+  const int rs = (data + 2 * pad + 63) / 64 * 64;
+  *padl = (rs - data) / 2;
+  return rs;
+}
+// true when the owner-layout detector takes this configuration (dword rows and base, a usable integer scale, an instantiation for its columns)
+bool cfar_owner_usable(const CfarParams& P, const uint8_t* d_polar, const CfarOwnerShape** shape) {
+  static const bool off = getenv("CFEAR_CFAR_OLD_KERNELS") != nullptr;  // tools/gpu_time_cfar.py: A/B timing against the round-5 kernels
+  if (off || (P.R & 3) != 0 || (reinterpret_cast<uintptr_t>(d_polar) & 3) != 0 || P.sh < 0 || P.iv_min > 255) return false;
+  const CfarOwnerShape* s = cfar_owner_shape(P.R, P.guard + P.window);
+  if (!s) return false;
+  int padl;
+  if (cfar_owner_columns(P, *s, &padl) > 64 * s->NW + 128) return false;
+  *shape = s;
+  return true;
+}
+int cfar_launch_owner(cfear_ctx* ctx, const CfarParams& P, const CfarOwnerShape& s, const uint8_t* d_polar, size_t rows, int* seg_count, uint32_t* recs,
+                      uint32_t* hmask, hipStream_t stream) {
+  int padl;
+  const int rs = cfar_owner_columns(P, s, &padl);
+#define CFAR_OWNER_CASE(TB_, NW_) \
+  if (s.TB == TB_ && s.NW == NW_) { \
+    if (rs <= 64 * NW_) return cfar_launch_owner_t<TB_, NW_, 64 * NW_>(ctx, P, padl + (64 * NW_ - rs) / 2, d_polar, rows, seg_count, recs, hmask, stream); \
+    if (rs <= 64 * NW_ + 64) return cfar_launch_owner_t<TB_, NW_, 64 * NW_ + 64>(ctx, P, padl + (64 * NW_ + 64 - rs) / 2, d_polar, rows, seg_count, recs, hmask, stream); \
+    return cfar_launch_owner_t<TB_, NW_, 64 * NW_ + 128>(ctx, P, padl + (64 * NW_ + 128 - rs) / 2, d_polar, rows, seg_count, recs, hmask, stream); \
+  }
+  CFAR_OWNER_CASE(28, 2)
+  CFAR_OWNER_CASE(20, 3)
+  CFAR_OWNER_CASE(16, 4)
+  CFAR_OWNER_CASE(32, 4)
+#undef CFAR_OWNER_CASE
+  return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "filter_cfar: no detector instantiation for this row length");
+}
+// detect -> segment scan -> emit with the owner-layout detector; d_rows: cfear_cfar_scratch_ints ints. d_counts[i] = detections of image i.
+int cfar_launch_owner_path(cfear_ctx* ctx, const CfarParams& P, const CfarOwnerShape& s, const uint8_t* d_polar, int n_scans, float* d_xyi, int capacity,
+                           int* d_counts, int* d_rows, hipStream_t stream, bool emit) {
+  const size_t rows = (size_t)n_scans * P.A, segs = rows * s.NW;
+  int* seg_count = d_rows; int* seg_base = seg_count + segs;
+  uint32_t* recs = reinterpret_cast<uint32_t*>(seg_base + segs);
+  uint32_t* hmask = recs + segs * CFAR_SEG_CAP;
+  int rc = cfar_launch_owner(ctx, P, s, d_polar, rows, seg_count, recs, hmask, stream);
+  if (rc != CFEAR_OK) return rc;
+  hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(n_scans), dim3(1024), 0, stream, seg_count, P.A * s.NW, seg_base, d_counts);
+  if (emit)
+    hipLaunchKernelGGL(cfar_emit_recs_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(CFAR_BLOCK), 0, stream, d_polar, P, ctx->d_trig, seg_count, seg_base, recs, hmask,
+                       d_xyi, capacity, (long long)segs, s.NW, s.TB);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
 size_t cfar_lds_bytes(const CfarParams& P) { return sizeof(uint32_t) * (size_t)(P.R + 1) + (size_t)((P.R + 3 + 7) & ~3); }
@@ -435,14 +897,22 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_gua
   int rc = cfar_params(ctx, window_size, nb_guard_cells, false_alarm_rate, max_distance, &P);
   if (rc != CFEAR_OK) return rc;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  int* d_tmp = nullptr;  // row counts, row bases, total, masks (a block of the context's pool)
+  int* d_tmp = nullptr;  // the detector's row scratch + the total (a block of the context's pool)
   size_t tmp_bytes = 0;
-  { void* blk = nullptr; rc = cfear_pool_alloc(ctx, sizeof(int) * ((2 + (size_t)P.mask_words) * P.A + 1), &blk, &tmp_bytes); if (rc != CFEAR_OK) return rc; d_tmp = static_cast<int*>(blk); }
-  int* d_count = d_tmp; int* d_base = d_tmp + P.A; int* d_total = d_tmp + 2 * P.A;
-  uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_total + 1);
-  rc = cfar_launch_detect(ctx, P, d_polar, (size_t)P.A, d_count, d_mask, ctx->stream);
+  const size_t row_ints = cfear_cfar_scratch_ints(ctx, 1);
+  { void* blk = nullptr; rc = cfear_pool_alloc(ctx, sizeof(int) * (row_ints + 1), &blk, &tmp_bytes); if (rc != CFEAR_OK) return rc; d_tmp = static_cast<int*>(blk); }
+  int* d_total = d_tmp + row_ints;
+  const CfarOwnerShape* shape = nullptr;
+  const bool owner = cfar_owner_usable(P, d_polar, &shape);
+  int* d_count = d_tmp; int* d_base = d_tmp + P.A;
+  uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_tmp + 2 * P.A);
+  if (owner) {
+    rc = cfar_launch_owner_path(ctx, P, *shape, d_polar, 1, nullptr, 0, d_total, d_tmp, ctx->stream, false);
+  } else {
+    rc = cfar_launch_detect(ctx, P, d_polar, (size_t)P.A, d_count, d_mask, ctx->stream);
+    if (rc == CFEAR_OK) hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_total);
+  }
   if (rc != CFEAR_OK) { cfear_pool_free(ctx, d_tmp, tmp_bytes); return rc; }
-  hipLaunchKernelGGL(cfar_row_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_count, P.A, d_base, d_total);
   int total = 0;
   hipError_t e = hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -450,9 +920,18 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_gua
   cfear_cloud* c = nullptr;
   rc = cfear_cloud_alloc(ctx, total, &c);
   if (rc != CFEAR_OK) { cfear_pool_free(ctx, d_tmp, tmp_bytes); return rc; }
-  if (total > 0)
-    hipLaunchKernelGGL(cfar_emit_kernel, dim3((P.A + 4 * CFAR_EMIT_ROWS - 1) / (4 * CFAR_EMIT_ROWS)), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask,
-                       c->d_xyi, c->cap, (long long)P.A);
+  if (total > 0) {
+    if (owner) {
+      const size_t segs = (size_t)P.A * shape->NW;
+      int* seg_count = d_tmp; int* seg_base = seg_count + segs;
+      uint32_t* recs = reinterpret_cast<uint32_t*>(seg_base + segs);
+      hipLaunchKernelGGL(cfar_emit_recs_kernel, dim3((unsigned)((segs + 255) / 256)), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, P, ctx->d_trig, seg_count, seg_base, recs,
+                         recs + segs * CFAR_SEG_CAP, c->d_xyi, c->cap, (long long)segs, shape->NW, shape->TB);
+    } else {
+      hipLaunchKernelGGL(cfar_emit_kernel, dim3((P.A + 4 * CFAR_EMIT_ROWS - 1) / (4 * CFAR_EMIT_ROWS)), dim3(CFAR_BLOCK), 0, ctx->stream, d_polar, P, ctx->d_trig, d_count, d_base, d_mask,
+                         c->d_xyi, c->cap, (long long)P.A);
+    }
+  }
   e = hipMemcpyAsync(c->d_n, d_total, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   cfear_pool_free(ctx, d_tmp, tmp_bytes);
@@ -465,7 +944,10 @@ int cfar_run(cfear_ctx* ctx, const uint8_t* d_polar, int window_size, int nb_gua
 
 // ints of row scratch the batched filter needs for n_scans images: row counts, row bases, hit masks
 __attribute__((visibility("hidden"))) size_t cfear_cfar_scratch_ints(const cfear_ctx* ctx, size_t n_scans) {
-  return n_scans * (size_t)ctx->A * (2 + 2 * (size_t)((ctx->R + 63) / 64));
+  size_t per_row = 2 + 2 * (size_t)((ctx->R + 63) / 64);  // mask-based kernels
+  const CfarOwnerShape* s = cfar_owner_shape(ctx->R, 0);  // owner-layout detector: segment counts, bases, record slots, overflow masks (its widest shape)
+  if (s && cfar_owner_ints_per_row(*s) > per_row) per_row = cfar_owner_ints_per_row(*s);
+  return n_scans * (size_t)ctx->A * per_row;
 }
 // the batched filter on `stream` with the caller's row scratch (cfear_cfar_scratch_ints): detect pass (the only one that reads the
 // images), one row scan per image, emit pass (cfear_filter_cfar_batch_device; the CA-CFAR stage of the batched odometry objects)
@@ -478,6 +960,11 @@ __attribute__((visibility("hidden"))) int cfear_launch_cfar_batch(cfear_ctx* ctx
   int rc = cfar_params(ctx, window_size, nb_guard_cells, false_alarm_rate, max_distance, &P);
   if (rc != CFEAR_OK) return rc;
   const size_t rows = (size_t)n_scans * ctx->A;
+  {
+    const CfarOwnerShape* shape = nullptr;
+    if (cfar_owner_usable(P, d_polar, &shape))
+      return cfar_launch_owner_path(ctx, P, *shape, d_polar, n_scans, d_xyi, capacity, d_counts, d_rows, stream, true);
+  }
   int* d_count = d_rows; int* d_base = d_count + rows;
   uint32_t* d_mask = reinterpret_cast<uint32_t*>(d_base + rows);
   rc = cfar_launch_detect(ctx, P, d_polar, rows, d_count, d_mask, stream);

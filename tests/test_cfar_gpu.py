@@ -56,6 +56,22 @@ def test_parameter_sweep_rows_of_whole_dwords(oracle, R, window, guard, pfa, min
     run(np.ascontiguousarray(img), oracle, zmin, mind, window, guard, pfa)
 
 
+@pytest.mark.parametrize("R", [3360, 3768, 1792])
+def test_rows_of_clutter(oracle, R):
+    """hundreds of detections per row: a wave of the owner-layout detector (csrc/cfar.hip, round 6) collects more candidates than the 64 its one-pass
+    decision takes and more hits than a segment's record slot holds - the threads' hit masks go out and the emit kernel walks them - next to quiet rows
+    that take the record route, in one image; 1792 bins = exactly the 64 x 28 bins two waves hold (the row then takes the next wider shape)"""
+    rng = np.random.default_rng(R)
+    img = rng.integers(0, 12, size=(12, R), dtype=np.uint8)
+    img[::2, ::8] = 255          # a comb: every spike is a detection
+    img[1::4, 100:103] = 200     # quiet rows with one return
+    img[3, :] = 90
+    img[3, ::5] = 140            # spikes over a plateau: some are hits, some not
+    n = run(img, oracle, zmin=20.0, window=40, guard=10)
+    assert n > 6 * (R // 8 - 20)
+    run(img, oracle, zmin=20.0, window=500, guard=10, pfa=0.0001)
+
+
 def test_world_sweep_host_and_device_entry_points(oracle):
     img = synth.world_scan(synth.World(7), 3, seed=2)
     n = run(img, oracle)
