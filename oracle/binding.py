@@ -116,9 +116,13 @@ def lib():
     L.cfo_filter_bruteforce.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
     L.cfo_cloud.argtypes = [u32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p]
     L.cfo_compensate.argtypes = [f32p, C.c_int, f64p, C.c_int]
+    L.cfo_loss_eval.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.cfo_loss_eval.restype = None
     L.cfo_cfar_scaling.argtypes = [C.c_int, C.c_double]
     L.cfo_cfar_scaling.restype = C.c_double
     L.cfo_cfar.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_double, C.c_int, C.c_int, C.c_float, f32p, C.c_int]
+    L.cfo_cfar_prefix.argtypes = L.cfo_cfar.argtypes
+    L.cfo_cfar_prefix.restype = C.c_int
     L.cfo_scan_create.argtypes = [f32p, C.c_int, C.POINTER(Params), C.c_int]
     L.cfo_scan_create.restype = C.c_void_p
     L.cfo_scan_free.argtypes = [C.c_void_p]
@@ -187,16 +191,25 @@ def cloud(slots, range_res, min_distance, peaks=False):
     return xyi[:n].copy()
 
 
-def cfar(img, range_res, static_threshold, min_distance, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0):
-    """AzimuthCACFAR::getFilteredPointCloud with the defaults of radarDriver::Parameters (radar_driver.h:43-44)."""
+def cfar(img, range_res, static_threshold, min_distance, window_size=10, nb_guard_cells=20, false_alarm_rate=0.01, max_distance=400.0, prefix=False):
+    """AzimuthCACFAR::getFilteredPointCloud with the defaults of radarDriver::Parameters (radar_driver.h:43-44). prefix=True: the window sums off a
+    prefix sum (cfo_cfar_prefix: the same arithmetic, exact sums; for long windows)."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     A, R = img.shape
     args = (_ptr(img, C.c_uint8), A, R, np.float32(range_res), np.float32(static_threshold), np.float32(min_distance),
             float(max_distance), int(window_size), int(nb_guard_cells), np.float32(false_alarm_rate))
-    n = lib().cfo_cfar(*args, None, 0)
+    fn = lib().cfo_cfar_prefix if prefix else lib().cfo_cfar
+    n = fn(*args, None, 0)
     xyi = np.zeros((max(n, 1), 3), dtype=np.float32)
-    lib().cfo_cfar(*args, _ptr(xyi, C.c_float), n)
+    fn(*args, _ptr(xyi, C.c_float), n)
     return xyi[:n].copy()
+
+
+def loss_eval(loss, loss_limit, s):
+    """(rho, rho', rho'') of the loss the registration builds (registration.cpp:78-97), at squared residual norm s"""
+    out = (C.c_double * 3)()
+    lib().cfo_loss_eval(int(loss), float(loss_limit), float(s), out)
+    return np.array(out[:])
 
 
 def compensate(xyi, mot, ccw):

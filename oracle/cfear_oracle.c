@@ -291,6 +291,51 @@ int cfo_cfar(const uint8_t* img, int A, int R, float range_res_f, float static_t
   return n;
 }
 
+/* The same detector with the window sums taken off a prefix sum of squares instead of being re-added per bin. Not a different arithmetic: every
+ * partial sum the reference's getMean forms is an integer below 2^53, so its double additions are exact and `sum` there equals the integer window sum
+ * here; N, the division, the mean of the two means, the scaling and the comparison are the statements above. (For the long windows of the reference's
+ * sweep - launch/oxford/eval/params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar:31: up to 500 bins - the literal version spends a second per sweep;
+ * tests/test_oracle_cpu.py checks the two against each other bin for bin.) */
+int cfo_cfar_prefix(const uint8_t* img, int A, int R, float range_res_f, float static_threshold_f, float min_distance_f,
+                    double max_distance, int window_size, int nb_guard_cells, float false_alarm_rate_f, float* xyi, int cap) {
+  const double range_resolution = (double)range_res_f, static_threshold = (double)static_threshold_f;
+  const double min_distance = (double)min_distance_f;
+  const double scaling_factor = cfo_cfar_scaling(window_size, (double)false_alarm_rate_f);
+  unsigned long long* pre = (unsigned long long*)malloc(sizeof(unsigned long long) * ((size_t)R + 1));
+  int n = 0;
+  for (int az = 0; az < A; az++) {
+    const uint8_t* row = img + (size_t)az * R;
+    const double theta = ((double)(az + 1) / A) * 2. * M_PI;
+    pre[0] = 0;
+    for (int i = 0; i < R; i++) pre[i + 1] = pre[i] + (unsigned long long)row[i] * row[i];
+    for (int bin = 0; bin < R; bin++) {
+      const double range = range_resolution * (double)bin;
+      const double intensity = (double)row[bin];
+      if (range > min_distance && range < max_distance && intensity > static_threshold) {
+        const int t0 = bin - nb_guard_cells - window_size > 0 ? bin - nb_guard_cells - window_size : 0;
+        const int t1 = bin - nb_guard_cells;
+        const int f0 = bin + nb_guard_cells;
+        const int f1 = R < bin + nb_guard_cells + window_size ? R : bin + nb_guard_cells + window_size;
+        const double tsum = t1 > t0 ? (double)(pre[t1] - pre[t0]) : 0., tN = t1 > t0 ? (double)(t1 - t0) : 0.;
+        const double fsum = f1 > f0 ? (double)(pre[f1] - pre[f0]) : 0., fN = f1 > f0 ? (double)(f1 - f0) : 0.;
+        const double mean = (tsum / tN + fsum / fN) / 2.0;
+        const double threshold = scaling_factor * mean;
+        const double squared_intensity = pow(intensity, 2.);
+        if (squared_intensity > threshold) {
+          if (n < cap) {
+            xyi[3 * n + 0] = (float)(range * cos(theta));
+            xyi[3 * n + 1] = (float)(range * sin(theta));
+            xyi[3 * n + 2] = (float)intensity;
+          }
+          n++;
+        }
+      }
+    }
+  }
+  free(pre);
+  return n;
+}
+
 /* utils.h:28-32 */
 static double rel_time_stamp(double x, double y, int ccw) {
   double a = atan2(y, x);
@@ -895,6 +940,10 @@ static void loss_eval(int loss, double a, double s, double rho[3]) {
     default: rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; return; /* nullptr loss */
   }
 }
+
+/* rho(s), rho'(s), rho''(s) of the loss the registration builds for (loss, loss_limit) - registration.cpp:78-97 -> the Ceres 2.0 forms above; exported so
+ * that tests can hold them against closed forms and, once it exists, against ceres::LossFunction::Evaluate itself (ref_golden.npz `ceres_loss_probe`) */
+void cfo_loss_eval(int loss, double loss_limit, double s, double rho[3]) { loss_eval(loss, loss_limit, s, rho); }
 
 typedef struct {
   const match_t* m; int nm; int cost; int loss; double loss_limit;

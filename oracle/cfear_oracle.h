@@ -105,9 +105,13 @@ int cfo_filter_bruteforce(const uint8_t* img, int A, int R, int z_min, int k, ui
  * xyi = 3 floats per point (x, y, intensity); returns number of points. */
 /* azimuth CA-CFAR, the alternative stage-1 filter (cfar.cpp:27-87, radar_driver.cpp:52-56); returns the number
  * of detections, writes at most cap of them */
+/* rho, rho', rho'' of the loss registration.cpp:78-97 builds (Ceres 2.0 forms; [3P]) */
+void cfo_loss_eval(int loss, double loss_limit, double s, double rho[3]);
 double cfo_cfar_scaling(int window_size, double false_alarm_rate);
 int cfo_cfar(const uint8_t* img, int A, int R, float range_res, float static_threshold, float min_distance,
              double max_distance, int window_size, int nb_guard_cells, float false_alarm_rate, float* xyi, int cap);
+int cfo_cfar_prefix(const uint8_t* img, int A, int R, float range_res, float static_threshold, float min_distance,
+             double max_distance, int window_size, int nb_guard_cells, float false_alarm_rate, float* xyi, int cap);  /* the same decisions, window sums off a prefix sum */
 int cfo_cloud(const uint32_t* slots, int A, int k, float range_res, float min_distance, int peaks,
               float* xyi);
 

@@ -10,6 +10,9 @@
 #include <string>
 #include <vector>
 
+#include <ceres/ceres.h>
+#include <ceres/version.h>
+
 #include <ros/ros.h>
 #include <cv_bridge/cv_bridge.h>
 #include <sensor_msgs/image_encodings.h>
@@ -215,6 +218,22 @@ int main(int argc, char** argv) {
       for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) covs.push_back(cov(a, b));
     }
     w.f64(pass == 0 ? "fuser_reg_cov_p2l" : "fuser_sampled_cov_p2l", covs, {8, 6, 6});
+  }
+  // ---- 6. what the reference leaves to the installed Ceres (CMakeLists.txt:38: find_package(Ceres REQUIRED), no version). Two things differ
+  //         between the versions its README's distributions ship (1.13 / 1.14 on Ubuntu 18.04, 2.0 on 20.04) and are visible in the results:
+  //         TukeyLoss - rho = a^2/3 (1 - (1 - s/a^2)^3) in 2.0, a^2/6 (...) with rho' = 1/2 (1 - s/a^2)^2 in <= 1.14 (a factor two on every cost and
+  //         covariance of a Tukey run; the oracle states the 2.0 form) - and the order of the convergence tests in the trust-region loop
+  //         (>= 1.13: the tolerances are checked before the step is accepted; the oracle's order), which the iteration counts above show. The
+  //         version and the losses' own Evaluate(s) are written out so that the comparison says which form the box had.
+  {
+    w.f64("ceres_version", {(double)CERES_VERSION_MAJOR, (double)CERES_VERSION_MINOR, (double)CERES_VERSION_REVISION}, {3});
+    const double ss[7] = {0.0, 0.005, 0.01, 0.04, 0.2, 0.25, 1.0};
+    ceres::HuberLoss huber(0.1); ceres::CauchyLoss cauchy(0.2); ceres::SoftLOneLoss softl1(0.1); ceres::TukeyLoss tukey(0.5);
+    ceres::LossFunction* fs[4] = {&huber, &cauchy, &softl1, &tukey};
+    std::vector<double> probe;
+    for (int f = 0; f < 4; f++)
+      for (int i = 0; i < 7; i++) { double rho[3]; fs[f]->Evaluate(ss[i], rho); probe.insert(probe.end(), rho, rho + 3); }
+    w.f64("ceres_loss_probe", probe, {4, 7, 3});  // [Huber 0.1, Cauchy 0.2, SoftLOne 0.1, Tukey 0.5][s][rho, rho', rho'']
   }
   std::printf("wrote %s\n", argv[2]);
   return 0;

@@ -70,3 +70,20 @@ def test_last_guard_bins_of_a_row_never_detect(oracle):
     got = oracle.cfar(img, 0.0595238, 60.0, 2.5, 10, 5, 0.01)
     r = np.hypot(got[:, 0], got[:, 1]) / np.float32(0.0595238)
     assert len(got) == 2 and np.allclose(r, 150.0, atol=1e-2)
+
+
+@pytest.mark.parametrize("window,guard,pfa,mind,zmin", [(40, 10, 0.01, 2.5, 20.0), (500, 10, 0.0001, 2.5, 20.0), (150, 10, 0.001, 0.0, 20.0), (3, 0, 0.2, 0.0, 0.0), (700, 30, 0.01, 2.5, 10.0)])
+def test_prefix_sum_twin_makes_the_literal_detectors_decisions(oracle, window, guard, pfa, mind, zmin):
+    """cfo_cfar_prefix (window sums off a prefix sum: what the long windows of the reference's sweep are checked with on the GPU,
+    launch/oxford/eval/params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar:31-32) against cfo_cfar (the per-bin window loop of cfar.cpp:76-86): the same cloud,
+    on a world sweep, on random bytes with a comb of returns, on rows shorter than the window, and on plateaus where I^2 sits on the threshold"""
+    rng = np.random.default_rng(window + guard)
+    world = synth.world_scan(synth.World(7), 3, seed=2)[:40]
+    rnd = rng.integers(0, 256, size=(12, 1001), dtype=np.uint8)
+    rnd[:, ::7] = np.minimum(rnd[:, ::7].astype(int) + 120, 255).astype(np.uint8)
+    levels = np.array([0, 40, 40, 80, 120, 200], dtype=np.uint8)
+    plateaus = np.ascontiguousarray(np.repeat(levels[rng.integers(0, len(levels), size=(12, 100))], 8, axis=1))
+    for img in (world, rnd, plateaus, rnd[:, :300].copy()):
+        a = oracle.cfar(img, 0.0595238, zmin, mind, window, guard, pfa)
+        b = oracle.cfar(img, 0.0595238, zmin, mind, window, guard, pfa, prefix=True)
+        assert a.shape == b.shape and np.array_equal(a, b)

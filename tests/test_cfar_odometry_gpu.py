@@ -33,8 +33,8 @@ def _hip_params(kw, max_points=0, **cfar):
                                cfar_false_alarm_rate=c["false_alarm_rate"], cfar_max_points=max_points, **kw)
 
 
-def _expect(oracle, fu, img, kw, cfar):
-    cloud = oracle.cfar(img, float(np.float32(kw["range_res"])), float(kw["z_min"]), 2.5, **cfar)
+def _expect(oracle, fu, img, kw, cfar, prefix=False):
+    cloud = oracle.cfar(img, float(np.float32(kw["range_res"])), float(kw["z_min"]), 2.5, prefix=prefix, **cfar)
     pose = fu.process_cloud(cloud)
     S = fu.last_summary()
     no = max(int(S.outer_iterations), 0)
@@ -79,6 +79,38 @@ def test_cfar_fuser_matches_oracle_at_every_sweep(oracle, route, kind, extra):
                 assert g == e, (t, q, g, e)
             assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
     assert min(npts) > 500 and e[3] == kw["submap_scan_size"] and e[2] > 50, (min(npts), max(npts), e)
+    odo.release()
+    ctx.close()
+
+
+@pytest.mark.parametrize("window,pfa,route", [(500, 0.0001, "replay_persistent"), (150, 0.001, "replay_batched"), (500, 0.0001, "replay_batched")])
+def test_cfar_fuser_long_windows_of_the_reference_sweep(oracle, window, pfa, route):
+    """the far corner and the middle of the reference's CA-CFAR grid (launch/oxford/eval/params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar:31-32: window 40 ... 500
+    x false-alarm rate 0.1 ... 0.0001, 10 guard cells) through cfear_odometry_replay_host, 60 sweeps, against the oracle's fuser at every sweep. The oracle's
+    detector here is its prefix-sum twin (cfo_cfar_prefix; the literal window loop takes a second per sweep at window 500) - checked against the literal one on
+    the first sweep of every sequence, and bin for bin in tests/test_cfar_cpu.py"""
+    T, B = 60, 2
+    cfar = dict(window_size=window, nb_guard_cells=10, false_alarm_rate=pfa)
+    kw = dict(PRESET)
+    frames = _frames(T, B, "blocks", seed0=window)
+    for q in range(B):
+        rr, zz = float(np.float32(kw["range_res"])), float(kw["z_min"])
+        assert np.array_equal(oracle.cfar(frames[0, q], rr, zz, 2.5, **cfar), oracle.cfar(frames[0, q], rr, zz, 2.5, prefix=True, **cfar))
+    fus = [oracle.Fuser(oracle.default_params(**kw)) for _ in range(B)]
+    ctx = capi.Context(_hip_params(kw, **cfar), A, R)
+    ctx.tune(capi.TUNE_REPLAY_PERSISTENT_MAX, 256 if route == "replay_persistent" else 0)
+    odo = ctx.odometry(B)
+    recs = odo.replay_host(frames)
+    npts = []
+    for t in range(T):
+        for q in range(B):
+            exp, e, n = _expect(oracle, fus[q], frames[t, q], kw, cfar, prefix=True)
+            npts.append(n)
+            g, pose = _rec_tuple(recs[t, q]), recs[t, q]["pose"]
+            if t > 0:
+                assert g == e, (t, q, g, e)
+            assert np.all(np.abs(pose[:2] - exp[:2]) < 1e-4) and abs(pose[2] - exp[2]) < 1e-5, (t, q, pose, exp)
+    assert min(npts) > 300 and e[3] == kw["submap_scan_size"] and e[2] > 30, (min(npts), max(npts), e)
     odo.release()
     ctx.close()
 

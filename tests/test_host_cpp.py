@@ -54,6 +54,50 @@ def test_offline_odometry_matches_oracle(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("filt", ["kstrong", "CA-CFAR"])
+def test_offline_odometry_mulran_route_end_to_end(oracle, tmp_path, filt):
+    """--dataset mulran: the recording is range-major (rows = range bins); the mirror's CallbackOffline dispatches on par.dataset like the reference
+    (radar_driver.cpp:163-176 -> :74-90), rotates on the device (cv::rotate ROTATE_90_COUNTERCLOCKWISE, :84), filters, and the fuser runs with
+    radar_ccw = true (the MulRan sensor turns counter-clockwise: launch/mulran). Against the oracle fed np.rot90 of the same range-major images."""
+    exe = build_harness()
+    T, A, R = 10, 400, 3360
+    imgs = np.empty((T, A, R), dtype=np.uint8)
+    for t0, chunk in synth.drive_chunks(T, "blocks", 61, 62, A, R, RR, ccw=True):
+        imgs[t0:t0 + len(chunk)] = chunk
+    range_major = np.ascontiguousarray(np.rot90(imgs, k=-1, axes=(1, 2)))  # (T, R, A); rot90(., k=1) of a sweep gives the azimuth-major image back
+    assert range_major.shape == (T, R, A) and np.array_equal(np.rot90(range_major[3]), imgs[3])
+    f = tmp_path / "mulran.u8"
+    range_major.tofile(f)
+    cfar = filt == "CA-CFAR"
+    args = [exe, "--frames", str(f), "--dataset", "mulran", "--radar_ccw", "1", "--range-res", "0.0595238", "--res", "3.0", "--submap_scan_size", "4",
+            "--z-min", "20" if cfar else "60", "--weight_option", "4", "--filter-type", filt, "--est_directory", str(tmp_path)]
+    if cfar:
+        args += ["--k_strongest", "10", "--covar_scale", "40", "--regularization", "0.01"]  # the reference's cross-wiring: guard cells, window, false-alarm rate
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    est = np.loadtxt(tmp_path / "est_00.txt")
+    assert est.shape == (T, 12)
+    kw = dict(range_res=RR, z_min=20.0 if cfar else 60.0, res=3.0, submap_scan_size=4, weight_opt=4, weight_intensity=1, compensate=1, radar_ccw=1, cost=1, loss=1)
+    if cfar:
+        kw.update(regularization=0.01, covar_scale=40.0)  # (the same values reach the fuser's P2D terms; P2L does not read them)
+    else:
+        kw.update(regularization=1.0)
+    fu = oracle.Fuser(oracle.default_params(**kw))
+    moved = 0.0
+    for t in range(T):
+        rot = np.ascontiguousarray(np.rot90(range_major[t]))
+        if cfar:
+            exp = fu.process_cloud(oracle.cfar(rot, float(RR), 20.0, 2.5, window_size=40, nb_guard_cells=10, false_alarm_rate=0.01))
+        else:
+            exp = fu.process_polar(rot)
+        got = np.array([est[t, 3], est[t, 7], np.arctan2(est[t, 4], est[t, 0])])
+        assert np.all(np.abs(got[:2] - exp[:2]) < 1e-4 + 5e-7), (t, got, exp)
+        assert abs(got[2] - exp[2]) < 1e-5 + 2e-6
+        moved = max(moved, float(np.hypot(exp[0], exp[1])))
+    assert moved > 3.0  # the drive goes somewhere: the rotation put the azimuths in the right order
+
+
+@pytest.mark.gpu
 def test_offline_odometry_replay_mode_gives_the_per_sweep_trajectory(tmp_path):
     """--replay 1 (cfear_odometry_replay_host from C++: pieces of the recording in pinned memory, no host round trip per sweep)
     writes the trajectory the per-sweep route through the mirror classes writes."""

@@ -314,3 +314,28 @@ def test_fuser_golden(oracle, gold):
             assert [S.outer_iterations] + list(S.inner_iterations[:8]) == list(gold["iters_" + tag][t])
             assert len(f.last_cells()) == gold["ncells_" + tag][t]
         assert np.linalg.norm(gold["traj_" + tag][-1][:2] - gold["world_gt"][-1][:2]) < 0.3
+
+
+@pytest.mark.parametrize("loss,a", [(1, 0.1), (2, 0.2), (3, 0.1), (5, 0.5), (4, 1.0), (0, 0.1)])
+def test_loss_functions_closed_forms_and_derivatives(oracle, loss, a):
+    """cfo_loss_eval (what registration.cpp:78-97 builds, Ceres 2.0 forms) against the published closed forms, and rho' / rho'' against central differences
+    of rho / rho'. Tukey is the version-dependent one: rho = a^2/3 (1 - (1 - s/a^2)^3) here (Ceres 2.0); Ceres <= 1.14 has a^2/6 and rho' = (1 - s/a^2)^2 / 2
+    (DESIGN.md section 2; oracle/ref_recipe writes ceres::TukeyLoss::Evaluate itself into ref_golden.npz)."""
+    b = a * a
+    forms = {0: lambda s: s,
+             1: lambda s: s if s <= b else 2 * a * np.sqrt(s) - b,
+             2: lambda s: b * np.log1p(s / b),
+             3: lambda s: 2 * b * (np.sqrt(1 + s / b) - 1),
+             5: lambda s: b / 3 * (1 - (1 - s / b) ** 3) if s <= b else b / 3}
+    for s in [1e-4, 0.3 * b, 0.9 * b, 1.7 * b, 10 * b, 2.5]:
+        rho = oracle.loss_eval(loss, a, s)
+        if loss in forms:
+            assert abs(rho[0] - forms[loss](s)) <= 1e-13 * max(1.0, abs(rho[0]))
+        if abs(s - b) < 1e-3 * b:
+            continue
+        h = 1e-6 * s
+        lo, hi = oracle.loss_eval(loss, a, s - h), oracle.loss_eval(loss, a, s + h)
+        assert abs((hi[0] - lo[0]) / (2 * h) - rho[1]) <= 1e-6 * max(abs(rho[1]), 1e-3)
+        assert abs((hi[1] - lo[1]) / (2 * h) - rho[2]) <= 1e-5 * max(abs(rho[2]), 1e-3)
+    if loss == 5:
+        assert abs(oracle.loss_eval(5, a, 4 * b)[0] - b / 3) < 1e-15 and oracle.loss_eval(5, a, 4 * b)[1] == 0.0
