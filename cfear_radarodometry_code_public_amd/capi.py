@@ -71,7 +71,7 @@ EXPORTS = [
     "cfear_version", "cfear_default_params", "cfear_create", "cfear_destroy", "cfear_last_error",
     "cfear_set_params", "cfear_synchronize", "cfear_tune", "cfear_kstrongest_device", "cfear_kstrongest_host",
     "cfear_rotate_polar", "cfear_rotate_polar_device", "cfear_filter_polar", "cfear_filter_polar_device", "cfear_filter_cfar", "cfear_filter_cfar_device", "cfear_filter_cfar_batch_device", "cfear_cloud_upload", "cfear_cloud_size",
-    "cfear_cloud_download", "cfear_clouds_download", "cfear_cloud_release", "cfear_compensate", "cfear_scan_create",
+    "cfear_cloud_download", "cfear_clouds_download", "cfear_cloud_release", "cfear_compensate", "cfear_compensate_pair", "cfear_scan_create",
     "cfear_scan_from_cells", "cfear_scan_release", "cfear_scan_size", "cfear_scan_download_cells", "cfear_scan_closest",
     "cfear_register", "cfear_register_soft", "cfear_get_cost", "cfear_cov_by_sampling", "cfear_odometry_create", "cfear_odometry_destroy", "cfear_odometry_reset",
     "cfear_odometry_step_device", "cfear_odometry_step_cloud_device", "cfear_odometry_step_host", "cfear_odometry_poses",
@@ -123,6 +123,7 @@ def lib():
         "cfear_clouds_download": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "cfear_cloud_release": (None, [vp, vp]),
         "cfear_compensate": (C.c_int, [vp, vp, f64p, C.c_int]),
+        "cfear_compensate_pair": (C.c_int, [vp, vp, vp, f64p, C.c_int]),
         "cfear_scan_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
         "cfear_scan_from_cells": (C.c_int, [vp, vp, C.c_int, C.POINTER(vp)]),
         "cfear_scan_release": (None, [vp, vp]),

@@ -105,6 +105,7 @@ void cfear_destroy(cfear_ctx* ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_cfar_rows) (void)hipFree(ctx->d_cfar_rows);
   for (auto& b : ctx->pool) (void)hipFree(b.second);
+  for (auto& b : ctx->hpool) (void)hipHostFree(b.second);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_img) (void)hipHostFree(ctx->h_img);
   if (ctx->ev_img) (void)hipEventDestroy(ctx->ev_img);
@@ -186,6 +187,25 @@ void cfear_pool_free(cfear_ctx* ctx, void* p, size_t bytes) {
   }
   ctx->pool.emplace_back(bytes, p);
   ctx->pool_bytes += bytes;
+}
+void* cfear_hpool_alloc(cfear_ctx* ctx, size_t bytes, size_t* got) {
+  const size_t need = (bytes + 4095) & ~(size_t)4095;
+  if (need > ((size_t)1 << 20)) return nullptr;  // mirrors are for the sweep-sized clouds of the per-call route
+  for (size_t i = 0; i < ctx->hpool.size(); i++)
+    if (ctx->hpool[i].first >= need && ctx->hpool[i].first <= 2 * need + 65536) {
+      void* p = ctx->hpool[i].second; *got = ctx->hpool[i].first;
+      ctx->hpool[i] = ctx->hpool.back(); ctx->hpool.pop_back();
+      return p;
+    }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  *got = need;
+  return p;
+}
+void cfear_hpool_free(cfear_ctx* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (!ctx || ctx->hpool.size() >= 64) { (void)hipHostFree(p); return; }  // (stream-ordered reuse like the device pool: the next writer is a later kernel)
+  ctx->hpool.emplace_back(bytes, p);
 }
 int cfear_ensure_hstage(cfear_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->h_stage_bytes) return CFEAR_OK;

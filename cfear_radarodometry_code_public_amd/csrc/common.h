@@ -53,6 +53,7 @@ struct cfear_ctx {
   // synchronising release).
   std::vector<std::pair<size_t, void*>> pool;
   size_t pool_bytes = 0;
+  std::vector<std::pair<size_t, void*>> hpool;  // ... and the pinned host blocks of the clouds' mirrors
   // pinned host staging of the per-call entry points: downloads that complete with ONE synchronisation, registration arguments in one copy
   unsigned char* h_stage = nullptr;
   size_t h_stage_bytes = 0;
@@ -87,6 +88,14 @@ struct cfear_cloud {  // pcl::PointCloud<pcl::PointXYZI> on the device: one bloc
   int* d_n = nullptr;      // point count (= block)
   void* block = nullptr;
   size_t bytes = 0;
+  // Host mirror (round 6): a pinned, device-visible copy of the block that the kernels producing or changing the cloud on the per-call route write as
+  // well - cfear_clouds_download then is a wait and a memcpy, no copy command (kernel + D2H + wait 21 us, kernel writing host memory + wait 13 us:
+  // profiles/r06_sync_latency.txt; the per-call route downloads four clouds a sweep). mirror_valid: the mirror holds what the device block holds.
+  unsigned char* h_block = nullptr;
+  size_t h_bytes = 0;
+  bool mirror_valid = false;
+  int* h_n() const { return reinterpret_cast<int*>(h_block); }
+  float* h_xyi() const { return reinterpret_cast<float*>(h_block + 16); }
 };
 
 // cabi.hip
@@ -94,6 +103,8 @@ extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_staging(cfear_
 extern "C" __attribute__((visibility("hidden"))) int cfear_pool_alloc(cfear_ctx* ctx, size_t bytes, void** out, size_t* got);
 extern "C" __attribute__((visibility("hidden"))) void cfear_pool_free(cfear_ctx* ctx, void* p, size_t bytes);
 extern "C" __attribute__((visibility("hidden"))) int cfear_ensure_hstage(cfear_ctx* ctx, size_t bytes);
+extern "C" __attribute__((visibility("hidden"))) void* cfear_hpool_alloc(cfear_ctx* ctx, size_t bytes, size_t* got);  // null: no mirror (not an error)
+extern "C" __attribute__((visibility("hidden"))) void cfear_hpool_free(cfear_ctx* ctx, void* p, size_t bytes);
 extern "C" __attribute__((visibility("hidden"))) int cfear_upload_image(cfear_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 // pipeline.hip
 extern "C" __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int cap, cfear_cloud** out);

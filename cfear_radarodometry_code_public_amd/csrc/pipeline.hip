@@ -22,15 +22,33 @@
 namespace {
 
 // ---- per-call kernels -------------------------------------------------------------------------
+// one workgroup per cloud: block 0 the filtered cloud, block 1 (if launched) the peaks cloud (radar_driver.cpp:59-60); each also writes its
+// cloud's host mirror (cfear_cloud::h_block) when it has one
+struct CloudOut { float* xyi; int* d_n; float* h_xyi; int* h_n; int cap; };
+__device__ __forceinline__ void cloud_mirror_block(const float* xyi, int n, int cap, float* h_xyi, int* h_n) {
+  if (!h_xyi) return;
+  __syncthreads();  // the block's own writes of xyi
+  const int m = 3 * (n < cap ? n : cap);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) h_xyi[i] = xyi[i];
+  if (threadIdx.x == 0) *h_n = n;
+}
 __global__ __launch_bounds__(BLOCK_F) void cloud_kernel(const uint32_t* slots, int A, int k, const double* trig, float rr,
-                                                        float md, int peaks, float* xyi, int cap, int* d_n) {
+                                                        float md, CloudOut o0, CloudOut o1) {
   __shared__ int red_i[64];
-  const int n = cloud_build_block(slots, A, k, trig, rr, md, peaks, xyi, cap, red_i);
-  if (threadIdx.x == 0) *d_n = n;
+  const int peaks = blockIdx.x;
+  const CloudOut o = peaks ? o1 : o0;
+  const int n = cloud_build_block(slots, A, k, trig, rr, md, peaks, o.xyi, o.cap, red_i);
+  if (threadIdx.x == 0) *o.d_n = n;
+  cloud_mirror_block(o.xyi, n, o.cap, o.h_xyi, o.h_n);
 }
 
-__global__ __launch_bounds__(BLOCK_F) void compensate_kernel(float* xyi, const int* d_n, double m0, double m1, double m2, int ccw) {
-  compensate_block(xyi, *d_n, m0, m1, m2, ccw);
+// Compensate (utils.cpp:96-113) of one cloud or of a sweep's two (the fuser compensates cloud and cloud_peaks by the same motion,
+// odometrykeyframefuser.cpp:148-149): one workgroup each
+__global__ __launch_bounds__(BLOCK_F) void compensate_kernel(CloudOut o0, CloudOut o1, double m0, double m1, double m2, int ccw) {
+  const CloudOut o = blockIdx.x ? o1 : o0;
+  const int n = *o.d_n;
+  compensate_block(o.xyi, n, m0, m1, m2, ccw);
+  cloud_mirror_block(o.xyi, n, o.cap, o.h_xyi, o.h_n);
 }
 
 __global__ __launch_bounds__(BLOCK_F) void features_kernel(ScanDev* S, const float* src_xyi, const int* d_n, FeatureParams P,
@@ -536,6 +554,7 @@ __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int 
   if (rc != CFEAR_OK) { delete c; return rc; }
   c->d_n = static_cast<int*>(c->block);
   c->d_xyi = reinterpret_cast<float*>(static_cast<unsigned char*>(c->block) + 16);
+  c->h_block = static_cast<unsigned char*>(cfear_hpool_alloc(ctx, 16 + sizeof(float) * 3 * (size_t)c->cap, &c->h_bytes));
   *out = c;
   return CFEAR_OK;
 }
@@ -543,7 +562,13 @@ __attribute__((visibility("hidden"))) int cfear_cloud_alloc(cfear_ctx* ctx, int 
 void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* c) {
   if (!c) return;
   cfear_pool_free(ctx, c->block, c->bytes);  // (stream-ordered reuse; no synchronisation, no hipFree on the per-sweep path)
+  cfear_hpool_free(ctx, c->h_block, c->h_bytes);
   delete c;
+}
+static CloudOut cloud_out(cfear_cloud* c) {
+  CloudOut o; o.xyi = c->d_xyi; o.d_n = c->d_n; o.cap = c->cap;
+  o.h_xyi = c->h_block ? c->h_xyi() : nullptr; o.h_n = c->h_block ? c->h_n() : nullptr;
+  return o;
 }
 
 int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_cloud** cloud, cfear_cloud** cloud_peaks) {
@@ -556,14 +581,15 @@ int cfear_filter_polar_device(cfear_ctx* ctx, const uint8_t* d_polar, cfear_clou
   rc = cfear_launch_kstrongest(ctx, d_polar, 1, ctx->d_slots, ctx->stream);  // radar_driver.cpp:58
   if (rc != CFEAR_OK) return rc;
   const int A = ctx->A, k = ctx->par.k_strongest, cap = A * k;
-  for (int peaks = 0; peaks < (cloud_peaks ? 2 : 1); peaks++) {  // radar_driver.cpp:59-60
-    cfear_cloud* c = nullptr;
-    rc = cfear_cloud_alloc(ctx, cap, &c);
-    if (rc != CFEAR_OK) return rc;
-    hipLaunchKernelGGL(cloud_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
-                       ctx->par.range_res, ctx->par.min_distance, peaks, c->d_xyi, cap, c->d_n);
-    if (peaks == 0) *cloud = c; else *cloud_peaks = c;
-  }
+  cfear_cloud *c0 = nullptr, *c1 = nullptr;  // radar_driver.cpp:59-60
+  rc = cfear_cloud_alloc(ctx, cap, &c0);
+  if (rc != CFEAR_OK) return rc;
+  if (cloud_peaks) { rc = cfear_cloud_alloc(ctx, cap, &c1); if (rc != CFEAR_OK) { cfear_cloud_release(ctx, c0); return rc; } }
+  hipLaunchKernelGGL(cloud_kernel, dim3(c1 ? 2 : 1), dim3(BLOCK_F), 0, ctx->stream, ctx->d_slots, A, k, ctx->d_trig,
+                     ctx->par.range_res, ctx->par.min_distance, cloud_out(c0), cloud_out(c1 ? c1 : c0));
+  c0->mirror_valid = c0->h_block != nullptr;
+  *cloud = c0;
+  if (c1) { c1->mirror_valid = c1->h_block != nullptr; *cloud_peaks = c1; }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -589,6 +615,7 @@ int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cl
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_n, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { cfear_cloud_release(ctx, c); return cfear_fail(ctx, CFEAR_ERR_HIP, "cloud_upload", e); }
+  if (c->h_block) { *c->h_n() = n; if (n > 0) memcpy(c->h_xyi(), xyi, sizeof(float) * 3 * (size_t)n); c->mirror_valid = true; }
   *cloud = c;
   return CFEAR_OK;
 }
@@ -596,6 +623,7 @@ int cfear_cloud_upload(cfear_ctx* ctx, const float* xyi, int n, cfear_cloud** cl
 int cfear_cloud_size(cfear_ctx* ctx, const cfear_cloud* c, int* n) {
   if (!ctx || !c || !n) return cfear_fail(ctx, CFEAR_ERR_INVALID, "cloud_size: bad argument");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (c->mirror_valid) { CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); *n = *c->h_n(); return CFEAR_OK; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(n, c->d_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
@@ -611,6 +639,19 @@ int cfear_clouds_download(cfear_ctx* ctx, const cfear_cloud* const* clouds, int 
     if (!clouds[i]) return cfear_fail(ctx, CFEAR_ERR_INVALID, "clouds_download: null cloud");
     const int want = (xyi && xyi[i] && capacity) ? (capacity[i] < clouds[i]->cap ? capacity[i] : clouds[i]->cap) : 0;
     off[i + 1] = off[i] + ((16 + sizeof(float) * 3 * (size_t)(want > 0 ? want : 0) + 63) & ~(size_t)63);
+  }
+  bool all_mirrored = true;
+  for (int i = 0; i < m; i++) all_mirrored = all_mirrored && clouds[i]->mirror_valid;
+  if (all_mirrored) {  // the kernels wrote the host copies: wait for them, hand the points on
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < m; i++) {
+      const int cnt = *clouds[i]->h_n();
+      if (n) n[i] = cnt;
+      const int want = (xyi && xyi[i] && capacity) ? (capacity[i] < clouds[i]->cap ? capacity[i] : clouds[i]->cap) : 0;
+      const int take = cnt < want ? cnt : want;
+      if (take > 0) memcpy(xyi[i], clouds[i]->h_xyi(), sizeof(float) * 3 * (size_t)take);
+    }
+    return CFEAR_OK;
   }
   int rc = cfear_ensure_hstage(ctx, off[m]);
   if (rc != CFEAR_OK) return rc;
@@ -639,7 +680,18 @@ int cfear_compensate(cfear_ctx* ctx, cfear_cloud* c, const double motion_xyt[3],
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // Affine3dToVectorXYeZ of the motion (utils.cpp:109-112): theta passes through atan2(sin, cos)
   const double th = atan2(sin(motion_xyt[2]), cos(motion_xyt[2]));
-  hipLaunchKernelGGL(compensate_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, c->d_xyi, c->d_n, motion_xyt[0], motion_xyt[1], th, ccw);
+  hipLaunchKernelGGL(compensate_kernel, dim3(1), dim3(BLOCK_F), 0, ctx->stream, cloud_out(c), cloud_out(c), motion_xyt[0], motion_xyt[1], th, ccw);
+  c->mirror_valid = c->h_block != nullptr;
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+int cfear_compensate_pair(cfear_ctx* ctx, cfear_cloud* c0, cfear_cloud* c1, const double motion_xyt[3], int ccw) {
+  if (!ctx || !c0 || !c1 || c0 == c1 || !motion_xyt) return cfear_fail(ctx, CFEAR_ERR_INVALID, "compensate_pair: bad argument");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const double th = atan2(sin(motion_xyt[2]), cos(motion_xyt[2]));
+  hipLaunchKernelGGL(compensate_kernel, dim3(2), dim3(BLOCK_F), 0, ctx->stream, cloud_out(c0), cloud_out(c1), motion_xyt[0], motion_xyt[1], th, ccw);
+  c0->mirror_valid = c0->h_block != nullptr; c1->mirror_valid = c1->h_block != nullptr;
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }

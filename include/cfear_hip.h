@@ -193,6 +193,8 @@ int cfear_clouds_download(cfear_ctx* ctx, const cfear_cloud* const* clouds, int 
 void cfear_cloud_release(cfear_ctx* ctx, cfear_cloud* cloud);
 /* Compensate(cloud, Tmotion, ccw) (utils.h:49, utils.cpp:96-113); motion = (tx, ty, theta). In place. */
 int cfear_compensate(cfear_ctx* ctx, cfear_cloud* cloud, const double motion_xyt[3], int ccw);
+/* ... of the two clouds of one sweep by the same motion in one launch (odometrykeyframefuser.cpp:148-149 compensates cloud and cloud_peaks) */
+int cfear_compensate_pair(cfear_ctx* ctx, cfear_cloud* cloud, cfear_cloud* cloud_peaks, const double motion_xyt[3], int ccw);
 
 /* ---- Stage 2: MapPointNormal (pointnormal.h:110-243) ------------------------------------------ */
 typedef struct cfear_scan cfear_scan; /* MapNormalPtr: cells + search structure, device resident */

@@ -358,16 +358,16 @@ inline void CompensateOn(const DevicePtr& fallback, PointCloudXYZI& cloud, const
     t = &tw.put(&cloud, cfear_cloud_size(cloud), 0, d);
   }
   const DevicePtr dev = t->dev->dev;
-  Compensate(dev, *t->dev, Tmotion, ccw);
   CloudTwin* sib = t->sibling ? tw.by_address(t->sibling) : nullptr;
   if (sib && (sib->ahead || sib->dev->dev != dev || sib->n == 0)) sib = nullptr;
   std::vector<int> n;
   if (sib) {
-    Compensate(dev, *sib->dev, Tmotion, ccw);
+    dev->check(cfear_compensate_pair(dev->ctx(), t->dev->h, sib->dev->h, mot, ccw ? 1 : 0), "cfear_compensate_pair");  // one launch for the sweep's two clouds
     DownloadInto(dev, {t->dev->h, sib->dev->h}, {&xyi, &sib->ahead_xyi}, n);
     sib->ahead = true; sib->ahead_n = (size_t)n[1]; sib->ahead_ccw = ccw;
     for (int i = 0; i < 3; i++) sib->ahead_mot[i] = mot[i];
   } else {
+    Compensate(dev, *t->dev, Tmotion, ccw);
     DownloadInto(dev, {t->dev->h}, {&xyi}, n);
   }
   cfear_cloud_from_xyi(cloud, xyi.data(), (size_t)n[0]);
