@@ -56,11 +56,20 @@ def gt_pose(t, step=1.0, yaw_rate=0.02, radius=None):
     return np.array([r * np.sin(psi), -r * np.cos(psi), psi])
 
 
+def _patch_hash(seg, patch, salt):
+    """deterministic uniform [0, 1) per (segment, patch along it): the world's reflectivity texture"""
+    x = np.sin(seg * 12.9898 + patch * 78.233 + salt * 37.719) * 43758.5453
+    return x - np.floor(x)
+
+
 def render_scan(segs, pose, motion, A, R, range_res, rng, ccw=False, z_min=60, distort=True, hits=2, p_extra=0.5, sigma=2.0,
-                amp_extra=0.45):
+                amp_extra=0.45, texture=None):
     """One sweep of a sensor at `pose` = (x, y, psi) (mid-sweep) that moves by `motion` = (mx, my, mth) per sweep in its own
     frame, over the wall segments `segs` [S, 2, 2]. The first `hits` intersections of every ray give Gaussian range blobs (the
-    first always, the later ones with probability p_extra each and amp_extra of the amplitude). Returns uint8 [A, R]."""
+    first always, the later ones with probability p_extra each and amp_extra of the amplitude). Returns uint8 [A, R].
+    texture = (patch length in m, fraction of strong patches, jitter): the echo's amplitude is a property of the place on the surface that was hit -
+    patches along every segment are either strong scatterers (amplitude 140-220: window frames, pillars, parked metal) or weak ones (45-65: plain
+    wall, mostly below z_min) - instead of a random number per azimuth and sweep; what survives the filter then sits at world-fixed spots."""
     res = float(np.float32(range_res))
     x0, y0, psi = pose
     a = np.arange(A)
@@ -85,9 +94,24 @@ def render_scan(segs, pose, motion, A, R, range_res, rng, ccw=False, z_min=60, d
         uu = (wx * dy[:, None] - wy * dx[:, None]) / den
     hit = (np.abs(den) > 1e-12) & (tt > 0.5) & (uu >= 0) & (uu <= 1)
     tt = np.where(hit, tt, np.inf)
-    order = np.sort(tt, axis=1)[:, :hits]
-    if order.shape[1] < hits:
-        order = np.concatenate([order, np.full((A, hits - order.shape[1]), np.inf)], axis=1)
+    if texture is not None:
+        nh = min(hits, tt.shape[1])
+        idx = np.argpartition(tt, nh - 1, axis=1)[:, :nh] if nh < tt.shape[1] else np.tile(np.arange(tt.shape[1]), (A, 1))
+        sub = np.take_along_axis(tt, idx, axis=1)
+        o2 = np.argsort(sub, axis=1)
+        idx = np.take_along_axis(idx, o2, axis=1)
+        order = np.take_along_axis(sub, o2, axis=1)
+        along = np.take_along_axis(np.where(hit, uu, 0.0), idx, axis=1) * np.hypot(e[:, 0], e[:, 1])[idx]
+        patch = np.floor(along / texture[0])
+        h1, h2 = _patch_hash(idx.astype(np.float64), patch, 1.0), _patch_hash(idx.astype(np.float64), patch, 2.0)
+        tex_amp = np.where(h1 < texture[1], 140.0 + 80.0 * h2, 45.0 + 20.0 * h2)
+        if order.shape[1] < hits:
+            order = np.concatenate([order, np.full((A, hits - order.shape[1]), np.inf)], axis=1)
+            tex_amp = np.concatenate([tex_amp, np.zeros((A, hits - tex_amp.shape[1]))], axis=1)
+    else:
+        order = np.sort(tt, axis=1)[:, :hits]
+        if order.shape[1] < hits:
+            order = np.concatenate([order, np.full((A, hits - order.shape[1]), np.inf)], axis=1)
     img = np.clip(rng.normal(25.0, 8.0, size=(A, R)), 0, 255)
     # 0.1 % salt speckle >= z_min
     nsp = int(0.001 * A * R)
@@ -102,6 +126,8 @@ def render_scan(segs, pose, motion, A, R, range_res, rng, ccw=False, z_min=60, d
             ok &= rng.random(A) < p_extra
         b0 = (rr - res / 2) / res
         amp = power * (1.0 if hno == 0 else amp_extra)
+        if texture is not None:
+            amp = tex_amp[:, hno] * (1.0 + texture[2] * (power - 145.0) / 55.0) * (1.0 if hno == 0 else amp_extra)
         for i in np.nonzero(ok)[0]:
             lo, hi = int(max(0, b0[i] - half)), int(min(R, b0[i] + half + 1))
             if lo >= hi:
@@ -258,7 +284,7 @@ def _box(ctr, hw, hh, ang):
     return [[cs[i], cs[(i + 1) % 4]] for i in range(4)]
 
 
-DRIVE_KINDS = ("blocks", "canyon", "field", "thicket")
+DRIVE_KINDS = ("blocks", "canyon", "field", "thicket", "street")
 
 
 class DriveWorld:
@@ -281,9 +307,13 @@ class DriveWorld:
             self.render = dict(hits=2, p_extra=0.5, sigma=2.0)
             n_obj, size, clear = 46, (2.0, 7.5), 6.0
             lim = (W - 8, H - 8)
-        elif kind in ("canyon", "thicket"):
+        elif kind in ("canyon", "thicket", "street"):
             self.track = Track(60.0, 40.0, (10.0, 12.0, 10.0, 16.0))
             self.render = dict(hits=5, p_extra=0.85, sigma=1.0, amp_extra=0.7)
+            if kind == "street":  # the canyon with a reflectivity that belongs to the surfaces (round 6): what the reference's P2P preset needs
+                # (patches of 1.5 m, a fifth of them strong: of the variants tried - profiles/r06_world_realism.json - the one on which P2P tracks best;
+                # denser strong patches bring the grid-locking of the plain canyon back)
+                self.render = dict(hits=5, p_extra=0.85, sigma=1.0, amp_extra=0.85, texture=(1.5, 0.2, 0.05))
             n_obj, size, clear = 320, (1.5, 6.0), 7.0
             lim = (150.0, 130.0)
             if kind == "thicket":  # the canyon's streets in a forest of small objects, every echo as strong as the first
@@ -301,7 +331,7 @@ class DriveWorld:
             n_obj, size, clear = 30, (0.6, 2.5), 5.0
             lim = (W - 10, H - 10)
         path = self.track.polyline(1.0)
-        if kind in ("canyon", "thicket"):  # facades 9-12 m left and right of the centre line, in pieces of 6-25 m with gaps and set-backs
+        if kind in ("canyon", "thicket", "street"):  # facades 9-12 m left and right of the centre line, in pieces of 6-25 m with gaps and set-backs
             for side in (-1.0, 1.0):
                 s = 0.0
                 while s < self.track.length:
