@@ -48,6 +48,10 @@ def test_drive_replay_matches_oracle_at_every_sweep(oracle, kind, sweeps, min_ce
     # array's capacity stays in LDS and the rest is evaluated from memory
     ("p2d_canyon", "canyon", 400, dict(cost=2, regularization=0.1, covar_scale=1.0)),
     ("p2p_canyon", "canyon", 400, dict(cost=0)),
+    # round 6: the street world - reflectivity fixed to the surfaces, the world on which the reference's P2P presets behave like odometry
+    # (profiles/r06_world_realism.json) - with CFEAR-3 as shipped, and with its ten-keyframe Cauchy variant (params/baseline_p2d/oxford_cfear-3-s10)
+    ("cfear3_k40_p2p_street", "street", 500, dict(k_strongest=40, cost=0, submap_scan_size=4, res=3.0)),
+    ("cfear3_s10_street", "street", 300, dict(k_strongest=40, cost=0, loss=2, loss_limit=0.1, submap_scan_size=10, res=3.0)),
 ])
 def test_drive_replay_of_the_other_presets(oracle, name, kind, sweeps, params):
     """The reference's other presets on driving-like motion (stops, crawling, ramps, corners, reversing): the P2D cost of
@@ -61,3 +65,5 @@ def test_drive_replay_of_the_other_presets(oracle, name, kind, sweeps, params):
     assert d["segments"] == c["segments"]
     if d["segments"]:
         assert abs(d["translation_percent"] - c["translation_percent"]) < 1e-6
+    if name == "cfear3_k40_p2p_street" and T >= 500:  # ... and it does track there (the plain canyon: > 10 %)
+        assert c["translation_percent"] < 3.0, c
