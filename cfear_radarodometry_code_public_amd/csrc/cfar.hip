@@ -41,6 +41,8 @@ struct CfarParams {
   double range_res, scaling;
   // owner-layout detector (cfar_detect_owner_kernel): prefix sums are kept as P << sh, a bin is worth a closer look when (S << sh) - I^2 * kopen <= 0
   int sh, kopen;
+  int cr[4], cq[4]; // owner-layout detector, set per launch shape: window bound c of bin TB t + e is row e + cr[c], column t + cq[c] (off = TB cq + cr)
+  int rmin, rmax;   // ... rows rmin .. TB + rmax - 1 exist (rmin <= 0 <= rmax)
   int stop;         // profiling (CFEAR_CFAR_STOP = n): a row's trip ends after phase n (1 prefix, 2 integer test); 0 = the product
 };
 
@@ -342,39 +344,37 @@ __device__ __forceinline__ void cfar_load_segment(__attribute__((address_space(1
 
 template <int TB, int NW, int RS /* columns of the transposed prefix array: a multiple of 64, so that the reads of two rows pair up as ds_read2st64_b32 off one base */,
           bool FULL /* the row is a whole number of threads' segments: branch-free loads, several rows in flight */>
-__global__ __launch_bounds__(64 * NW) void cfar_detect_owner_kernel(const uint8_t* __restrict__ polar, CfarParams P, int rows, int padl, int* __restrict__ seg_count,
+__global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 1) void cfar_detect_owner_kernel(const uint8_t* __restrict__ polar, CfarParams P, int rows, int padl, int* __restrict__ seg_count,
                                                                     uint32_t* __restrict__ recs, uint32_t* __restrict__ hmask) {
   constexpr int NT = 64 * NW, ND = TB / 4;
   static_assert(TB % 4 == 0 && TB <= 32 && RS % 64 == 0, "bins per thread / row stride");
   extern __shared__ __attribute__((aligned(16))) uint32_t cfar_lds[];
   typedef __attribute__((address_space(3))) uint32_t l_u32;
   typedef __attribute__((address_space(1))) const uint32_t g_cu32;
-  l_u32* const lp = (l_u32*)cfar_lds;                 // [2 TB][RS] scaled prefix sums; thread t's column is padl + t
-  l_u32* const lcand = lp + 2 * TB * RS;              // [NW][64] a wave's candidate bins (what the integer test left)
+  // [nrows][RS] scaled prefix sums: row rho of column padl + t holds P'[TB t + rho], rho = rmin .. TB + rmax - 1 - the thread's own TB values and,
+  // either side, copies of its neighbours' first rmax / last -rmin ones, so that bin TB t + e + off is (row e + r, column t + q) for every e with ONE
+  // (r, q) per window bound: off = TB q + r with r taken in (-TB, TB) such that the rows all four bounds need are as few as possible (the host's choice:
+  // for guard 10, window 40 and 28 bins per thread r = 6, -10, 10, -6: 48 rows instead of the 56 of r in [0, TB))
+  const int nrows = TB + P.rmax - P.rmin;
+  l_u32* const lp = (l_u32*)cfar_lds;                 // physical row 0 = row rmin
+  l_u32* const lp0 = lp - P.rmin * RS;                // row 0
+  l_u32* const lcand = lp + nrows * RS;               // [NW][64] a wave's candidate bins (what the integer test left)
   l_u32* const lstage = lcand + NW * 64;              // [NW][CFAR_SEG_CAP] a wave's records of the row, until the next trip writes them out
-  int* const red_i = (int*)(cfar_lds + 2 * TB * RS + NW * 64 + NW * CFAR_SEG_CAP);  // [16] scan scratch
+  int* const red_i = (int*)(lstage + NW * CFAR_SEG_CAP);  // [16] scan scratch
   const int R = P.R, g = P.guard, w = P.window, sh = P.sh, ndw = R >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // the four window bounds of bin TB t + e: rows e + r, column t + q of the transposed array (off = TB q + r, 0 <= r < TB)
-  l_u32 *pA, *pB, *pC, *pD;
-  {
-    const int off[4] = {-g - w, -g, g, g + w};
-    l_u32* pp[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int r = ((off[c] % TB) + TB) % TB, q = (off[c] - r) / TB;
-      pp[c] = lp + (r * RS + padl + tid + q);
-    }
-    pA = pp[0]; pB = pp[1]; pC = pp[2]; pD = pp[3];
-  }
-  l_u32* const pown = lp + (padl + tid);  // P'[TB t + e] = pown[e RS]
+  l_u32* const pA = lp0 + (P.cr[0] * RS + padl + tid + P.cq[0]);
+  l_u32* const pB = lp0 + (P.cr[1] * RS + padl + tid + P.cq[1]);
+  l_u32* const pC = lp0 + (P.cr[2] * RS + padl + tid + P.cq[2]);
+  l_u32* const pD = lp0 + (P.cr[3] * RS + padl + tid + P.cq[3]);
+  l_u32* const pown = lp0 + (padl + tid);  // P'[TB t + e] = pown[e RS]
   // Columns: thread t's at padl + t. Left of thread 0 the array reads 0 (bins < 0: written once, here), right of the thread that holds bin R it
   // reads the row total (bins >= R): a window a row end clips is then simply the difference of two entries, like everywhere else. The threads past
   // the row's end write those columns as a matter of course (their bytes are zeros); where the workgroup has no such thread a loop fills them in.
   const int tR = R / TB, padr = (g + w + TB - 1) / TB + 1;
   const int last_col_thread = min(tR + padr, RS - 1 - padl);
   const bool writes = tid <= last_col_thread;
-  for (int k = tid; k < 2 * TB * padl; k += NT) lp[(k / padl) * RS + k % padl] = 0u;
+  for (int k = tid; k < nrows * (padl + 1); k += NT) lp[(k / (padl + 1)) * RS + k % (padl + 1)] = 0u;  // (column padl: the rows below 0 are thread -1's; thread 0 writes the others every row)
   // this thread's bins inside the range gate (cfar.cpp:45)
   uint32_t vmask;
   {
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(64 * NW) void cfar_detect_owner_kernel(const uint8_
   auto decide = [&](int bin, int* iv2_out) -> bool {
     const int t = bin / TB, e = bin - t * TB, dt = t - tid;
     const uint32_t ts = (pB[e * RS + dt] - pA[e * RS + dt]) >> sh, fs = (pD[e * RS + dt] - pC[e * RS + dt]) >> sh;
-    const int iv2 = (int)((pown[(e + 1) * RS + dt] - pown[e * RS + dt]) >> sh);
+    const uint32_t p1 = e + 1 < TB ? pown[(e + 1) * RS + dt] : pown[dt + 1];  // P'[bin + 1]: the next row, or the next thread's first
+    const int iv2 = (int)((p1 - pown[e * RS + dt]) >> sh);
     *iv2_out = iv2;
     const int t1 = bin - g, f0 = bin + g;
     const int tn = t1 > 0 ? min(t1, w) : 0, fn = f0 < R ? min(R - f0, w) : 0;  // cfar.cpp:48-53
@@ -462,19 +463,36 @@ __global__ __launch_bounds__(64 * NW) void cfar_detect_owner_kernel(const uint8_
     if (P.stop == 12) { prev_total = (nq[0] ^ nq[TB - 1] ^ (int)qs[3] ^ (int)o) == 0x12345 ? 0 : -1; __syncthreads(); return; }
     // (the barrier of the scan also ends the previous row's reads of everything written below)
     if (writes) {
+      uint32_t (&pv)[TB] = qs;  // the squares' registers become the prefix values
 #pragma unroll
-      for (int e = 0; e < TB; e++) {
-        pown[e * RS] = o;
-        pown[(e + TB) * RS - 1] = o;  // ... one column to the left in the second copy
-        o += qs[e];
+      for (int e = 0; e < TB; e++) { const uint32_t t = qs[e]; pv[e] = o; pown[e * RS] = o; o += t; }
+      // the copies for the neighbours: the first rmax values one column to the left in the rows above TB, the last -rmin one column to the right in
+      // the rows below 0 (one jump into a run of stores each: the counts are the launch's, not the compiler's)
+#define CFAR_DUP_HI(E) case (E) + 1: if constexpr ((E) < TB) pown[((E) + TB) * RS - 1] = pv[(E) < TB ? (E) : 0]; [[fallthrough]];
+      switch (P.rmax) {
+        CFAR_DUP_HI(31) CFAR_DUP_HI(30) CFAR_DUP_HI(29) CFAR_DUP_HI(28) CFAR_DUP_HI(27) CFAR_DUP_HI(26) CFAR_DUP_HI(25) CFAR_DUP_HI(24)
+        CFAR_DUP_HI(23) CFAR_DUP_HI(22) CFAR_DUP_HI(21) CFAR_DUP_HI(20) CFAR_DUP_HI(19) CFAR_DUP_HI(18) CFAR_DUP_HI(17) CFAR_DUP_HI(16)
+        CFAR_DUP_HI(15) CFAR_DUP_HI(14) CFAR_DUP_HI(13) CFAR_DUP_HI(12) CFAR_DUP_HI(11) CFAR_DUP_HI(10) CFAR_DUP_HI(9) CFAR_DUP_HI(8)
+        CFAR_DUP_HI(7) CFAR_DUP_HI(6) CFAR_DUP_HI(5) CFAR_DUP_HI(4) CFAR_DUP_HI(3) CFAR_DUP_HI(2) CFAR_DUP_HI(1) CFAR_DUP_HI(0)
+        default: break;
       }
+#undef CFAR_DUP_HI
+#define CFAR_DUP_LO(K) case (K): if constexpr ((K) <= TB) pown[-(K) * RS + 1] = pv[(K) <= TB ? TB - (K) : 0]; [[fallthrough]];
+      switch (-P.rmin) {
+        CFAR_DUP_LO(32) CFAR_DUP_LO(31) CFAR_DUP_LO(30) CFAR_DUP_LO(29) CFAR_DUP_LO(28) CFAR_DUP_LO(27) CFAR_DUP_LO(26) CFAR_DUP_LO(25)
+        CFAR_DUP_LO(24) CFAR_DUP_LO(23) CFAR_DUP_LO(22) CFAR_DUP_LO(21) CFAR_DUP_LO(20) CFAR_DUP_LO(19) CFAR_DUP_LO(18) CFAR_DUP_LO(17)
+        CFAR_DUP_LO(16) CFAR_DUP_LO(15) CFAR_DUP_LO(14) CFAR_DUP_LO(13) CFAR_DUP_LO(12) CFAR_DUP_LO(11) CFAR_DUP_LO(10) CFAR_DUP_LO(9)
+        CFAR_DUP_LO(8) CFAR_DUP_LO(7) CFAR_DUP_LO(6) CFAR_DUP_LO(5) CFAR_DUP_LO(4) CFAR_DUP_LO(3) CFAR_DUP_LO(2) CFAR_DUP_LO(1)
+        default: break;
+      }
+#undef CFAR_DUP_LO
     }
-    if (last_col_thread >= NT - 1) {  // (uniform; a row that nearly fills the workgroup) columns right of the last thread's: the row total
-      const int c0 = padl + NT - 1, ncol = RS - c0;  // the second copy of the last thread's column, then whole columns
+    if (last_col_thread >= NT - 1) {  // (uniform; a row that nearly fills the workgroup) what no thread is there to write, right of the last thread's column: the row total
+      const int c0 = padl + NT - 1, ncol = RS - 1 - c0;  // whole columns c0 + 1 .., and the rows above TB of column c0 itself (thread NT's first values)
       const uint32_t tot_s = (uint32_t)tot << sh;
-      for (int k = tid; k < TB + 2 * TB * (ncol - 1); k += NT) {
-        if (k < TB) lp[(TB + k) * RS + c0] = tot_s;
-        else lp[((k - TB) % (2 * TB)) * RS + c0 + 1 + (k - TB) / (2 * TB)] = tot_s;
+      for (int k = tid; k < nrows * ncol + P.rmax; k += NT) {
+        if (k < nrows * ncol) lp[(k / ncol) * RS + c0 + 1 + k % ncol] = tot_s;
+        else lp0[(TB + k - nrows * ncol) * RS + c0] = tot_s;
       }
     }
 #pragma unroll
@@ -486,7 +504,7 @@ __global__ __launch_bounds__(64 * NW) void cfar_detect_owner_kernel(const uint8_
     // every four reads - fourteen LDS round trips a row with nothing else to do at two waves per SIMD)
     uint32_t h = 0;
     {
-      constexpr int GB = TB % 7 == 0 ? 7 : (TB % 5 == 0 ? 5 : 4), NG = TB / GB;
+      constexpr int GB = 4, NG = TB / GB;  // (two groups = sixteen two-row reads: what the LDS counter can have outstanding)
       uint32_t va[2][GB], vb[2][GB], vc[2][GB], vd[2][GB];
 #pragma unroll
       for (int k = 0; k < GB; k++) {
@@ -792,11 +810,30 @@ int cfar_device_cus(int device) {
   if (!cus[device]) { int n = 0; cus[device] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ? n : 256; }
   return cus[device];
 }
-constexpr size_t cfar_owner_lds_bytes(int TB, int NW, int RS) { return sizeof(uint32_t) * (2 * (size_t)TB * RS + 64 * NW + (size_t)NW * CFAR_SEG_CAP + 16); }
+size_t cfar_owner_lds_bytes(int nrows, int NW, int RS) { return sizeof(uint32_t) * ((size_t)nrows * RS + 64 * NW + (size_t)NW * CFAR_SEG_CAP + 16); }
+// (row, column) offsets of the four window bounds for TB bins per thread: r in (-TB, TB), the combination with the fewest rows
+void cfar_owner_offsets(CfarParams* P, int TB) {
+  const int off[4] = {-P->guard - P->window, -P->guard, P->guard, P->guard + P->window};
+  int best = 1 << 30;
+  for (int m = 0; m < 16; m++) {
+    int r[4], lo = 0, hi = 0;
+    for (int c = 0; c < 4; c++) {
+      r[c] = ((off[c] % TB) + TB) % TB;
+      if (((m >> c) & 1) && r[c] > 0) r[c] -= TB;
+      lo = r[c] < lo ? r[c] : lo; hi = r[c] > hi ? r[c] : hi;
+    }
+    if (hi - lo < best) {
+      best = hi - lo; P->rmin = lo; P->rmax = hi;
+      for (int c = 0; c < 4; c++) { P->cr[c] = r[c]; P->cq[c] = (off[c] - r[c]) / TB; }
+    }
+  }
+}
 template <int TB, int NW, int RS, bool FULL>
-int cfar_launch_owner_tf(cfear_ctx* ctx, const CfarParams& P, int padl, const uint8_t* d_polar, size_t rows, int* seg_count, uint32_t* recs, uint32_t* hmask, hipStream_t stream) {
+int cfar_launch_owner_tf(cfear_ctx* ctx, const CfarParams& P0, int padl, const uint8_t* d_polar, size_t rows, int* seg_count, uint32_t* recs, uint32_t* hmask, hipStream_t stream) {
   constexpr int NT = 64 * NW;
-  constexpr size_t lds = cfar_owner_lds_bytes(TB, NW, RS);
+  CfarParams P = P0;
+  cfar_owner_offsets(&P, TB);
+  const size_t lds = cfar_owner_lds_bytes(TB + P.rmax - P.rmin, NW, RS);
   if (lds > 64 * 1024)
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_detect_owner_kernel<TB, NW, RS, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((160 * 1024) / (lds + 512));  // persistent workgroups: what a compute unit's LDS holds, up to 32 waves
