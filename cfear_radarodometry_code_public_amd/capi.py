@@ -236,7 +236,13 @@ class Context:
         TUNE_FILTER_CUS, TUNE_REPLAY_PERSISTENT_MAX, TUNE_REPEAT_SHORTCUT, TUNE_REGISTRATION_ORDER: results do not depend on them - and
         TUNE_MAX_CELLS, the cell capacity batched odometry objects created afterwards are sized for (an overflow is reported, never silent)"""
         self._check(self._L.cfear_tune(self._h, int(key), int(value)), "cfear_tune")
-        self._tuned[int(key)] = int(value)
+        # what the library holds after its clamps (csrc/cabi.hip cfear_tune), so that a later restore puts back a value the context really had
+        k, v = int(key), int(value)
+        clamp = {TUNE_FILTER_ROWS_PER_WAVE: lambda x: max(x, 0), TUNE_ODOMETRY_OVERLAP: lambda x: min(max(x, 0), 8), TUNE_FILTER_CUS: lambda x: max(x, 0),
+                 TUNE_REGISTRATION_ORDER: lambda x: int(x != 0), TUNE_MAX_CELLS: lambda x: max(x, 0), TUNE_REPEAT_SHORTCUT: lambda x: int(x != 0),
+                 TUNE_VOXEL_ORDER: lambda x: int(x == 1), TUNE_NN_TIE_RULE: lambda x: x if 0 <= x <= 2 else 0, TUNE_LARGE_SUBMAP_KERNEL: lambda x: x if 0 <= x <= 2 else 0,
+                 TUNE_REPLAY_PERSISTENT_MAX: lambda x: max(x, 0)}
+        self._tuned[k] = clamp.get(k, lambda x: x)(v)
 
     # ---- stage 1 ----
     def kstrongest_host(self, polar):
@@ -575,7 +581,9 @@ class Odometry:
         flag words instead of raising (bit 0 cells lost, bit 1 points lost)"""
         if per_sequence:
             out = np.zeros(self.B, dtype=np.int32)
-            self._ctx._L.cfear_odometry_status(self._ctx._h, self._h, out.ctypes.data)
+            rc = self._ctx._L.cfear_odometry_status(self._ctx._h, self._h, out.ctypes.data)
+            if rc not in (0, -6):  # (0 and CFEAR_ERR_CAPACITY are what the flag words describe; anything else - a HIP error, a failed join - is not)
+                self._ctx._check(rc, "cfear_odometry_status")
             return out
         self._ctx._check(self._ctx._L.cfear_odometry_status(self._ctx._h, self._h, None), "cfear_odometry_status")
 

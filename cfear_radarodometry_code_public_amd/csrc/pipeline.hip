@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BLOCK_R, 3) void get_cost_samples_kernel(ScanDev* c
   const size_t c = (size_t)cap;
   double* m = match_base + (size_t)b * 8 * c;
   W.tmx = m; W.tmy = m + c; W.a0 = m + 2 * c; W.a1 = m + 3 * c; W.a2 = m + 4 * c; W.sx = m + 5 * c; W.sy = m + 6 * c; W.w = m + 7 * c;
-  W.assoc = assoc_base + (size_t)b * c; W.cap = cap; W.acap = cap;
+  W.assoc = assoc_base + (size_t)b * 3 * c; W.cap = cap; W.acap = 3 * cap;
   W.red = reinterpret_cast<double*>(lds + RegLds::red_d);
   W.red_i = reinterpret_cast<int*>(lds + RegLds::red_i);
   get_cost_block(sp, n, my_poses, P, W, reinterpret_cast<double*>(lds + RegLds::par), reinterpret_cast<RegShared*>(lds + RegLds::regsh), itr,
@@ -936,6 +936,8 @@ static int register_impl(cfear_ctx* ctx, cfear_scan* const* scans, int n, double
   memcpy(poses_xyt, h_poses, sizeof(double) * 3 * n);
   if (cov6_last) memcpy(cov6_last, h_cov, sizeof(double) * 36);
   if (summary) memcpy(summary, ctx->h_stage + in_bytes, sizeof(cfear_reg_summary));
+  if (reinterpret_cast<const cfear_reg_summary*>(ctx->h_stage + in_bytes)->assoc_path < 0)  // (registration_dev.h: the kd descent's stack did not fit the match scratch)
+    return cfear_fail(ctx, CFEAR_ERR_UNSUPPORTED, "register: NN_TIE_RULE could not be honoured for this problem size (match scratch too small for the kd-tree descent); the result used the production rule");
   return CFEAR_OK;
 }
 
@@ -1093,7 +1095,7 @@ int cfear_cov_by_sampling(cfear_ctx* ctx, cfear_scan* const* scans, int n, const
       }
   // device buffers: poses, samples, scan pointers, costs, residual counts, per-sample match arrays
   const size_t bytes = sizeof(double) * (3 * (size_t)n + 3 * (size_t)m + (size_t)m) + sizeof(void*) * (size_t)n + sizeof(int) * (size_t)m +
-                       (sizeof(double) * 8 + sizeof(int)) * (size_t)m * cap + 256;
+                       (sizeof(double) * 8 + 3 * sizeof(int)) * (size_t)m * cap + 256;  // (three ints of association scratch per pair: the grouped path, as scratch_layout)
   unsigned char* d = nullptr;
   if (hipMalloc(&d, bytes) != hipSuccess) return cfear_fail(ctx, CFEAR_ERR_NOMEM, "hipMalloc cost samples");
   double* d_match = reinterpret_cast<double*>(d);
@@ -1683,6 +1685,10 @@ static int replay_check(cfear_ctx* ctx, cfear_odometry* o, const uint8_t* frames
   if (!ctx || !o || !frames || n_sweeps <= 0) return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: bad argument");
   if (!odo_shape_ok(ctx, o))
     return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: submap_scan_size / k_strongest / filter_type changed after odometry_create, or a parity mode (cfear_tune NN_TIE_RULE / VOXEL_ORDER) was switched under the object");
+  // CA-CFAR reads the images as dwords: every chunk of the replay starts a whole number of sweeps (of B images) after `frames`, so the base and the
+  // sweep size decide the alignment of all of them - refused here, before any chunk has advanced the sequences' state
+  if (o->filter == CFEAR_FILTER_CACFAR && ((reinterpret_cast<uintptr_t>(frames) & 3) != 0 || (n_sweeps > 1 && (((size_t)o->B * ctx->A * ctx->R) & 3) != 0)))
+    return cfear_fail(ctx, CFEAR_ERR_INVALID, "odometry_replay: filter_type CA-CFAR needs a 4-byte aligned recording and B * A * R a multiple of 4 (the detector reads whole dwords)");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return odo_join(ctx, o);
 }
@@ -1717,9 +1723,10 @@ static int odo_capacity_check(cfear_ctx* ctx, cfear_odometry* o, const char* wha
     return cfear_fail(ctx, CFEAR_ERR_CAPACITY, msg);
   }
   if (f & 1) {
-    char msg[256];
-    snprintf(msg, sizeof(msg), "%s: a scan produced more than %d oriented surface points (cfear_tune CFEAR_TUNE_MAX_CELLS): its first %d were kept, "
-             "the results of that sequence are those of a truncated scan", what, o->cap_cells, o->cap_cells);
+    char msg[400];
+    snprintf(msg, sizeof(msg), "%s: a scan produced more than %d oriented surface points (%s): its first %d were kept, the results of that sequence are those of a "
+             "truncated scan", what, o->cap_cells, ctx->tune_max_cells > 0 ? "cfear_tune CFEAR_TUNE_MAX_CELLS of this object" :
+             "the default of objects with more than 7 keyframes: min(points per scan, 4096); raise it with cfear_tune CFEAR_TUNE_MAX_CELLS before cfear_odometry_create", o->cap_cells);
     return cfear_fail(ctx, CFEAR_ERR_CAPACITY, msg);
   }
   return CFEAR_OK;

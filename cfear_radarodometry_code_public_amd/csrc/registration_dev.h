@@ -1109,8 +1109,11 @@ __device__ __forceinline__ int build_problem_block(ScanDev* const* scans, int n,
     int cnt = 0;
     for (int p = p0; p < p1; p++) {
       // (the kd descent's per-thread stack needs CFEAR_KD_STACK * 16 B * blockDim of the match arrays: 64 B per pair of capacity)
-      const int ti = (tie_rule != 0 && (size_t)sh->rw.cap * 64 >= (size_t)nt * CFEAR_KD_STACK * sizeof(KdVisit))
-                         ? associate_pair_rule(scans, src, sh, nsrc, p, curr_radius, tie_rule) : associate_pair(src, sh, nsrc, p, curr_radius);
+      // A parity mode that cannot be honoured is an error, not the production rule in disguise: assoc_path goes out negative and the host entry points refuse
+      // the result (CFEAR_ERR_UNSUPPORTED).
+      const bool rule_ok = tie_rule == 0 || (size_t)sh->rw.cap * 64 >= (size_t)nt * CFEAR_KD_STACK * sizeof(KdVisit);
+      if (!rule_ok) assoc_path = -3;
+      const int ti = (tie_rule != 0 && rule_ok) ? associate_pair_rule(scans, src, sh, nsrc, p, curr_radius, tie_rule) : associate_pair(src, sh, nsrc, p, curr_radius);
       sh->rw.assoc[p] = ti;
       cnt += (ti >= 0) ? 1 : 0;
     }

@@ -50,7 +50,7 @@ def run(oracle, T, kind, world_seed=0, seed=1, piece=250, params=None, device=0,
         t0 = time.time()
         for i in range(fill):
             if cfar:  # the oracle's detector (cfar.cpp:27-87; min_distance 2.5 as radar_driver.cpp:52-56 passes it), then the fuser on its cloud
-                e = fu.process_cloud(oracle.cfar(buf[i, 0], float(np.float32(kw["range_res"])), float(kw["z_min"]), 2.5, **cfar))
+                e = fu.process_cloud(oracle.cfar(buf[i, 0], float(np.float32(kw["range_res"])), float(kw["z_min"]), 2.5, prefix=cfar["window_size"] > 100, **cfar))  # (long windows: the prefix-sum twin, tests/test_cfar_cpu.py)
             else:
                 e = fu.process_polar(buf[i, 0])
             S = fu.last_summary()

@@ -16,6 +16,10 @@ PRESETS = {"s10_p2p": S10, "s10_p2d": dict(S10, cost=2), "s50_cfear3": dict(S10,
            "nocomp_p2p_k40": dict(cost=0, submap_scan_size=4, res=3.0, k_strongest=40, loss=1, loss_limit=0.1, weight_intensity=1, weight_opt=0, compensate=0),
            "res1_s3": dict(cost=1, submap_scan_size=3, res=1.0, k_strongest=12, loss=1, loss_limit=0.1, weight_intensity=1, weight_opt=0),
            # params/kstrong_vs_cfar/oxford-cfear-3-ca-cfar: the detector in front of the fuser (tests/test_cfar_odometry_gpu.py)
+           # round 6: CFEAR-3 as shipped (launch/oxford_demo:32-40: P2P, k = 40, four keyframes), for the street world (profiles/r06_world_realism.json)
+           "cfear3_k40_p2p": dict(k_strongest=40, cost=0, submap_scan_size=4, res=3.0, loss=1, loss_limit=0.1, weight_intensity=1, weight_opt=4),
+           "ca_cfar_w500": dict(z_min=20.0, cost=0, submap_scan_size=4, res=3.0, loss=1, loss_limit=0.1, weight_intensity=0, weight_opt=0, regularization=1.0, covar_scale=1.0,
+                                cfar=dict(window_size=500, nb_guard_cells=10, false_alarm_rate=0.0001)),
            "ca_cfar": dict(z_min=20.0, cost=0, submap_scan_size=4, res=3.0, loss=1, loss_limit=0.1, weight_intensity=0, weight_opt=0, regularization=1.0, covar_scale=1.0,
                            cfar=dict(window_size=40, nb_guard_cells=10, false_alarm_rate=0.01))}
 

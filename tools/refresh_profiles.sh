@@ -31,3 +31,8 @@ cd $R; timeout 300 python tools/gpu_time_cfar.py 2>&1 | grep -v amdgpu > $O/${P}
 for ps in cfear1 nocomp_p2p_k40 res1_s3; do timeout 900 python tests/run_drive_parity.py canyon ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_canyon_$ps.json $ps > /dev/null 2>&1; done
 timeout 900 python tests/run_drive_parity.py blocks 10000 $O/${P}_drive10k_blocks_cfear1.json cfear1 > /dev/null 2>&1
 for k in canyon blocks; do timeout 900 python tests/run_drive_parity.py $k ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_${k}_ca_cfar.json ca_cfar > /dev/null 2>&1; done  # (the oracle's literal detector: ~75 ms per sweep)
+# round 6: the street world (reflectivity fixed to the surfaces) with CFEAR-3 as shipped and the large-submap presets; the drop-in route; the CA-CFAR detector's counters
+for ps in cfear3_k40_p2p s10_p2p s50_cfear3; do timeout 900 python tests/run_drive_parity.py street ${DRIVE_SWEEPS_LARGE:-2000} $O/${P}_drive_street_$ps.json $ps > /dev/null 2>&1; done
+timeout 900 python tests/run_drive_parity.py street ${DRIVE_SWEEPS:-2000} $O/${P}_drive_street.json > /dev/null 2>&1
+timeout 300 python tools/gpu_dropin.py 2000 > $O/${P}_dropin_phases.txt 2>&1
+(bash $R/tools/pmc_cfar.sh) > $O/${P}_cfar_pmc.txt 2>&1
