@@ -597,6 +597,398 @@ __global__ __launch_bounds__(256, OCC) void kstrongest_kernel(const uint8_t* __r
   }
 }
 
+
+// ---- round 6: the same filter with the phases after the selection run for TWO rows at once ------------------------------------------------------
+// Per row (S-world, profiles/r05_k1_phases.txt) the kernel above issues 35 vector instructions for the load, 115 for the threshold search and the
+// masks, and 148 for what follows - candidates to lanes (80), ranking (27), suppression and emission (41) - wave-wide operations on the ~14 candidates
+// of a row in a 64-lane wave. Here a wave selects two consecutive rows (both rows' loads issued up front), and when both leave at most 32 candidates
+// the 148 run once for the pair: row A's candidates in lanes 0..31, row B's in lanes 32..63 - one packed prefix scan, the owner scan stopped at
+// the half (the two row broadcasts become one), the ranking loop over the longer of the two lists, one suppression pass. The price is a second LDS
+// window per wave (both rows' bytes must stay readable until the suppression): 38 KB per workgroup, four workgroups per unit instead of seven - which
+// is why both rows' loads go out before either is looked at. Rows that do not fit (more than 32 candidates, k > 32, a kept point within three bins
+// of a row end) take the one-row phases, written here once more as a lambda. Same results bit for bit (tests/test_kstrongest_gpu.py runs both).
+// Selected with CFEAR_K1_PAIR=1 (read once); measured against the kernel above in profiles/r06_k1_pair.txt.
+template <int NCH>
+__global__ __launch_bounds__(256, 4) void kstrongest_pair_kernel(const uint8_t* __restrict__ polar, uint32_t* __restrict__ slots, int A, int R,
+                                                                 long long n_rows, int u_zmin, int k, long long alloc_bytes, int rows_per_wave) {
+  constexpr int SUMBITS = NCH == 4 ? 7 : (NCH == 8 ? 8 : 9);
+  __shared__ uint4 lds_win[4][2][NCH * 64];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_keys[4][64];
+  __shared__ uint32_t lds_ge[20];
+  __shared__ uint32_t lds_cmp[4][(1 + NCH) * 64];  // per wave: slot offsets (both rows, 16 bits each) and the mask words of row A, then of row B
+  __shared__ uint8_t lds_nth[16 * 4];  // lds_nth[n * 4 + r] = position of the r-th set bit of nibble n (a nibble table: with the byte table of the kernel above
+                                       // the workgroup is 80 bytes over a quarter of the unit's LDS)
+  if (threadIdx.x <= 16) lds_ge[threadIdx.x] = chunk_range_mask((int)threadIdx.x, 16);
+  if (threadIdx.x < 16) {
+    const uint32_t b = threadIdx.x;
+    int r = 0;
+    for (int p = 0; p < 4; p++)
+      if ((b >> p) & 1u) lds_nth[b * 4 + r++] = (uint8_t)p;
+    for (; r < 4; r++) lds_nth[b * 4 + r] = 0;
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint8_t* const win0 = reinterpret_cast<uint8_t*>(&lds_win[wave][0][0]);
+  uint8_t* const win1 = reinterpret_cast<uint8_t*>(&lds_win[wave][1][0]);
+  uint32_t* const keys = &lds_keys[wave][0];
+  uint32_t* const cmp_ex = &lds_cmp[wave][0];
+  uint32_t* const cmp_w = &lds_cmp[wave][64];  // [NCH][64]: words 0 .. NCH/2-1 row A, NCH/2 .. NCH-1 row B
+  const long long scan_bytes = (long long)A * (long long)R;
+  const int Tfloor = u_zmin > 1 ? u_zmin : 1;
+  const long long g0 = ((long long)blockIdx.x * 4 + wave) * rows_per_wave;
+  long long g1 = g0 + rows_per_wave;
+  if (g1 > n_rows) g1 = n_rows;
+  int Tprev = Tfloor;
+
+  struct Row { long long g, scan; int bearing, head, c_lo, c_hi; bool edge_row; const uint8_t* wp; long long wstart_off; };
+  struct Sel { uint32_t w[NCH / 2]; int cnt, lo; };
+  auto row_of = [&](long long g) -> Row {
+    Row r;
+    r.g = g; r.scan = g / A; r.bearing = (int)(g - r.scan * A);
+    const long long row_off = g * (long long)R;
+    r.wstart_off = (row_off - 6) & ~15LL;
+    r.head = (int)(row_off - r.wstart_off);
+    r.c_lo = r.wstart_off >= 0 ? 0 : (int)((-r.wstart_off + 15) >> 4);
+    r.c_hi = (r.head + R + 6 + 15) >> 4;
+    const long long lim = (alloc_bytes - r.wstart_off + 15) >> 4;
+    if (lim < r.c_hi) r.c_hi = (int)lim;
+    r.edge_row = r.bearing == 0 || r.bearing == A - 1;
+    r.wp = polar + r.wstart_off;
+    return r;
+  };
+  // the row's chunks on their way (clamped addresses: no branch around the loads)
+  auto issue = [&](const Row& r, uint4 (&v)[NCH]) {
+    if (!r.edge_row && r.c_lo == 0) {
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int cc = min(j * 64 + lane, r.c_hi - 1);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r.wp + (uint32_t)(16 * cc)));
+        v[j] = make_uint4(t.x, t.y, t.z, t.w);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int cc = min(max(j * 64 + lane, r.c_lo), r.c_hi - 1);
+        v[j] = *reinterpret_cast<const uint4*>(r.wp + (uint32_t)(16 * cc));
+      }
+    }
+  };
+  // ... into the row's LDS window (scan-masked on the first / last row of an image), then the threshold search of the kernel above -> packed masks
+  auto select = [&](const Row& r, uint4 (&v)[NCH], uint8_t* win) -> Sel {
+    if (!r.edge_row && r.c_lo == 0) {
+#pragma unroll
+      for (int j = 0; j < NCH; j++) reinterpret_cast<uint4*>(win)[j * 64 + lane] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int c = j * 64 + lane;
+        if (c < r.c_lo || c >= r.c_hi) v[j] = make_uint4(0, 0, 0, 0);
+        uint4 staged = v[j];
+        if (r.edge_row) {
+          const long long ca = r.wstart_off + 16LL * c;
+          const long long slo = r.scan * scan_bytes - ca, shi = (r.scan + 1) * scan_bytes - ca;
+          if (slo > 0 || shi < 16) staged = chunk_keep(staged, (int)(slo > 16 ? 16 : slo), (int)(shi < 0 ? 0 : (shi > 16 ? 16 : shi)));
+        }
+        reinterpret_cast<uint4*>(win)[c] = staged;
+      }
+    }
+    const int head = r.head;
+    const int jt = (head + R - 1) >> 10;
+    int hb = head - 16 * lane, tb = head + R - 16 * (jt * 64 + lane);
+    hb = hb < 0 ? 0 : (hb > 16 ? 16 : hb);
+    tb = tb < 0 ? 0 : (tb > 16 ? 16 : tb);
+    const uint32_t vhead = lds_ge[hb];
+    const uint32_t vtail = (~lds_ge[tb] & 0x0F0F0F0Fu) & (jt == 0 ? vhead : 0x0F0F0F0Fu);
+    const uint32_t vtail2 = 0u;
+    wave_lds_fence();
+    int lo = Tprev;
+    uint32_t m[NCH];
+    int cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+    if (cnt < k && lo > Tfloor) {
+      lo = Tfloor;
+      int lm = lane_max_byte_regs<NCH>(v, vhead, jt, vtail);
+      if (lm < Tfloor) lm = 0;
+      int tl = 0, th = 256;
+      while (th - tl > 1) {
+        const int mid = (tl + th) >> 1;
+        if (__popcll(__ballot(lm >= mid)) >= k) tl = mid; else th = mid;
+      }
+      if (tl > lo) lo = tl;
+      cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+    }
+    if (cnt > 64 && lo < 255) {
+      int lm = lane_max_byte_regs<NCH>(v, vhead, jt, vtail);
+      int tl = lo, th = 256;
+      while (th - tl > 1) {
+        const int mid = (tl + th) >> 1;
+        if (__popcll(__ballot(lm >= mid)) >= k) tl = mid; else th = mid;
+      }
+      if (tl > lo) {
+        lo = tl;
+        cnt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo, m, vhead, jt, vtail, vtail2));
+      }
+    }
+    if (cnt > 64) {
+      int hi = 256;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        uint32_t mm[NCH];
+        const int c2 = wave_sum_small<SUMBITS>(count_mask<NCH>(v, mid, mm, vhead, jt, vtail, vtail2));
+        if (c2 >= k) {
+          lo = mid; cnt = c2;
+#pragma unroll
+          for (int j = 0; j < NCH; j++) m[j] = mm[j];
+          if (c2 <= 64) break;
+        } else {
+          hi = mid;
+        }
+      }
+    }
+    // (the next row starts one higher already when this one collected more than 24: the pair phases take rows of at most 32)
+    Tprev = (cnt > 24 && lo < 255) ? lo + 1 : lo;
+    if (cnt > 64) {
+      uint32_t mg[NCH];
+      const int c_gt = wave_sum_small<SUMBITS>(count_mask<NCH>(v, lo + 1, mg, vhead, jt, vtail, vtail2));
+      const int pstar = tie_position(win, head, R, lo, k - c_gt, lane);
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int bp = 16 * (j * 64 + lane) - head;
+        const int nb = pstar - bp;
+        const uint32_t keep = lds_ge[nb < 0 ? 0 : (nb > 16 ? 16 : nb)];
+        m[j] = mg[j] | (m[j] & ~mg[j] & keep);
+      }
+      cnt = k;
+    } else if (u_zmin == 0 && cnt < k && R > cnt && lo == 1) {
+      int need = k - cnt;
+      if (need > R - cnt) need = R - cnt;
+      const int pstar = tie_position(win, head, R, 0, need, lane);
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int bp = 16 * (j * 64 + lane) - head;
+        const uint32_t keep = chunk_range_mask(pstar - bp, R - bp);
+        m[j] |= (~m[j]) & 0x0F0F0F0Fu & keep;
+      }
+      cnt += need;
+    }
+    Sel s;
+    pack_masks<NCH>(m, s.w);
+    s.cnt = cnt; s.lo = lo;
+    return s;
+  };
+  // set bit number r of a lane's packed mask words -> window offset of that byte
+  auto bit_to_woff = [&](const uint32_t* words /* LDS: stride 64 */, int l, int r) -> uint32_t {
+    uint32_t sel = 0u;
+    int wi = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < NCH / 2; i++) {
+      const uint32_t wv = words[i * 64 + l];
+      const int ci = __popc(wv);
+      if (!found) {
+        if (r < ci) { sel = wv; wi = i; found = true; } else r -= ci;
+      }
+    }
+    int t = 0;
+    const uint32_t lo16 = sel & 0xFFFFu;
+    const int c16 = __popc(lo16);
+    if (r >= c16) { r -= c16; t = 16; sel >>= 16; } else sel = lo16;
+    const uint32_t lo8 = sel & 0xFFu;
+    const int c8 = __popc(lo8);
+    if (r >= c8) { r -= c8; t += 8; sel >>= 8; } else sel = lo8;
+    const uint32_t lo4 = sel & 0xFu;
+    const int c4 = __popc(lo4);
+    if (r >= c4) { r -= c4; t += 4; sel >>= 4; } else sel = lo4;
+    t += lds_nth[(sel & 0xFu) * 4 + r];
+    const int j = 2 * wi + ((t >> 2) & 1);
+    const int bi = 4 * (t & 3) + (t >> 3);
+    return (uint32_t)(16 * (j * 64 + l) + bi);
+  };
+  // 13-tap non-max suppression of one kept point (radar_filters.cpp:238-298) with all seven scores present (or masked by `covered`)
+  auto peak_of = [&](const uint8_t* win, int head, int mpos, bool mask_scores, uint32_t covered) -> uint32_t {
+    const int off0 = head + mpos - 6;
+    int bv[13];
+#pragma unroll
+    for (int t = 0; t < 13; t++) bv[t] = win[off0 + t];
+    int sm[7];
+    sm[0] = ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + bv[6]);
+#pragma unroll
+    for (int u = 1; u < 7; u++) sm[u] = sm[u - 1] - bv[u - 1] + bv[u + 6];
+    if (mask_scores) {
+#pragma unroll
+      for (int u = 0; u < 7; u++)
+        if (!((covered >> u) & 1u)) sm[u] = 0;
+    }
+    bool largest = true;
+#pragma unroll
+    for (int i = 1; i <= 3; i++)
+      if (sm[3 - i] > sm[3] || sm[3] < sm[3 + i]) largest = false;
+    return largest ? (1u << 25) : 0u;
+  };
+  // the one-row phases of the kernel above (candidates to lanes, ranking, suppression, emission) from a row's packed masks
+  auto finish_one = [&](const Row& r, const Sel& s, uint8_t* win) {
+    const int head = r.head, cnt = s.cnt;
+    const int C = cnt < 64 ? cnt : 64;
+    const int kk = k < C ? k : C;
+    uint32_t key = 0u;
+    {
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) c += __popc(s.w[i]);
+      const int ex = wave_inclusive_scan(c) - c;
+      keys[lane] = 0u;
+      cmp_ex[lane] = (uint32_t)ex;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) cmp_w[i * 64 + lane] = s.w[i];
+      wave_lds_fence();
+      if (c > 0 && ex < 64) keys[ex] = (uint32_t)(lane + 1);
+      wave_lds_fence();
+      const int owner = wave_inclusive_max((int)keys[lane]) - 1;
+      if (lane < C) {
+        const uint32_t woff = bit_to_woff(cmp_w, owner, lane - (int)cmp_ex[owner]);
+        key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
+      }
+    }
+    bool kept;
+    int rank = 0;
+    wave_lds_fence();
+    if (C > 2 * k) {
+      const uint32_t k24 = key & 0xFFFFFFu;
+      uint32_t klo = (uint32_t)s.lo << 16, khi = 256u << 16;
+      while (khi - klo > 1u) {
+        const uint32_t mid = (klo + khi) >> 1;
+        const int c = __popcll(__ballot(k24 >= mid));
+        if (c >= k) { klo = mid; if (c == k) break; } else khi = mid;
+      }
+      kept = k24 >= klo;
+      const unsigned long long keptb = __ballot(kept);
+      const int kpos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(keptb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)keptb, 0u));
+      if (kept) keys[kpos] = key;
+      if (lane >= kk && lane < kk + 4) keys[lane] = 0u;
+      wave_lds_fence();
+      for (int j = 0; j < kk; j += 4) {
+        const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
+        rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+      }
+    } else {
+      keys[lane] = key;
+      wave_lds_fence();
+      for (int j = 0; j < C; j += 4) {
+        const uint4 ka = reinterpret_cast<const uint4*>(keys)[j >> 2];
+        rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+      }
+      kept = lane < C && rank < kk;
+    }
+    const int mpos = (int)(key & 0xFFFFu);
+    uint32_t peak = 0;
+    const bool interior = mpos >= 3 && mpos < R - 3;
+    uint32_t covered = 0x7Fu;
+    const bool edge_points = __ballot(kept && !interior) != 0;
+    if (edge_points) {
+      if (R >= 24) {
+        const bool ik = kept && interior;
+        int marks = (ik && mpos <= 8) ? (1 << (mpos - 3)) : 0;
+        marks |= (ik && mpos >= R - 9) ? (1 << (6 + mpos - (R - 9))) : 0;
+        marks = __builtin_amdgcn_readlane(wave_inclusive_or(marks), 63);
+        uint32_t es = (uint32_t)marks & 0x3Fu, ee = ((uint32_t)marks >> 6) & 0x3Fu;
+        es |= es << 1; es |= es << 2; es |= es << 3;
+        ee |= ee << 1; ee |= ee << 2; ee |= ee << 3;
+        const uint32_t c_lo = ((es << 3) >> (mpos < 3 ? mpos : 0)) & 0x7Fu;
+        const uint32_t c_hi = (ee >> (mpos >= R - 3 ? mpos - R + 9 : 0)) & 0x7Fu;
+        covered = interior ? 0x7Fu : (mpos < 3 ? c_lo : c_hi);
+      } else {
+        covered = 0;
+        unsigned long long kb = __ballot(kept);
+        while (kb) {
+          const int i = __ffsll((long long)kb) - 1;
+          kb &= kb - 1;
+          const int mi = (int)(__builtin_amdgcn_readlane((int)key, i) & 0xFFFF);
+          if (mi >= 3 && mi < R - 3) {
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+              const int rr = mpos - 3 + t;
+              if (rr >= mi - 3 && rr <= mi + 3) covered |= 1u << t;
+            }
+          }
+        }
+      }
+    }
+    if (kept) peak = peak_of(win, head, mpos, edge_points, covered);
+    uint32_t* out = slots + r.g * (long long)k;
+    if (kept) out[kk - 1 - rank] = key | peak;
+    if (lane >= kk && lane < k) out[lane] = 0u;
+    wave_lds_fence();
+  };
+  // ... and for two rows of at most 32 candidates each at once: row A in lanes 0..31, row B in lanes 32..63. Returns false (nothing written) when a
+  // kept point sits within three bins of a row end: the caller runs the one-row phases then.
+  auto finish_two = [&](const Row& ra, const Sel& sa, const Row& rb, const Sel& sb) -> bool {
+    const int half = lane >> 5, slot = lane & 31;
+    const int C = half ? sb.cnt : sa.cnt, kk = k < C ? k : C, head = half ? rb.head : ra.head;
+    const uint8_t* win = half ? win1 : win0;
+    uint32_t key = 0u;
+    {
+      int ca = 0, cb = 0;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) { ca += __popc(sa.w[i]); cb += __popc(sb.w[i]); }
+      const int c2 = ca | (cb << 16);
+      const int ex2 = wave_inclusive_scan(c2) - c2;  // (both prefix sums in one scan: each stays below 2^16)
+      keys[lane] = 0u;
+      cmp_ex[lane] = (uint32_t)ex2;
+#pragma unroll
+      for (int i = 0; i < NCH / 2; i++) { cmp_w[i * 64 + lane] = sa.w[i]; cmp_w[(NCH / 2 + i) * 64 + lane] = sb.w[i]; }
+      wave_lds_fence();
+      if (ca > 0) keys[ex2 & 0xFFFF] = (uint32_t)(lane + 1);        // < 32: the row has at most 32 candidates
+      if (cb > 0) keys[32 + (ex2 >> 16)] = (uint32_t)(lane + 1);
+      wave_lds_fence();
+      int o = (int)keys[lane];  // owner scan inside the halves: the row steps and the broadcast into rows 1 and 3, not the one across the middle
+      o = dpp_max_i<0x111, 0xF>(o); o = dpp_max_i<0x112, 0xF>(o); o = dpp_max_i<0x114, 0xF>(o); o = dpp_max_i<0x118, 0xF>(o);
+      o = dpp_max_i<0x142, 0xA>(o);
+      const int owner = o - 1;
+      if (slot < C) {
+        const uint32_t e2 = cmp_ex[owner];
+        const uint32_t woff = bit_to_woff(cmp_w + (half ? (NCH / 2) * 64 : 0), owner, slot - (int)(half ? (e2 >> 16) : (e2 & 0xFFFFu)));
+        key = (woff - (uint32_t)head) | ((uint32_t)win[woff] << 16) | (1u << 24);
+      }
+    }
+    int rank = 0;
+    wave_lds_fence();
+    keys[lane] = key;  // lanes past a row's candidates hold key 0: smaller than any candidate
+    wave_lds_fence();
+    const int Cmax = sa.cnt > sb.cnt ? sa.cnt : sb.cnt;
+    for (int j = 0; j < Cmax; j += 4) {
+      const uint4 ka = reinterpret_cast<const uint4*>(keys)[(32 * half + j) >> 2];
+      rank += (ka.x > key) ? 1 : 0; rank += (ka.y > key) ? 1 : 0; rank += (ka.z > key) ? 1 : 0; rank += (ka.w > key) ? 1 : 0;
+    }
+    const bool kept = slot < C && rank < kk;
+    const int mpos = (int)(key & 0xFFFFu);
+    const bool interior = mpos >= 3 && mpos < R - 3;
+    if (__ballot(kept && !interior) != 0) { wave_lds_fence(); return false; }
+    const uint32_t peak = kept ? peak_of(win, head, mpos, false, 0x7Fu) : 0u;
+    uint32_t* out = slots + (half ? rb.g : ra.g) * (long long)k;
+    if (kept) out[kk - 1 - rank] = key | peak;
+    if (slot >= kk && slot < k) out[slot] = 0u;
+    wave_lds_fence();
+    return true;
+  };
+
+  // (Asking for the next pair's rows as soon as the registers are free - before the pair phases - was measured too: the loads have to be unconditional
+  // for the wait counters to stay countable, the rows past a wave's last are then read again, and at six rows per wave that is a third more traffic:
+  // 461 us against 417 us per 1536 scans, profiles/r06_k1_pair.txt.)
+  for (long long g = g0; g < g1; g += 2) {
+    const bool two = g + 1 < g1;
+    const Row ra = row_of(g), rb = row_of(two ? g + 1 : g);
+    uint4 va[NCH], vb[NCH];
+    issue(ra, va);
+    if (two) issue(rb, vb);
+    const Sel sa = select(ra, va, win0);
+    if (!two) { finish_one(ra, sa, win0); break; }
+    const Sel sb = select(rb, vb, win1);
+    if (sa.cnt <= 32 && sb.cnt <= 32 && k <= 32 && finish_two(ra, sa, rb, sb)) continue;
+    finish_one(ra, sa, win0);
+    finish_one(rb, sb, win1);
+  }
+}
 }  // namespace
 
 // Launch-shape knobs live in the context (cfear_tune, include/cfear_hip.h): occupancy variant and rows per wave.
@@ -624,6 +1016,12 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const long long blocks = (n_waves + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
   const int occ = ctx->tune_k1_occ;
+  static const bool pair = getenv("CFEAR_K1_PAIR") != nullptr && atoi(getenv("CFEAR_K1_PAIR")) != 0;  // the two-rows-at-once variant (A/B: tools/gpu_time_k1_pair.sh)
+  if (pair && R + 27 <= 4 * 1024) {
+    hipLaunchKernelGGL((kstrongest_pair_kernel<4>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+    return CFEAR_OK;
+  }
   if (R + 27 <= 4 * 1024) {
     if (occ >= 7)
       hipLaunchKernelGGL((kstrongest_kernel<4, 7>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
