@@ -36,3 +36,4 @@ for ps in cfear3_k40_p2p s10_p2p s50_cfear3; do timeout 900 python tests/run_dri
 timeout 900 python tests/run_drive_parity.py street ${DRIVE_SWEEPS:-2000} $O/${P}_drive_street.json > /dev/null 2>&1
 timeout 300 python tools/gpu_dropin.py 2000 > $O/${P}_dropin_phases.txt 2>&1
 (bash $R/tools/pmc_cfar.sh) > $O/${P}_cfar_pmc.txt 2>&1
+(bash $R/tools/gpu_time_k1_pair.sh) > /dev/null 2>&1   # -> ${O}/r06_k1_pair.txt (the two-rows-at-once filter variant against the production kernel)
