@@ -764,7 +764,13 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
   const ScanDev h = scan_header(s->d_block, cap, cap, true, ctx->tune_nn_tie == 2);
   ScanDev back;
   int* d_vorder = nullptr;
-  hipError_t e = hipMemcpyAsync(s->d_block, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream);  // h lives until the synchronize below
+  // the header goes in and comes back through the context's pinned staging (from / to the stack the two small copies are pageable: the runtime
+  // stages and waits for each - on the per-sweep route two of the ~15 host round trips of a sweep)
+  constexpr size_t HS = (sizeof(ScanDev) + 63) & ~(size_t)63;
+  rc = cfear_ensure_hstage(ctx, 2 * HS);
+  if (rc != CFEAR_OK) { cfear_pool_free(ctx, s->d_block, s->bytes); delete s; return rc; }
+  memcpy(ctx->h_stage, &h, sizeof(h));
+  hipError_t e = hipMemcpyAsync(s->d_block, ctx->h_stage, sizeof(h), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     const int capmax = cap > ctx->A * ctx->par.k_strongest ? cap : ctx->A * ctx->par.k_strongest;
     BlockScratch B = scratch_header(static_cast<unsigned char*>(ctx->d_scratch), capmax, (MAX_SCANS - 1) * capmax);
@@ -779,8 +785,9 @@ int cfear_scan_create(cfear_ctx* ctx, const cfear_cloud* cloud, cfear_scan** sca
     e = hipGetLastError();
   }
   // the reference exits on an empty cloud (pointnormal.cpp:72-75); report it instead
-  if (e == hipSuccess) e = hipMemcpyAsync(&back, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_stage + HS, s->d_block, sizeof(back), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) memcpy(&back, ctx->h_stage + HS, sizeof(back));
   if (d_vorder) (void)hipFree(d_vorder);
   if (e != hipSuccess) {
     cfear_pool_free(ctx, s->d_block, s->bytes);

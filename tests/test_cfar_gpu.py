@@ -72,6 +72,43 @@ def test_rows_of_clutter(oracle, R):
     run(img, oracle, zmin=20.0, window=500, guard=10, pfa=0.0001)
 
 
+def test_random_configurations_bit_exact(oracle):
+    """sixty random (row length, window, guard, false-alarm rate, static threshold, range gate) combinations on small images of three kinds - random bytes
+    with a comb, plateaus, a noise floor with blobs: every shape of the owner-layout detector (28 / 20 / 16 / 32 bins per thread, rows that are and are
+    not a whole number of segments), every choice of its integer scale and row offsets, windows longer than the row, and the round-5 kernels for rows
+    of odd length - against the oracle (its prefix-sum twin: tests/test_cfar_cpu.py holds that against the literal detector)"""
+    rng = np.random.default_rng(20260929)
+    ran = 0
+    for it in range(60):
+        R = int(rng.choice([64, 200, 776, 1000, 1792, 2048, 3360, 3584, 3768, 4096, 5000, 8000, 1001, 3361]))
+        A = int(rng.integers(3, 9))
+        window = int(rng.choice([1, 3, 10, 40, 70, 100, 150, 300, 500, 900]))
+        guard = int(rng.choice([0, 1, 5, 10, 20, 37]))
+        pfa = float(rng.choice([0.3, 0.1, 0.01, 0.001, 0.0001]))
+        zmin = float(rng.choice([0.0, 20.0, 60.0, 100.0]))
+        mind = float(rng.choice([0.0, 2.5, 30.0]))
+        kind = it % 3
+        if kind == 0:
+            img = rng.integers(0, 256, size=(A, R), dtype=np.uint8)
+            img[:, ::7] = np.minimum(img[:, ::7].astype(int) + 120, 255).astype(np.uint8)
+        elif kind == 1:
+            levels = np.array([0, 40, 40, 80, 120, 200], dtype=np.uint8)
+            img = np.ascontiguousarray(np.repeat(levels[rng.integers(0, len(levels), size=(A, R // 8 + 1))], 8, axis=1)[:, :R])
+        else:
+            img = np.clip(rng.normal(25.0, 8.0, size=(A, R)), 0, 255).astype(np.uint8)
+            for a in range(A):
+                for c in rng.integers(0, R, size=6):
+                    lo, hi = max(0, c - 3), min(R, c + 4)
+                    img[a, lo:hi] = np.maximum(img[a, lo:hi], rng.integers(90, 255))
+        ctx = capi.Context(capi.default_params(range_res=RR, z_min=zmin, min_distance=mind), A, R)
+        got = ctx.filter_cfar(img, window, guard, pfa).download()
+        exp = oracle.cfar(img, RR, zmin, mind, window, guard, pfa, prefix=True)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (it, R, A, window, guard, pfa, zmin, mind, kind, got.shape, exp.shape)
+        ran += len(exp) > 0
+        ctx.close()
+    assert ran > 30
+
+
 def test_world_sweep_host_and_device_entry_points(oracle):
     img = synth.world_scan(synth.World(7), 3, seed=2)
     n = run(img, oracle)
