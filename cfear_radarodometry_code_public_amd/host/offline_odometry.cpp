@@ -35,6 +35,9 @@ int main(int argc, char** argv) {
            "                      radar_driver.cpp:74-90) and go through the driver's cv::rotate first; --radar_ccw usually goes with it\n"
            "       [--soft_constraint 0] [--covar_sampling 0] [--covar_XY_sample_range 0.4] [--covar_yaw_sample_range 0.0043625]\n"
            "       [--covar_samples_per_axis 3] [--covar_sampling_scale 4]   (offline_odometry.cpp:166-178; --cov_file <path> writes the 36 values per sweep)\n"
+           "       [--pinned_frames 1]  the per-sweep route reads every sweep into ONE page-locked buffer (cfear_host_alloc) instead of pageable memory:\n"
+           "                      what a reader that owns its frame buffer can do (the image then goes to the device by DMA straight from it); a rosbag\n"
+           "                      message is a fresh pageable allocation per sweep - the default 0 measures that\n"
            "       [--replay 1]   whole recording through cfear_odometry_replay_host (pieces of 256 sweeps in pinned memory, no\n"
            "                      host round trip per sweep) instead of one CallbackOffline + pointcloudCallback per sweep\n");
     return argc < 2;
@@ -143,7 +146,11 @@ int main(int argc, char** argv) {
     }
     radarDriver driver(dev, rad_par, true);
     OdometryKeyframeFuser fuser(dev, par, true);
-    std::vector<uint8_t> img((size_t)A * R);
+    const bool pinned_frames = atoi(arg(argc, argv, "--pinned_frames", "0")) != 0;
+    std::vector<uint8_t> img_pageable(pinned_frames ? 0 : (size_t)A * R);
+    uint8_t* img_pinned = nullptr;
+    if (pinned_frames) dev->check(cfear_host_alloc(dev->ctx(), (size_t)A * R, reinterpret_cast<void**>(&img_pinned)), "cfear_host_alloc");
+    struct ImgView { uint8_t* p; size_t n; uint8_t* data() const { return p; } size_t size() const { return n; } } img{pinned_frames ? img_pinned : img_pageable.data(), (size_t)A * R};
     std::ofstream est(est_dir + "/est_00.txt");
     est << std::fixed; est.precision(6);
     std::ofstream covs;
@@ -177,6 +184,7 @@ int main(int argc, char** argv) {
     }
     std::cout << "frames " << n << ", with the file read: " << n / std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << " Hz\n"
               << CFEAR_TIMING.GetStatistics();
+    if (img_pinned) { cfear_synchronize(dev->ctx()); cfear_host_free(dev->ctx(), img_pinned); }
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << std::endl;
     return 3;

@@ -315,6 +315,7 @@ class radarDriver {
     const auto t1 = std::chrono::steady_clock::now();
     std::vector<int> n;
     DownloadInto(dev, {last_cloud_->h, last_peaks_->h}, {&xyi_[0], &xyi_[1]}, n);
+    CFEAR_TIMING.Document("driver: ... of which the wait and the copy out of the mirrors", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     cloud = cfear_make_cloud(); cloud_peaks = cfear_make_cloud();
     cfear_cloud_from_xyi(*cloud, xyi_[0].data(), (size_t)n[0]); cfear_cloud_from_xyi(*cloud_peaks, xyi_[1].data(), (size_t)n[1]);
     CloudTwins& tw = CloudTwins::instance();

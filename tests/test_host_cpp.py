@@ -51,6 +51,11 @@ def test_offline_odometry_matches_oracle(oracle, tmp_path):
         got = np.array([est[t, 3], est[t, 7], np.arctan2(est[t, 4], est[t, 0])])
         assert np.all(np.abs(got[:2] - exp[:2]) < 1e-4 + 5e-7), (t, got, exp)  # +5e-7: 6-decimal KITTI text
         assert abs(got[2] - exp[2]) < 1e-5 + 2e-6
+    # the same recording with every sweep read into one page-locked buffer (the image then goes to the device by DMA straight from it): the same file
+    os.makedirs(tmp_path / "p", exist_ok=True)
+    r = subprocess.run(args[:-1] + [str(tmp_path / "p"), "--pinned_frames", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "p" / "est_00.txt").read_text() == (tmp_path / "est_00.txt").read_text()
 
 
 @pytest.mark.gpu

@@ -16,9 +16,9 @@ subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
 with tempfile.TemporaryDirectory() as td:
     f = os.path.join(td, "sweeps.u8")
     imgs[idx].tofile(f)
-    for rep in range(2):
+    for rep in range(3):  # (the third run: every sweep read into one page-locked buffer - a reader that owns its frame buffer - instead of pageable memory)
         r = subprocess.run([os.path.join(host, "offline_odometry"), "--frames", f, "--azimuths", str(A), "--bins", str(R), "--range-res", str(float(rr)), "--res", "3.0",
-                            "--submap_scan_size", "4", "--z-min", "60", "--weight_option", "4", "--est_directory", td] + sys.argv[2:], capture_output=True, text=True)
+                            "--submap_scan_size", "4", "--z-min", "60", "--weight_option", "4", "--est_directory", td, "--pinned_frames", "1" if rep == 2 else "0"] + sys.argv[2:], capture_output=True, text=True)
         lines = r.stdout.splitlines()
-        print("run %d rc %d" % (rep, r.returncode)); print("\n".join(l for l in lines if "Frame: %d," % n in l or not l.startswith("Frame")))
+        print("run %d rc %d%s" % (rep, r.returncode, " (--pinned_frames 1)" if rep == 2 else "")); print("\n".join(l for l in lines if "Frame: %d," % n in l or not l.startswith("Frame")))
         if r.returncode: print(r.stderr)
