@@ -1012,11 +1012,12 @@ int cfear_launch_kstrongest(cfear_ctx* ctx, const uint8_t* d_polar, int n_scans,
   const int rows_cap = ctx->tune_k1_rows > 0 ? ctx->tune_k1_rows : (n_scans >= 1536 ? 6 : 4);
   if (rows_per_wave > rows_cap) rows_per_wave = rows_cap;
   if (rows_per_wave < 1) rows_per_wave = 1;
+  static const bool pair = getenv("CFEAR_K1_PAIR") != nullptr && atoi(getenv("CFEAR_K1_PAIR")) != 0;  // the two-rows-at-once variant (A/B: tools/gpu_time_k1_pair.sh)
+  if (pair && rows_per_wave < 2) rows_per_wave = 2;  // (small launches too: a wave of the variant wants a pair)
   const long long n_waves = (n_rows + rows_per_wave - 1) / rows_per_wave;
   const long long blocks = (n_waves + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
   const int occ = ctx->tune_k1_occ;
-  static const bool pair = getenv("CFEAR_K1_PAIR") != nullptr && atoi(getenv("CFEAR_K1_PAIR")) != 0;  // the two-rows-at-once variant (A/B: tools/gpu_time_k1_pair.sh)
   if (pair && R + 27 <= 4 * 1024) {
     hipLaunchKernelGGL((kstrongest_pair_kernel<4>), grid, block, 0, stream, d_polar, d_slots, A, R, n_rows, u_zmin, k, alloc, rows_per_wave);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());

@@ -125,3 +125,17 @@ def test_kept_points_at_the_row_ends(oracle, R, k):
             pos = pos[(pos >= 0) & (pos < R)]
             img[a, pos] = rng.integers(120, 256, size=len(pos)) if a % 2 else 200  # distinct intensities / ties
     run_case(oracle, img, k, 60)
+
+
+def test_two_rows_at_once_variant_is_bit_exact(tmp_path):
+    """kstrongest_pair_kernel (csrc/kstrongest.hip, round 6: the phases after the selection once per pair of rows; off by default because it is slower -
+    DESIGN.md Appendix A.1) is selected by CFEAR_K1_PAIR=1, read once per process: a child process runs this file's bit-exactness cases under the switch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CFEAR_K1_PAIR="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kstrongest_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "not two_rows_at_once", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
