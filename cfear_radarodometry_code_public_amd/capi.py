@@ -314,6 +314,11 @@ class Context:
         m = np.asarray(motion_xyt, dtype=np.float64).copy()
         self._check(self._L.cfear_compensate(self._h, cloud._h, m.ctypes.data, int(ccw)), "cfear_compensate")
 
+    def compensate_pair(self, cloud, cloud_peaks, motion_xyt, ccw):
+        """cfear_compensate_pair: a sweep's two clouds by the same motion in one launch (odometrykeyframefuser.cpp:148-149)"""
+        m = np.asarray(motion_xyt, dtype=np.float64).copy()
+        self._check(self._L.cfear_compensate_pair(self._h, cloud._h, cloud_peaks._h, m.ctypes.data, int(ccw)), "cfear_compensate_pair")
+
     # ---- stage 2 (MapPointNormal) ----
     def scan_create(self, cloud):
         s = C.c_void_p()

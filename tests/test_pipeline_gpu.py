@@ -56,6 +56,18 @@ def test_cloud_matches_oracle(oracle, seq):
             ulp = np.spacing(np.abs(e2[:, :2]).astype(np.float32))
             assert np.all(np.abs(g2[:, :2] - e2[:, :2]) <= ulp)
             assert np.mean(g2[:, :2] != e2[:, :2]) < 1e-3
+            # both clouds of the sweep in one launch (cfear_compensate_pair): what two single calls give, bit for bit - through the clouds' host mirrors
+            # (the filter's own clouds) and through the copy route (an uploaded one)
+            a, b = ctx.filter_polar(imgs[t])
+            a1, b1 = ctx.filter_polar(imgs[t])
+            ctx.compensate_pair(a, b, mot, ccw)
+            ctx.compensate(a1, mot, ccw); ctx.compensate(b1, mot, ccw)
+            assert np.array_equal(a.download(), a1.download()) and np.array_equal(b.download(), b1.download())
+            assert np.array_equal(a.download(), g2)
+            u = ctx.cloud_upload(expp)
+            ctx.compensate_pair(c2, u, mot, ccw)  # (c2 a second time: the motion applies again)
+            ctx.compensate(a1, mot, ccw)
+            assert np.array_equal(c2.download(), a1.download()) and np.array_equal(u.download(), b1.download())
     ctx.close()
 
 
