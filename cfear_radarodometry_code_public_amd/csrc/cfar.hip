@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, NW == 2 ? 3 : 1) void cfar_detect_owner_ke
       }
     }
     h &= vmask;
-    if (P.stop == 2) { prev_total = h == 0xFFFFFFFFu ? 0 : -1; return; }
+    if (P.stop == 2) { prev_total = (h ^ (uint32_t)nq[0]) == 0x12345u ? 0 : -1; return; }  // (a condition the compiler cannot decide: with `h == ~0u` - h has 28 bits - it moved the whole test behind this return)
     // ---- what it leaves, in bin order: one lane per candidate decides, the hits close ranks ----
     const int c = __popc(h);
     int total = 0;
