@@ -612,8 +612,7 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_emit_recs_kernel(const uint8_
     const double cos_t = trig[2 * az], sin_t = trig[2 * az + 1];  // theta = (az + 1) / A * 2 pi, host libm (cfar.cpp:40)
     float* out = xyi + 3 * (size_t)img * cap;  // image i writes at most `cap` points at xyi + i * cap * 3
     const uint32_t* rr = recs + (size_t)gs * CFAR_SEG_CAP;
-    for (int k = 0; k < c; k++) {
-      const uint32_t rec = rr[k];
+    auto put = [&](uint32_t rec, int k) __attribute__((always_inline)) {
       const int o = base + k;
       if (o < cap) {
         const double range = P.range_res * (double)(rec & 0xFFFFu);
@@ -621,7 +620,16 @@ __global__ __launch_bounds__(CFAR_BLOCK) void cfar_emit_recs_kernel(const uint8_
         out[3 * (size_t)o + 1] = (float)(range * sin_t);
         out[3 * (size_t)o + 2] = (float)(rec >> 16);
       }
-    }
+    };
+    // the first eight slots of the segment in one round trip (a segment holds four or five records on the reference's preset; the slots exist whether
+    // written or not, and a slot is 8-byte aligned for every shape), the rest one by one
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2* r2 = reinterpret_cast<const u32x2*>(rr);
+    const u32x2 p0 = r2[0], p1 = r2[1], p2 = r2[2], p3 = r2[3];
+    const uint32_t first[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < c) put(first[k], k);
+    for (int k = 8; k < c; k++) put(rr[k], k);
   }
   unsigned long long ov = __builtin_amdgcn_ballot_w64((craw & CFAR_SEG_MASKS) != 0);
   while (ov) {
